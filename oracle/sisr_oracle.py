@@ -1,0 +1,403 @@
+"""CPU oracle for the SISR residual-conv + channel/meta-attention hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a functional, plain-PyTorch (fp32, CPU)
+restatement of the reference's forward passes for the path SURVEY.md §8 names.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+it; the product package never does and fails loudly without its HIP library.
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks every function here
+against golden vectors produced by running the *imported reference itself* in
+the build container (tools/make_fixtures.py -> tests/golden/*.npz).
+
+Style: stateless functions over a flat ``{reference state_dict key: tensor}``
+mapping, so a reference checkpoint (``state['network']``) drives it directly and
+autograd on those tensors yields the reference's parameter gradients.  The
+arithmetic semantics relied upon are PyTorch's (the reference's only numeric
+dependency, requirements.txt:1): zero-padded cross-correlation, mean pooling,
+PixelShuffle channel order, Softmax(dim=-1), L1Loss(mean), Adam.
+
+All ``ref:`` citations are relative to /root/reference/Code/.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- primitives
+def conv(sd, key, x):
+    """ref: SISR/models/advanced/common.py:5-8 (default_conv): k x k, pad k//2, bias."""
+    w = sd[key + ".weight"]
+    return F.conv2d(x, w, sd.get(key + ".bias"), padding=w.shape[-1] // 2)
+
+
+def _fc(sd, key, v):
+    """1x1 conv on a (B,C,1,1) vector == dense layer; kept as conv2d to share ATen path."""
+    return F.conv2d(v, sd[key + ".weight"], sd[key + ".bias"])
+
+
+def gap(x):
+    """ref: advanced/architectures.py:21 nn.AdaptiveAvgPool2d(1)."""
+    return F.adaptive_avg_pool2d(x, 1)
+
+
+def upsampler(sd, key, x, scale):
+    """ref: advanced/common.py:20-45: [conv C->4C, PixelShuffle(2)] x log2(scale) or conv C->9C + PS(3).
+    No activation, no BN on every in-scope model (act=False)."""
+    if scale & (scale - 1) == 0:
+        for i in range(int(math.log2(scale))):
+            x = F.pixel_shuffle(conv(sd, f"{key}.{2 * i}", x), 2)
+        return x
+    if scale == 3:
+        return F.pixel_shuffle(conv(sd, f"{key}.0", x), 3)
+    raise NotImplementedError(scale)
+
+
+# ----------------------------------------------------------------------------- attention gates
+def ca_gate(sd, key, x):
+    """sigmoid(W2 relu(W1 gap(x))) -> (B,C,1,1).  ref: advanced/architectures.py:23-31."""
+    y = F.relu(_fc(sd, key + ".conv_du.0", gap(x)))
+    return torch.sigmoid(_fc(sd, key + ".conv_du.2", y))
+
+
+def ca_layer(sd, key, x):
+    """ref: advanced/architectures.py:13-32 CALayer.forward."""
+    return x * ca_gate(sd, key, x)
+
+
+def para_ca_gate(sd, key, attributes, nonlinearity, num_layers=2):
+    """Meta-attention gate.  ref: attention_manipulators/q_layer.py:20-43.
+    Layer list is [conv, (relu,)]* + sigmoid, so conv indices depend on ``nonlinearity``."""
+    y = attributes
+    idx = 0
+    multiplier = num_layers
+    for _ in range(num_layers):
+        y = _fc(sd, f"{key}.attribute_integrator.{idx}", y)
+        idx += 1
+        if nonlinearity and multiplier != 1:
+            y = F.relu(y)
+            idx += 1
+        multiplier -= 1
+    return torch.sigmoid(y)
+
+
+def para_ca_layer(sd, key, x, attributes, nonlinearity, num_layers=2):
+    """ref: q_layer.py:39-43."""
+    return x * para_ca_gate(sd, key, attributes, nonlinearity, num_layers)
+
+
+def para_ca_widths(channels, num_metadata, num_layers=2):
+    """FC widths [M, h1, ..., C].  ref: q_layer.py:22-31 (M>15 uses the offset formula)."""
+    widths = [num_metadata]
+    mult = num_layers
+    for _ in range(num_layers):
+        if num_metadata > 15:
+            widths.append((channels - num_metadata) // mult + num_metadata)
+        else:
+            widths.append(channels // mult)
+        mult -= 1
+    return widths
+
+
+def qca_layer(sd, key, x, attributes, style):
+    """Six-style combined channel/meta attention.  ref: attention_manipulators/architectures.py:105-127."""
+    y = gap(x)
+    if style == "standard":
+        y = torch.sigmoid(_fc(sd, key + ".conv_du.2", F.relu(_fc(sd, key + ".conv_du.0", y))))
+    elif style == "modulate":
+        y = torch.sigmoid(_fc(sd, key + ".conv_du.2", F.relu(_fc(sd, key + ".conv_du.0", y)))) * attributes
+    elif style in ("max_concat", "softmax"):
+        y = torch.cat((y, attributes), dim=1)
+        y = torch.sigmoid(_fc(sd, key + ".conv_du.2", F.relu(_fc(sd, key + ".conv_du.0", y))))
+        if style == "softmax":
+            y = torch.softmax(y, dim=1)
+    elif style == "mini_concat":
+        y = _fc(sd, key + ".pre_concat", y)
+        y = torch.cat((y, attributes), dim=1)
+        # conv_du = [ReLU, conv, Sigmoid]: the ReLU also hits the concatenated metadata
+        y = torch.sigmoid(_fc(sd, key + ".conv_du.1", F.relu(y)))
+    elif style == "extended_attention":
+        for i in range(3):
+            y = F.relu(_fc(sd, f"{key}.feature_convs.{i}.0", torch.cat((y, attributes), dim=1)))
+        y = torch.sigmoid(_fc(sd, key + ".final_conv.0", y))
+    else:
+        raise NotImplementedError(style)
+    return x * y
+
+
+def pa_layer(sd, key, x):
+    """Per-pixel attention 64->8->1.  ref: attention_manipulators/architectures.py:13-26."""
+    y = F.relu(F.conv2d(x, sd[key + ".pa.0.weight"], sd[key + ".pa.0.bias"]))
+    y = torch.sigmoid(F.conv2d(y, sd[key + ".pa.2.weight"], sd[key + ".pa.2.bias"]))
+    return x * y
+
+
+# ----------------------------------------------------------------------------- blocks
+def res_block(sd, key, x, res_scale):
+    """ref: advanced/common.py:68-72: x + res_scale * conv(relu(conv(x)))."""
+    r = conv(sd, key + ".body.2", F.relu(conv(sd, key + ".body.0", x)))
+    return r * res_scale + x
+
+
+def rcab(sd, key, x):
+    """ref: advanced/architectures.py:68-71.  res_scale is stored but never applied."""
+    r = conv(sd, key + ".body.2", F.relu(conv(sd, key + ".body.0", x)))
+    return ca_layer(sd, key + ".body.3", r) + x
+
+
+def residual_group(sd, key, x, n_resblocks):
+    """ref: advanced/architectures.py:107-110."""
+    r = x
+    for i in range(n_resblocks):
+        r = rcab(sd, f"{key}.body.{i}", r)
+    return conv(sd, f"{key}.body.{n_resblocks}", r) + x
+
+
+def qrcab(sd, key, x, md, style, pa, q_layer):
+    """ref: attention_manipulators/architectures.py:172-180."""
+    r = conv(sd, key + ".body.2", F.relu(conv(sd, key + ".body.0", x)))
+    r = qca_layer(sd, key + ".final_body", r, md, style)
+    if pa:
+        r = pa_layer(sd, key + ".pa_node", r)
+    if q_layer:
+        r = para_ca_layer(sd, key + ".q_node", r, md, nonlinearity=True)
+    return r + x
+
+
+def q_residual_group(sd, key, x, md, n_resblocks, style, pa, q_layer, num_q_layers):
+    """ref: attention_manipulators/architectures.py:215-233."""
+    r = x
+    for i in range(n_resblocks):
+        q_in = q_layer if (num_q_layers is None or i < num_q_layers) else False
+        r = qrcab(sd, f"{key}.body.{i}", r, md, style, pa, q_in)
+    return conv(sd, key + ".final_body", r) + x
+
+
+def param_res_block(sd, key, x, md, res_scale, q_layer_nonlinearity):
+    """ref: attention_manipulators/architectures.py:348-356."""
+    r = conv(sd, key + ".body.2", F.relu(conv(sd, key + ".body.0", x))) * res_scale
+    return para_ca_layer(sd, key + ".attention_layer", r, md, q_layer_nonlinearity) + x
+
+
+def lam_module(sd, key, x):
+    """Layer attention.  x: (B,N,C,H,W) -> (B,N*C,H,W).  ref: advanced/HAN_blocks.py:16-37."""
+    b, n, c, h, w = x.shape
+    q = x.reshape(b, n, -1)
+    energy = torch.bmm(q, q.transpose(1, 2))
+    energy = energy.max(dim=-1, keepdim=True)[0] - energy
+    att = torch.softmax(energy, dim=-1)
+    out = torch.bmm(att, q).reshape(b, n, c, h, w)
+    out = sd[key + ".gamma"] * out + x
+    return out.reshape(b, n * c, h, w)
+
+
+def csam_module(sd, key, x):
+    """Channel-spatial attention.  ref: advanced/HAN_blocks.py:51-76 (Conv3d 1->1, k3, pad1)."""
+    att = torch.sigmoid(F.conv3d(x.unsqueeze(1), sd[key + ".conv.weight"], sd[key + ".conv.bias"], padding=1))
+    att = (sd[key + ".gamma"] * att).reshape(x.shape)
+    return x * att + x
+
+
+# ----------------------------------------------------------------------------- whole nets
+def rcan(sd, x, n_resgroups=10, n_resblocks=20, scale=4):
+    """ref: advanced/architectures.py:156-161."""
+    h = conv(sd, "head.0", x)
+    r = h
+    for g in range(n_resgroups):
+        r = residual_group(sd, f"body.{g}", r, n_resblocks)
+    r = conv(sd, f"body.{n_resgroups}", r) + h
+    return conv(sd, "tail.1", upsampler(sd, "tail.0", r, scale))
+
+
+def edsr(sd, x, num_blocks=16, scale=4, res_scale=0.1):
+    """ref: advanced/architectures.py:219-225."""
+    h = conv(sd, "head.0", x)
+    r = h
+    for i in range(num_blocks):
+        r = res_block(sd, f"body.{i}", r, res_scale)
+    r = conv(sd, f"body.{num_blocks}", r) + h
+    return conv(sd, "tail.1", upsampler(sd, "tail.0", r, scale))
+
+
+def _han_tail(sd, h, layers, scale):
+    """Shared HAN/QHAN epilogue.  ``layers`` oldest-first; the reference stacks newest-first
+    (advanced/architectures.py:359-362) and feeds the *last* map to CSAM."""
+    res1 = torch.stack(layers[::-1], dim=1)
+    out2 = conv(sd, "last_conv", lam_module(sd, "la", res1))
+    out1 = csam_module(sd, "csa", layers[-1])
+    r = conv(sd, "last", torch.cat([out1, out2], 1)) + h
+    return conv(sd, "tail.1", upsampler(sd, "tail.0", r, scale))
+
+
+def han(sd, x, n_resgroups=10, n_resblocks=20, scale=4):
+    """ref: advanced/architectures.py:352-377."""
+    h = conv(sd, "head.0", x)
+    r = h
+    layers = []
+    for g in range(n_resgroups):
+        r = residual_group(sd, f"body.{g}", r, n_resblocks)
+        layers.append(r)
+    r = conv(sd, f"body.{n_resgroups}", r)
+    layers.append(r)
+    return _han_tail(sd, h, layers, scale)
+
+
+def qrcan(sd, x, md, n_resgroups=10, n_resblocks=20, scale=4, style="modulate", include_pixel_attention=False,
+          include_q_layer=False, selective_meta_blocks=None, num_q_layers_inner_residual=None):
+    """ref: attention_manipulators/architectures.py:285-316."""
+    h = conv(sd, "head.0", x)
+    r = h
+    for g in range(n_resgroups):
+        q = include_q_layer if (selective_meta_blocks is None or selective_meta_blocks[g]) else False
+        r = q_residual_group(sd, f"body.{g}", r, md, n_resblocks, style, include_pixel_attention, q,
+                             num_q_layers_inner_residual)
+    r = conv(sd, "final_body", r) + h
+    return conv(sd, "tail.1", upsampler(sd, "tail.0", r, scale))
+
+
+def qedsr(sd, x, md, num_blocks=16, scale=4, res_scale=0.1, q_layer_nonlinearity=False):
+    """ref: attention_manipulators/architectures.py:392-399 (head is a bare conv: key 'head')."""
+    h = conv(sd, "head", x)
+    r = h
+    for i in range(num_blocks):
+        r = param_res_block(sd, f"body.{i}", r, md, res_scale, q_layer_nonlinearity)
+    r = conv(sd, "final_body", r) + h
+    return conv(sd, "tail.1", upsampler(sd, "tail.0", r, scale))
+
+
+def qhan(sd, x, md, n_resgroups=10, n_resblocks=20, scale=4, num_q_layers_inner_residual=None):
+    """ref: attention_manipulators/architectures.py:512-540 (style 'standard', q-layer on, no PA)."""
+    h = conv(sd, "head.0", x)
+    r = h
+    layers = []
+    for g in range(n_resgroups):
+        r = q_residual_group(sd, f"body.{g}", r, md, n_resblocks, "standard", False, True,
+                             num_q_layers_inner_residual)
+        layers.append(r)
+    r = conv(sd, f"body.{n_resgroups}", r)
+    layers.append(r)
+    return _han_tail(sd, h, layers, scale)
+
+
+NETS = {"rcan": rcan, "edsr": edsr, "han": han, "qrcan": qrcan, "qedsr": qedsr, "qhan": qhan}
+META_NETS = ("qrcan", "qedsr", "qhan")
+
+
+def forward(name, sd, x, metadata=None, **cfg):
+    """Dispatch by registry name (ref: SISR/models/__init__.py:26-30 lower-cased handler names)."""
+    if name in META_NETS:
+        return NETS[name](sd, x, metadata, **cfg)
+    return NETS[name](sd, x, **cfg)
+
+
+# ----------------------------------------------------------------------------- host-side metadata logic
+def num_metadata(metadata_list):
+    """ref: attention_manipulators/__init__.py:13-24."""
+    if metadata_list is None:
+        return 1
+    n = len(metadata_list)
+    if "all" in metadata_list:
+        n += 39
+    if "blur_kernel" in metadata_list:
+        n += 9
+    elif "unmodified_blur_kernel" in metadata_list:
+        n += 440
+    return n
+
+
+def generate_channels(batch_size, metadata, keys, metadata_list, n_meta):
+    """(B,M) collated metadata (+ key tuples) -> fp32 (B,n_meta,1,1).  ref: attention_manipulators/__init__.py:30-51.
+    ``keys`` is default_collate's list[M] of B-tuples; the mask is built from sample 0's key."""
+    if metadata is None:
+        raise RuntimeError("Metadata needs to be specified for this network to run properly.")
+    md = torch.as_tensor(np.asarray(metadata))
+    if "all" in metadata_list:
+        mask = torch.ones(n_meta, dtype=torch.bool)
+    else:
+        mask = torch.tensor([k[0] in metadata_list for k in keys], dtype=torch.bool)
+    out = torch.ones(batch_size, n_meta)
+    for i in range(batch_size):
+        row = md[i] if len(keys) == 1 else md[i][mask]
+        out[i] = out[i] * row  # float64 row promoted then stored into the fp32 buffer
+    return out[:, :, None, None]
+
+
+def scale_qpi(qpi, n_feats=64, min_mu=-0.2, max_mu=0.8, sig=0.2, clamp=False):
+    """'modulate' style: scalar -> n_feats-bin Gaussian.  ref: attention_manipulators/handlers.py:38-54."""
+    mu = qpi * (max_mu - min_mu) + min_mu
+    base = np.linspace(0, 1, n_feats)
+    rows = []
+    for i in range(mu.shape[0]):
+        m = mu[i].squeeze().numpy()
+        rows.append(torch.from_numpy((1 / (np.sqrt(2 * np.pi) * sig)) * np.exp(-np.power(base - m, 2.0) /
+                                                                              (2 * np.power(sig, 2.0)))).float())
+    full = torch.stack(rows)
+    if clamp:
+        full = torch.clamp(full, 0, 1)
+    return full[:, :, None, None]
+
+
+# ----------------------------------------------------------------------------- metric
+def rgb_to_y(img):
+    """BT.601 'jpg' luma, no offset.  ref: sr_tools/image_manipulation.py:65-70."""
+    return 0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2]
+
+
+def psnr(a, b, max_value=1.0):
+    """ref: sr_tools/metrics.py:6-17 (float32 mse, 100 when identical)."""
+    mse = np.mean((np.array(a, dtype=np.float32) - np.array(b, dtype=np.float32)) ** 2)
+    if mse == 0:
+        return 100
+    return 20 * np.log10(max_value / np.sqrt(mse))
+
+
+def y_psnr(sr, hr):
+    """Eval protocol: clip to [0,1], Y of each, PSNR(max=1).  ref: SISR/models/__init__.py:158-169,
+    training_handler.py:179-224 / standard_eval.py:262-294."""
+    sr = np.clip(np.asarray(sr), 0, 1)
+    return psnr(rgb_to_y(sr), rgb_to_y(np.asarray(hr)), max_value=1)
+
+
+# ----------------------------------------------------------------------------- train step
+class Trainer:
+    """Functional mirror of BaseModel.run_train/standard_update (ref: SISR/models/__init__.py:466-489,
+    :299-335): L1Loss(mean) -> zero_grad -> backward -> [clip_grad_norm_] -> Adam.step -> scheduler.step
+    (scheduler stepped per *batch*)."""
+
+    def __init__(self, name, state_dict, lr=1e-4, scheduler=None, scheduler_params=None, grad_clip=None,
+                 betas=(0.9, 0.999), **cfg):
+        self.name, self.cfg = name, cfg
+        self.sd = {k: v.detach().clone().float().requires_grad_(True) for k, v in state_dict.items()}
+        self.opt = torch.optim.Adam(list(self.sd.values()), lr=lr, betas=betas)
+        self.sched = None
+        if scheduler == "cosine_annealing_warm_restarts":
+            self.sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(
+                self.opt, T_0=scheduler_params["restart_period"], T_mult=scheduler_params["t_mult"],
+                eta_min=scheduler_params["lr_min"])
+        elif scheduler == "multi_step_lr":
+            self.sched = torch.optim.lr_scheduler.MultiStepLR(
+                self.opt, milestones=scheduler_params["milestones"], gamma=scheduler_params["gamma"])
+        elif scheduler == "step_lr":
+            self.sched = torch.optim.lr_scheduler.StepLR(
+                self.opt, step_size=scheduler_params["step_size"], gamma=scheduler_params["gamma"])
+        elif scheduler is not None:
+            raise RuntimeError("%s scheduler not implemented" % scheduler)
+        self.grad_clip = grad_clip or None
+
+    def step(self, x, y, metadata=None):
+        out = forward(self.name, self.sd, x, metadata, **self.cfg)
+        loss = F.l1_loss(out, y)
+        self.opt.zero_grad()
+        loss.backward()
+        if self.grad_clip is not None:
+            torch.nn.utils.clip_grad_norm_(list(self.sd.values()), self.grad_clip)
+        gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in self.sd.values())).item()  # post-clip
+        self.opt.step()
+        if self.sched is not None:
+            self.sched.step()
+        return loss.item(), out.detach(), gnorm
+
+    @property
+    def lr(self):
+        return self.opt.param_groups[0]["lr"]
