@@ -1,0 +1,114 @@
+/* libsisr_hip.so -- C ABI of the MI355X (gfx950) SISR forward/backward kernels.
+ *
+ * Drop-in boundary.  The reference has no FFI: its hot path is the nn.Module tree built by the
+ * model handlers (Code/SISR/models/advanced/architectures.py, attention_manipulators/architectures.py)
+ * and executed by BaseModel.run_train / run_eval (Code/SISR/models/__init__.py:466-522).  Each entry
+ * point below replaces the ATen kernels one of those modules dispatches to; the citation on each
+ * function names the reference module.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *  - The caller owns every buffer (device pointers unless stated); nothing here allocates, frees,
+ *    synchronises or throws.  Workspaces are sized by the *_workspace_bytes() queries.
+ *  - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *  - Return 0 on success, negative on error: -1 bad argument, -2 misaligned pointer/stride
+ *    (16-byte alignment is required for activations), -3-16*hipError launch failure, -4 unsupported
+ *    shape (channel counts must be multiples of 64 on the matrix-core kernels).
+ *  - Re-entrant and thread-safe: no global state.
+ *  - fp32 everywhere.  Activations are NHWC in 64-channel chunks described by a 6-element int64
+ *    "view": {sB, sH, sW, chi, clo, cdiv}; element (b,h,w,chunk q,c) is at
+ *        base + b*sB + h*sH + w*sW + (q / cdiv)*chi + (q % cdiv)*clo + c        (strides in floats)
+ *    Plain NHWC with C channels: {H*W*C, W*C, C, 0, 64, 1<<30}.  The output of
+ *    conv(64 -> 64 r^2) + PixelShuffle(r) is the view {rH*rW*64, r*rW*64, r*64, rW*64, 64, r} of the
+ *    [B][rH][rW][64] tensor, with chunk q holding original channels {c*r*r + q}: the shuffle is an
+ *    address map, never a copy (ref: advanced/common.py:28-31).
+ *  - Conv weights stay in the reference's OIHW layout in the caller's parameters; kernels take
+ *    either a packed copy (sisr_pack_conv3x3) or generic strides: element (o, i, tap) is read at
+ *    w[o*so + i*si + (flip ? 8-tap : tap)], with channel maps o = n*perm_n + q*perm_q for in-chunk
+ *    index n of chunk q.  Forward: so = Cin*9, si = 9, flip = 0.  Input gradient: roles swapped
+ *    (so = 9, si = Cin*9) and flip = 1.
+ */
+#ifndef SISR_HIP_H
+#define SISR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- 3x3 convolution, Cin and Cout multiples of 64 (fp32 MFMA 32x32x2) ------------------------
+ * ref: advanced/common.py:5-8 default_conv -> nn.Conv2d(k=3, pad=1) forward, and (with role-swapped,
+ * flipped packed weights) its input gradient.  Fused:  y = mask( relu?( conv(x*in_scale+in_shift) + bias )
+ * * alpha * out_scale ) + res, optional per-wave GAP partial sums of y.
+ *   bias index    = n*bias_n + q*bias_q   (nullable)
+ *   in_scale/shift: [B][cin]  (nullable; applied to in-image pixels only, zero padding stays zero)
+ *   out_scale     : [B][cout] (nullable)          res, mask: same view as y (nullable)
+ *   gap_partial   : [B][sisr_conv3x3_c64_gap_parts(H,W)][cout] (nullable) */
+int sisr_pack_conv3x3(const float* w, float* packed, int cout, int cin, int64_t so, int64_t si, int flip_taps,
+                      int out_perm_n, int out_perm_q, int in_perm_n, int in_perm_q, void* stream);
+int sisr_conv3x3_c64_gap_parts(int H, int W);
+int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked, const float* bias, int bias_n,
+                     int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,
+                     const float* in_scale, const float* in_shift, const float* out_scale, float alpha, int relu,
+                     float* gap_partial, int B, int H, int W, int cin, int cout, void* stream);
+
+/* ---- 3x3 convolution weight + bias gradient (fp32 MFMA), deterministic two-stage reduction ------
+ * ref: autograd's convolution_backward for default_conv (loss.backward(), SISR/models/__init__.py:483).
+ *   dW = alpha * sum X (x) dY',  db = alpha * sum dY',  dY' = dY*dy_scale[b][co] + dy_shift[b][co] */
+size_t sisr_wgrad3x3_c64_workspace_bytes(int B, int H, int W, int cin, int cout);
+int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
+                      const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so, int64_t si,
+                      int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n, int in_perm_q, float* dbias,
+                      int bias_n, int bias_q, float* workspace, size_t workspace_bytes, int B, int H, int W, int cin,
+                      int cout, void* stream);
+
+/* ---- RGB-side 3x3 convolutions (fp32 VALU, HBM-bound) ------------------------------------------
+ * ref: head = default_conv(3, n_feats), tail[-1] = default_conv(n_feats, 3)
+ * (advanced/architectures.py:141,150-152).  x/y of the 3-channel side are planar NCHW. */
+int sisr_conv3x3_cin3(const float* x, const float* w, int64_t so, int64_t si, int flip_taps, const float* bias,
+                      float* y, const int64_t* yview, int B, int H, int W, int cout, void* stream);
+int sisr_conv3x3_cout3(const float* x, const int64_t* xview, const float* w, int64_t so, int64_t si, int flip_taps,
+                       const float* bias, float* y, int B, int H, int W, int cin, void* stream);
+size_t sisr_corr3x3_c3_workspace_bytes(int B, int H, int W, int channels);
+int sisr_corr3x3_c3(const float* P, const float* Q, const int64_t* qview, float alpha, float* dw, int64_t so,
+                    int64_t si, int flip_taps, int a_is_out, float* dbias, float* workspace, size_t workspace_bytes,
+                    int B, int H, int W, int channels, void* stream);
+
+/* ---- channel attention gate (64 channels) --------------------------------------------------------
+ * ref: advanced/architectures.py:13-32 CALayer; attention_manipulators/architectures.py:125 QCALayer 'standard'.
+ * fwd: s = inv_hw*sum(partials); hid = relu(W1 s + b1); ca = sigmoid(W2 hid + b2); g = ca * (mul or 1)
+ * bwd: from partial sums of dg = sum_hw dOut*t: shift = dL/ds * inv_hw, dmul = dg*ca, dW1 db1 dW2 db2 */
+int sisr_ca_gate_fwd(const float* gap_partial, int parts, int B, float inv_hw, const float* w1, const float* b1,
+                     const float* w2, const float* b2, int channels, int hidden, const float* mul, float* s,
+                     float* hid, float* ca, float* g, void* stream);
+int sisr_ca_gate_bwd(const float* dg_partial, int parts, int B, float inv_hw, const float* w1, const float* w2,
+                     int channels, int hidden, const float* s, const float* hid, const float* ca, const float* mul,
+                     float* shift, float* dmul, float* dw1, float* db1, float* dw2, float* db2, void* stream);
+
+/* ---- meta-attention gate --------------------------------------------------------------------------
+ * ref: attention_manipulators/q_layer.py:4-43 ParaCALayer: m = sigmoid(V2 act(V1 md + c1) + c2) */
+int sisr_meta_gate_fwd(const float* md, int B, int M, int hidden, int channels, const float* v1, const float* c1,
+                       const float* v2, const float* c2, int relu, float* hid, float* m, void* stream);
+int sisr_meta_gate_bwd(const float* dm, const float* m, const float* hid, const float* md, int B, int M, int hidden,
+                       int channels, const float* v1, const float* v2, int relu, float* dv1, float* dc1, float* dv2,
+                       float* dc2, float* dmd, void* stream);
+
+/* ---- gated residual: y = t*g[b,c] + shift[b,c] + x  (g, shift, x nullable)
+ * ref: the `x * y` / `res += x` tails of CALayer, RCAB, QRCAB, ParamResBlock; with shift it is also the
+ * CALayer input gradient dy*g + dL/ds/HW.  gate_dg_partial: per-slice sums of dy*t (t NULL: of dy = GAP). */
+int sisr_gate_residual_fwd(const float* t, const float* g, const float* shift, const float* x, float* y, int B,
+                           long hw, int channels, void* stream);
+int sisr_gate_dg_parts(long hw);
+int sisr_gate_dg_partial(const float* dy, const float* t, float* part, int B, long hw, int channels, void* stream);
+int sisr_sum_partials(const float* part, int parts, int B, int channels, float scale, float* out, void* stream);
+
+/* ---- loss and optimiser ---------------------------------------------------------------------------
+ * ref: SISR/models/__init__.py:268 nn.L1Loss, :299-308 optim.Adam, :481-489 standard_update */
+size_t sisr_l1_loss_workspace_bytes(void);
+int sisr_l1_loss(const float* a, const float* b, long n, float* loss, float* grad, float* workspace, void* stream);
+int sisr_adam_flat(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
+                   float step_size, float inv_bc2_sqrt, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

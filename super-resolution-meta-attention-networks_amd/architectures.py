@@ -1,0 +1,415 @@
+"""Drop-in nn.Module classes for the in-scope SISR networks, executing on the HIP kernels.
+
+Each class keeps the reference's constructor signature, sub-module names, parameter shapes
+(OIHW fp32) and construction ORDER, so that (a) ``state_dict()`` keys / checkpoints are
+interchangeable with the reference and (b) the same seed yields the same initial weights
+(tests/test_init_parity.py pins both against the reference's own output).  The nn.Conv2d
+children are parameter holders only: ``forward`` never calls them, it hands their tensors to
+the fused operators in ops.py.  Feature maps flow as channels_last (NHWC) tensors end to end;
+only the 3-channel input/output are NCHW.
+
+ref files: Code/SISR/models/advanced/{common,architectures}.py,
+           Code/SISR/models/attention_manipulators/{q_layer,architectures}.py
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+
+def default_conv(in_channels, out_channels, kernel_size, bias=True):
+    """ref: advanced/common.py:5-8"""
+    return nn.Conv2d(in_channels, out_channels, kernel_size, padding=(kernel_size // 2), bias=bias)
+
+
+def _conv(holder, x, **kw):
+    return ops.conv3x3(x, holder.weight, holder.bias, **kw)
+
+
+def _ca_params(seq):
+    """(w1, b1, w2, b2) of a conv_du = [Conv1x1, ReLU, Conv1x1, Sigmoid] stack."""
+    return seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias
+
+
+# ----------------------------------------------------------------------------- plain blocks
+class Upsampler(nn.Sequential):
+    """ref: advanced/common.py:20-45.  conv(C -> r^2 C) + PixelShuffle(r); the shuffle is fused into the
+    conv's store (an address map), so the nn.PixelShuffle children only keep the module indices."""
+
+    def __init__(self, conv, scale, n_feat, bn=False, act=False, bias=True):
+        if bn or act:
+            raise NotImplementedError("Upsampler with BatchNorm/activation is not used by any in-scope model")
+        m = []
+        if (scale & (scale - 1)) == 0:
+            for _ in range(int(math.log(scale, 2))):
+                m.append(conv(n_feat, 4 * n_feat, 3, bias))
+                m.append(nn.PixelShuffle(2))
+        elif scale == 3:
+            m.append(conv(n_feat, 9 * n_feat, 3, bias))
+            m.append(nn.PixelShuffle(3))
+        else:
+            raise NotImplementedError
+        super().__init__(*m)
+
+    def forward(self, x):
+        mods = list(self)
+        for i in range(0, len(mods), 2):
+            x = _conv(mods[i], x, shuffle=mods[i + 1].upscale_factor)
+        return x
+
+
+class ResBlock(nn.Module):
+    """ref: advanced/common.py:48-72: x + res_scale * conv(relu(conv(x)))"""
+
+    def __init__(self, conv, n_feats, kernel_size, bias=True, bn=False, act=None, res_scale=1.0):
+        super().__init__()
+        if bn:
+            raise NotImplementedError("BatchNorm ResBlock is not used by any in-scope model")
+        self.body = nn.Sequential(conv(n_feats, n_feats, kernel_size, bias=bias), nn.ReLU(True),
+                                  conv(n_feats, n_feats, kernel_size, bias=bias))
+        self.res_scale = res_scale
+
+    def forward(self, x):
+        b = self.body
+        return ops.res_block(x, b[0].weight, b[0].bias, b[2].weight, b[2].bias, res_scale=self.res_scale)
+
+
+class CALayer(nn.Module):
+    """ref: advanced/architectures.py:13-32"""
+
+    def __init__(self, channel, reduction=16):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.conv_du = nn.Sequential(nn.Conv2d(channel, channel // reduction, 1, padding=0, bias=True),
+                                     nn.ReLU(inplace=True),
+                                     nn.Conv2d(channel // reduction, channel, 1, padding=0, bias=True), nn.Sigmoid())
+
+    def forward(self, x):
+        return ops.ca_layer(x, *_ca_params(self.conv_du))
+
+
+class RCAB(nn.Module):
+    """ref: advanced/architectures.py:48-71 (res_scale stored, never applied)"""
+
+    def __init__(self, conv, n_feat, kernel_size, reduction, bias=True, bn=False, act=None, res_scale=1):
+        super().__init__()
+        if bn:
+            raise NotImplementedError("BatchNorm RCAB is not used by any in-scope model")
+        self.body = nn.Sequential(conv(n_feat, n_feat, kernel_size, bias=bias), nn.ReLU(True),
+                                  conv(n_feat, n_feat, kernel_size, bias=bias), CALayer(n_feat, reduction))
+        self.res_scale = res_scale
+
+    def forward(self, x):
+        b = self.body
+        return ops.res_block(x, b[0].weight, b[0].bias, b[2].weight, b[2].bias, ca=_ca_params(b[3].conv_du))
+
+
+class ResidualGroup(nn.Module):
+    """ref: advanced/architectures.py:94-110"""
+
+    def __init__(self, conv, n_feat, kernel_size, reduction, act, res_scale, n_resblocks):
+        super().__init__()
+        body = [RCAB(conv, n_feat, kernel_size, reduction, bias=True, bn=False, act=act, res_scale=res_scale)
+                for _ in range(n_resblocks)]
+        body.append(conv(n_feat, n_feat, kernel_size))
+        self.body = nn.Sequential(*body)
+
+    def forward(self, x):
+        res = x
+        mods = list(self.body)
+        for blk in mods[:-1]:
+            res = blk(res)
+        return _conv(mods[-1], res, residual=x)
+
+
+def _check_rgb(x, what):
+    if not x.is_cuda:
+        raise RuntimeError(f"{what}: this network only runs on a HIP device (no CPU fallback); got a CPU tensor")
+
+
+class RCAN(nn.Module):
+    """ref: advanced/architectures.py:126-161"""
+
+    def __init__(self, n_resblocks=20, n_resgroups=10, n_feats=64, in_feats=3, out_feats=3, scale=4, reduction=16,
+                 res_scale=1.0):
+        super().__init__()
+        act = nn.ReLU(True)
+        head = [default_conv(in_feats, n_feats, 3)]
+        body = [ResidualGroup(default_conv, n_feats, 3, reduction, act=act, res_scale=res_scale,
+                              n_resblocks=n_resblocks) for _ in range(n_resgroups)]
+        body.append(default_conv(n_feats, n_feats, 3))
+        tail = [Upsampler(default_conv, scale, n_feats, act=False), default_conv(n_feats, out_feats, 3)]
+        self.head = nn.Sequential(*head)
+        self.body = nn.Sequential(*body)
+        self.tail = nn.Sequential(*tail)
+
+    def forward(self, x):
+        _check_rgb(x, "RCAN")
+        x = _conv(self.head[0], x)
+        res = x
+        mods = list(self.body)
+        for g in mods[:-1]:
+            res = g(res)
+        res = _conv(mods[-1], res, residual=x)
+        return _conv(self.tail[1], self.tail[0](res))
+
+
+class EDSR(nn.Module):
+    """ref: advanced/architectures.py:183-225"""
+
+    def __init__(self, in_features=3, out_features=3, net_features=64, num_blocks=16, scale=4, res_scale=0.1):
+        super().__init__()
+        act = nn.ReLU(True)
+        head = [default_conv(in_features, net_features, 3)]
+        body = [ResBlock(default_conv, net_features, 3, act=act, res_scale=res_scale) for _ in range(num_blocks)]
+        body.append(default_conv(net_features, net_features, 3))
+        tail = [Upsampler(default_conv, scale, net_features), default_conv(net_features, out_features, 3)]
+        self.head = nn.Sequential(*head)
+        self.body = nn.Sequential(*body)
+        self.tail = nn.Sequential(*tail)
+
+    def forward(self, x):
+        _check_rgb(x, "EDSR")
+        x = _conv(self.head[0], x)
+        res = x
+        mods = list(self.body)
+        for blk in mods[:-1]:
+            res = blk(res)
+        res = _conv(mods[-1], res, residual=x)
+        return _conv(self.tail[1], self.tail[0](res))
+
+
+# ----------------------------------------------------------------------------- meta-attention blocks
+class ParaCALayer(nn.Module):
+    """Meta-attention.  ref: attention_manipulators/q_layer.py:4-43"""
+
+    def __init__(self, network_channels, num_metadata, nonlinearity=False, num_layers=2):
+        super().__init__()
+        layers, multiplier, inputs = [], num_layers, [num_metadata]
+        self.fc_index = []
+        for i in range(num_layers):
+            if num_metadata > 15:
+                inputs.append((network_channels - num_metadata) // multiplier + num_metadata)
+            else:
+                inputs.append(network_channels // multiplier)
+            self.fc_index.append(len(layers))
+            layers.append(nn.Conv2d(inputs[i], inputs[i + 1], 1, padding=0, bias=True))
+            if nonlinearity and multiplier != 1:
+                layers.append(nn.ReLU(inplace=True))
+            multiplier -= 1
+        layers.append(nn.Sigmoid())
+        self.attribute_integrator = nn.Sequential(*layers)
+        self.nonlinearity = bool(nonlinearity)
+        if num_layers != 2:
+            raise NotImplementedError("the meta-gate kernel implements the reference's default num_layers=2")
+
+    def gate(self, attributes):
+        """(B,M,1,1) -> (B,C) sigmoid gate (the only part that depends on parameters)."""
+        a, b = (self.attribute_integrator[i] for i in self.fc_index)
+        return ops.meta_gate(attributes, a.weight, a.bias, b.weight, b.bias, self.nonlinearity)
+
+    def forward(self, x, attributes):
+        return ops.gate_mul(x, self.gate(attributes))
+
+
+class PALayer(nn.Module):
+    """ref: attention_manipulators/architectures.py:13-26.  Parameter holder; the per-pixel 1x1 gate has no
+    HIP kernel yet ('next')."""
+
+    def __init__(self, channel):
+        super().__init__()
+        self.pa = nn.Sequential(nn.Conv2d(channel, channel // 8, 1, padding=0, bias=True), nn.ReLU(inplace=True),
+                                nn.Conv2d(channel // 8, 1, 1, padding=0, bias=True), nn.Sigmoid())
+
+    def forward(self, x):
+        raise NotImplementedError("pixel attention (include_pixel_attention=True) is not implemented on the HIP path")
+
+
+class QCALayer(nn.Module):
+    """ref: attention_manipulators/architectures.py:34-127.  'standard' (the paper's configuration) runs the
+    fused CA kernels; the five metadata-mixing styles finish the HIP global-average-pool with their few-element
+    FC stack in stock torch ops on the device (B x <=74 values) before the HIP gate multiply."""
+
+    def __init__(self, channel, style, reduction=16, num_metadata=1):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        if reduction < 16:
+            raise RuntimeError('Using an extreme channel attention reduction value')
+        channel_in = channel if style in ('modulate', 'mini_concat', 'standard') else channel + num_metadata
+        cr = channel // reduction
+        if style in ('modulate', 'max_concat', 'softmax', 'standard'):
+            self.conv_du = nn.Sequential(nn.Conv2d(channel_in, cr, 1, padding=0, bias=True), nn.ReLU(inplace=True),
+                                         nn.Conv2d(cr, channel, 1, padding=0, bias=True), nn.Sigmoid())
+        elif style == 'mini_concat':
+            self.pre_concat = nn.Conv2d(channel_in, cr, 1, padding=0, bias=True)
+            self.conv_du = nn.Sequential(nn.ReLU(inplace=True),
+                                         nn.Conv2d(cr + num_metadata, channel, 1, padding=0, bias=True), nn.Sigmoid())
+        elif style == 'extended_attention':
+            fractions = [(channel_in, channel // 2), (channel // 2 + num_metadata, channel // 4),
+                         (channel // 4 + num_metadata, cr)]
+            self.feature_convs = nn.ModuleList()
+            for inp, outp in fractions:
+                self.feature_convs.append(nn.Sequential(nn.Conv2d(inp, outp, 1, padding=0, bias=True),
+                                                        nn.ReLU(inplace=True)))
+            self.final_conv = nn.Sequential(nn.Conv2d(cr, channel, 1, padding=0, bias=True), nn.Sigmoid())
+        if style == 'softmax':
+            self.softmax = nn.Softmax(dim=1)
+        self.style = style
+
+    def gate_from_pool(self, y, attributes):
+        s = self.style
+        if s == 'modulate':
+            return self.conv_du(y) * attributes
+        if s == 'max_concat':
+            return self.conv_du(torch.cat((y, attributes), dim=1))
+        if s == 'mini_concat':
+            return self.conv_du(torch.cat((self.pre_concat(y), attributes), dim=1))
+        if s == 'extended_attention':
+            for sec in self.feature_convs:
+                y = sec(torch.cat((y, attributes), dim=1))
+            return self.final_conv(y)
+        if s == 'softmax':
+            return self.softmax(self.conv_du(torch.cat((y, attributes), dim=1)))
+        raise NotImplementedError(s)
+
+    def forward(self, x, attributes):
+        if self.style == 'standard':
+            return ops.ca_layer(x, *_ca_params(self.conv_du))
+        return ops.gate_mul(x, self.gate_from_pool(ops.global_avg_pool(x), attributes))
+
+
+class QRCAB(nn.Module):
+    """ref: attention_manipulators/architectures.py:145-180"""
+
+    def __init__(self, conv, n_feat, kernel_size, reduction, style='modulate', pa=False, q_layer=False, bias=True,
+                 bn=False, act=None, res_scale=1, num_metadata=1):
+        super().__init__()
+        if bn:
+            raise NotImplementedError("BatchNorm QRCAB is not used by any in-scope model")
+        body = [conv(n_feat, n_feat, kernel_size, bias=bias), nn.ReLU(True), conv(n_feat, n_feat, kernel_size, bias=bias)]
+        self.final_body = QCALayer(channel=n_feat, reduction=reduction, style=style, num_metadata=num_metadata)
+        self.pa = pa
+        self.q_layer = q_layer
+        if pa:
+            self.pa_node = PALayer(channel=n_feat)
+        if q_layer:
+            self.q_node = ParaCALayer(network_channels=n_feat, num_metadata=num_metadata, nonlinearity=True)
+        self.body = nn.Sequential(*body)
+        self.res_scale = res_scale
+
+    def forward(self, x):
+        feat, md = x
+        b = self.body
+        if self.pa:
+            return self.pa_node(feat), md  # raises: not implemented on the HIP path
+        if self.final_body.style == 'standard':
+            m = self.q_node.gate(md) if self.q_layer else None
+            y = ops.res_block(feat, b[0].weight, b[0].bias, b[2].weight, b[2].bias,
+                              ca=_ca_params(self.final_body.conv_du), m=m)
+            return y, md
+        # metadata-mixing CA styles: conv pair fused, gates composed
+        t = ops.res_block_convs(feat, b[0].weight, b[0].bias, b[2].weight, b[2].bias)
+        g = self.final_body.gate_from_pool(ops.global_avg_pool(t), md)
+        if self.q_layer:
+            g = g * self.q_node.gate(md).reshape(g.shape)
+        return ops.gate_mul(t, g, feat), md
+
+
+class QResidualGroup(nn.Module):
+    """ref: attention_manipulators/architectures.py:208-233"""
+
+    def __init__(self, conv, n_feat, kernel_size, reduction, act, res_scale, n_resblocks, style, num_metadata, pa,
+                 q_layer, num_q_layers):
+        super().__init__()
+        body = []
+        for index in range(n_resblocks):
+            q_in = q_layer if (num_q_layers is None or index < num_q_layers) else False
+            body.append(QRCAB(conv, n_feat, kernel_size, reduction, bias=True, bn=False, act=act, res_scale=res_scale,
+                              style=style, pa=pa, q_layer=q_in, num_metadata=num_metadata))
+        self.final_body = conv(n_feat, n_feat, kernel_size)
+        self.body = nn.Sequential(*body)
+
+    def forward(self, x):
+        feat, md = x
+        res = feat
+        for blk in self.body:
+            res, _ = blk((res, md))
+        return _conv(self.final_body, res, residual=feat), md
+
+
+class QRCAN(nn.Module):
+    """ref: attention_manipulators/architectures.py:246-316"""
+
+    def __init__(self, n_resblocks=20, n_resgroups=10, n_feats=64, in_feats=3, out_feats=3, scale=4, reduction=16,
+                 res_scale=1.0, style='modulate', num_metadata=1, include_pixel_attention=False,
+                 selective_meta_blocks=None, num_q_layers_inner_residual=None, include_q_layer=False, **kwargs):
+        super().__init__()
+        act = nn.ReLU(True)
+        self.style = style
+        head = [default_conv(in_feats, n_feats, 3)]
+        body = []
+        for index in range(n_resgroups):
+            include_q = include_q_layer if (selective_meta_blocks is None or selective_meta_blocks[index]) else False
+            body.append(QResidualGroup(default_conv, n_feats, 3, reduction, style=style, num_metadata=num_metadata,
+                                       pa=include_pixel_attention, q_layer=include_q, act=act, res_scale=res_scale,
+                                       n_resblocks=n_resblocks, num_q_layers=num_q_layers_inner_residual))
+        self.final_body = default_conv(n_feats, n_feats, 3)
+        tail = [Upsampler(default_conv, scale, n_feats, act=False), default_conv(n_feats, out_feats, 3)]
+        self.head = nn.Sequential(*head)
+        self.body = nn.Sequential(*body)
+        self.tail = nn.Sequential(*tail)
+
+    def forward(self, x, metadata):
+        _check_rgb(x, "QRCAN")
+        x = _conv(self.head[0], x)
+        res = x
+        for g in self.body:
+            res, _ = g((res, metadata))
+        res = _conv(self.final_body, res, residual=x)
+        return _conv(self.tail[1], self.tail[0](res))
+
+
+class ParamResBlock(nn.Module):
+    """ref: attention_manipulators/architectures.py:332-356"""
+
+    def __init__(self, conv, n_feats, n_params, kernel_size, act=None, bias=True, res_scale=1.0,
+                 q_layer_nonlinearity=False):
+        super().__init__()
+        self.body = nn.Sequential(conv(n_feats, n_feats, kernel_size, bias=bias), nn.ReLU(True),
+                                  conv(n_feats, n_feats, kernel_size, bias=bias))
+        self.attention_layer = ParaCALayer(n_feats, n_params, nonlinearity=q_layer_nonlinearity)
+        self.res_scale = res_scale
+
+    def forward(self, x):
+        feat, md = x
+        b = self.body
+        y = ops.res_block(feat, b[0].weight, b[0].bias, b[2].weight, b[2].bias, m=self.attention_layer.gate(md),
+                          res_scale=self.res_scale)
+        return y, md
+
+
+class QEDSR(nn.Module):
+    """ref: attention_manipulators/architectures.py:359-399"""
+
+    def __init__(self, in_features=3, out_features=3, num_features=64, input_para=1, num_blocks=16, scale=4,
+                 res_scale=0.1, q_layer_nonlinearity=False, **kwargs):
+        super().__init__()
+        self.head = default_conv(in_features, num_features, 3)
+        body = [ParamResBlock(default_conv, num_features, input_para, 3, res_scale=res_scale,
+                              q_layer_nonlinearity=q_layer_nonlinearity) for _ in range(num_blocks)]
+        self.final_body = default_conv(num_features, num_features, 3)
+        tail = [Upsampler(default_conv, scale, num_features), default_conv(num_features, out_features, 3)]
+        self.body = nn.Sequential(*body)
+        self.tail = nn.Sequential(*tail)
+
+    def forward(self, x, metadata):
+        _check_rgb(x, "QEDSR")
+        x = _conv(self.head, x)
+        res = x
+        for blk in self.body:
+            res, _ = blk((res, metadata))
+        res = _conv(self.final_body, res, residual=x)
+        return _conv(self.tail[1], self.tail[0](res))

@@ -1,0 +1,318 @@
+// Channel-attention / meta-attention gates and the gated residual, fp32.
+//
+//   CA gate   (ref: advanced/architectures.py:13-32 CALayer; attention_manipulators/architectures.py:125
+//              QCALayer style 'standard'):  s = mean_hw(t);  h = relu(W1 s + b1);  ca = sigmoid(W2 h + b2)
+//   meta gate (ref: attention_manipulators/q_layer.py:20-43 ParaCALayer):
+//              m = sigmoid(V2 act(V1 md + c1) + c2),  act = ReLU or identity
+//   block out (ref: advanced/architectures.py:68-71 RCAB, attention_manipulators/architectures.py:172-180
+//              QRCAB, :348-356 ParamResBlock):       y = t * g[b,c] + x,   g = ca, ca*m or m
+// The GAP itself is produced by the conv epilogue as per-wave partial sums; these kernels finish
+// it.  All reductions run in a fixed order (no atomics), so results are run-to-run reproducible.
+// These are M = batch sized contractions (64x4, 10x32x64): VALU + wave shuffles, not MFMA.
+#include "sisr_common.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
+
+// ---------------------------------------------------------------- CA gate forward (C = 64, one wave per sample)
+// part: [B][parts][64] partial sums.  Outputs s, ca, g: [B][64]; hid: [B][R].
+__global__ __launch_bounds__(64) void ca_gate_fwd_kernel(const float* __restrict__ part, int parts, float inv_hw,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         int R, const float* __restrict__ mul, float* __restrict__ s_out,
+                                                         float* __restrict__ hid_out, float* __restrict__ ca_out,
+                                                         float* __restrict__ g_out) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float* pp = part + (long)b * parts * 64 + c;
+  float s = 0.f;
+  for (int k = 0; k < parts; ++k) s += pp[(long)k * 64];
+  s *= inv_hw;
+  s_out[b * 64 + c] = s;
+  float z = b2[c];
+  for (int j = 0; j < R; ++j) {
+    float h = wave_sum(w1[j * 64 + c] * s) + b1[j];
+    h = fmaxf(h, 0.f);
+    if (c == 0) hid_out[b * R + j] = h;
+    z += w2[c * R + j] * h;
+  }
+  const float ca = sigmoidf(z);
+  ca_out[b * 64 + c] = ca;
+  g_out[b * 64 + c] = mul ? ca * mul[b * 64 + c] : ca;
+}
+
+// ---------------------------------------------------------------- CA gate backward
+// dgpart: [B][parts][64] partial sums of dg = sum_hw dOut*t.  One wave; loops over the batch so the
+// weight gradients are summed in batch order.  Outputs: shift[b][c] = dL/ds * inv_hw (the GAP backward
+// broadcast, consumed as the dgrad/wgrad prologue shift), dmul = dg*ca, and dW1,db1,dW2,db2.
+__global__ __launch_bounds__(64) void ca_gate_bwd_kernel(const float* __restrict__ dgpart, int parts, int B,
+                                                         float inv_hw, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, int R,
+                                                         const float* __restrict__ s_in, const float* __restrict__ hid,
+                                                         const float* __restrict__ ca_in, const float* __restrict__ mul,
+                                                         float* __restrict__ shift, float* __restrict__ dmul,
+                                                         float* __restrict__ dw1, float* __restrict__ db1,
+                                                         float* __restrict__ dw2, float* __restrict__ db2) {
+  const int c = threadIdx.x;
+  float adb2 = 0.f;
+  float adw2[16], adw1[16], adb1[16];  // R <= 16 (reduction 16 on 64..256 channels; launcher checks)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) adw2[j] = adw1[j] = adb1[j] = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* pp = dgpart + (long)b * parts * 64 + c;
+    float dg = 0.f;
+    for (int k = 0; k < parts; ++k) dg += pp[(long)k * 64];
+    const float ca = ca_in[b * 64 + c];
+    float dca = dg;
+    if (mul) {
+      dmul[b * 64 + c] = dg * ca;
+      dca = dg * mul[b * 64 + c];
+    }
+    const float dz2 = dca * ca * (1.f - ca);
+    adb2 += dz2;
+    const float s = s_in[b * 64 + c];
+    float ds = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < R) {
+        const float h = hid[b * R + j];
+        adw2[j] += dz2 * h;
+        float dh = wave_sum(w2[c * R + j] * dz2);
+        const float dz1 = h > 0.f ? dh : 0.f;
+        adb1[j] += dz1;
+        adw1[j] += dz1 * s;
+        ds += w1[j * 64 + c] * dz1;
+      }
+    }
+    shift[b * 64 + c] = ds * inv_hw;
+  }
+  db2[c] = adb2;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j < R) {
+      dw2[c * R + j] = adw2[j];
+      dw1[j * 64 + c] = adw1[j];
+      if (c == 0) db1[j] = adb1[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- meta gate (ParaCALayer) forward / backward
+// md [B][M]; v1 [Hd][M]; c1 [Hd]; v2 [C][Hd]; c2 [C].  One block per sample, blockDim = 256.
+__global__ __launch_bounds__(256) void meta_gate_fwd_kernel(const float* __restrict__ md, int M, int Hd, int C,
+                                                            const float* __restrict__ v1, const float* __restrict__ c1,
+                                                            const float* __restrict__ v2, const float* __restrict__ c2,
+                                                            int relu, float* __restrict__ hid, float* __restrict__ m) {
+  extern __shared__ float sm[];  // Hd floats
+  const int b = blockIdx.x;
+  for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
+    float z = c1[j];
+    for (int k = 0; k < M; ++k) z += v1[(long)j * M + k] * md[(long)b * M + k];
+    if (relu) z = fmaxf(z, 0.f);
+    sm[j] = z;
+    hid[(long)b * Hd + j] = z;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float z = c2[c];
+    for (int j = 0; j < Hd; ++j) z += v2[(long)c * Hd + j] * sm[j];
+    m[(long)b * C + c] = sigmoidf(z);
+  }
+}
+
+// dm [B][C] -> dv2 [C][Hd], dc2 [C], dv1 [Hd][M], dc1 [Hd], dmd [B][M] (nullable).  One block; batch loop
+// inside so parameter gradients accumulate in batch order.  Scratch: dz2 [C] + dz1 [Hd] in LDS.
+__global__ __launch_bounds__(256) void meta_gate_bwd_kernel(const float* __restrict__ dm, const float* __restrict__ m,
+                                                            const float* __restrict__ hid, const float* __restrict__ md,
+                                                            int B, int M, int Hd, int C, const float* __restrict__ v1,
+                                                            const float* __restrict__ v2, int relu,
+                                                            float* __restrict__ dv1, float* __restrict__ dc1,
+                                                            float* __restrict__ dv2, float* __restrict__ dc2,
+                                                            float* __restrict__ dmd) {
+  extern __shared__ float sm[];
+  float* dz2 = sm;
+  float* dz1 = sm + C;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (long i = tid; i < (long)C * Hd; i += nt) dv2[i] = 0.f;
+  for (long i = tid; i < (long)Hd * M; i += nt) dv1[i] = 0.f;
+  for (int i = tid; i < C; i += nt) dc2[i] = 0.f;
+  for (int i = tid; i < Hd; i += nt) dc1[i] = 0.f;
+  __syncthreads();
+  for (int b = 0; b < B; ++b) {
+    for (int c = tid; c < C; c += nt) {
+      const float mv = m[(long)b * C + c];
+      const float d = dm[(long)b * C + c] * mv * (1.f - mv);
+      dz2[c] = d;
+      dc2[c] += d;
+    }
+    __syncthreads();
+    for (long i = tid; i < (long)C * Hd; i += nt) {  // element (c, j) owned by one thread for every b
+      const int c = (int)(i / Hd), j = (int)(i - (long)c * Hd);
+      dv2[i] += dz2[c] * hid[(long)b * Hd + j];
+    }
+    for (int j = tid; j < Hd; j += nt) {
+      float dh = 0.f;
+      for (int c = 0; c < C; ++c) dh += v2[(long)c * Hd + j] * dz2[c];
+      if (relu && !(hid[(long)b * Hd + j] > 0.f)) dh = 0.f;
+      dz1[j] = dh;
+      dc1[j] += dh;
+    }
+    __syncthreads();
+    for (long i = tid; i < (long)Hd * M; i += nt) {
+      const int j = (int)(i / M), k = (int)(i - (long)j * M);
+      dv1[i] += dz1[j] * md[(long)b * M + k];
+    }
+    if (dmd) {
+      for (int k = tid; k < M; k += nt) {
+        float d = 0.f;
+        for (int j = 0; j < Hd; ++j) d += v1[(long)j * M + k] * dz1[j];
+        dmd[(long)b * M + k] = d;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- gated residual: y = t*g[b,c] + shift[b,c] + x
+// t, x, y: contiguous [B][HW][C]; g, shift: [B][C] (nullable -> 1, 0); x nullable.  C % 4 == 0.
+__global__ __launch_bounds__(256) void gate_residual_fwd_kernel(const float* __restrict__ t, const float* __restrict__ g,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ x, float* __restrict__ y,
+                                                                long hw, int C, long total4) {
+  const int c4n = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / c4n;
+    const int c4 = (int)(i - pix * c4n);
+    const long b = pix / hw;
+    f32x4 v = reinterpret_cast<const f32x4*>(t)[i];
+    if (g) v = v * *reinterpret_cast<const f32x4*>(g + b * C + c4 * 4);
+    if (shift) v = v + *reinterpret_cast<const f32x4*>(shift + b * C + c4 * 4);
+    if (x) v = v + reinterpret_cast<const f32x4*>(x)[i];
+    reinterpret_cast<f32x4*>(y)[i] = v;
+  }
+}
+
+// dg partials: part[b][k][c] = sum over pixel slice k of dy*t (t == nullptr: of dy -- the plain GAP)
+// (C = 64, 256 threads = 16 px x 16 float4)
+__global__ __launch_bounds__(256) void gate_dg_partial_kernel(const float* __restrict__ dy, const float* __restrict__ t,
+                                                              float* __restrict__ part, long hw, int parts) {
+  __shared__ f32x4 red[256];
+  const int b = blockIdx.y, k = blockIdx.x;
+  const int c4 = threadIdx.x & 15, pr = threadIdx.x >> 4;
+  const long per = (hw + parts - 1) / parts;
+  const long p0 = (long)k * per;
+  const long p1 = p0 + per < hw ? p0 + per : hw;
+  const f32x4* d4 = reinterpret_cast<const f32x4*>(dy) + (long)b * hw * 16;
+  const f32x4* t4 = reinterpret_cast<const f32x4*>(t) + (long)b * hw * 16;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (t) {
+    for (long p = p0 + pr; p < p1; p += 16) acc += d4[p * 16 + c4] * t4[p * 16 + c4];
+  } else {
+    for (long p = p0 + pr; p < p1; p += 16) acc += d4[p * 16 + c4];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    f32x4 s = red[threadIdx.x];
+    for (int r = 1; r < 16; ++r) s += red[r * 16 + threadIdx.x];
+    reinterpret_cast<f32x4*>(part + ((long)b * parts + k) * 64)[threadIdx.x] = s;
+  }
+}
+
+// out[b][c] = scale * sum_k part[b][k][c]
+__global__ void sum_partials_kernel(const float* __restrict__ part, int parts, int C, float scale,
+                                    float* __restrict__ out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long b = i / C;
+  const int c = (int)(i - b * C);
+  float s = 0.f;
+  for (int k = 0; k < parts; ++k) s += part[((long)b * parts + k) * C + c];
+  out[i] = s * scale;
+}
+
+// ---------------------------------------------------------------- C ABI
+extern "C" int sisr_ca_gate_fwd(const float* gap_partial, int parts, int B, float inv_hw, const float* w1,
+                                const float* b1, const float* w2, const float* b2, int channels, int hidden,
+                                const float* mul, float* s, float* hid, float* ca, float* g, void* stream) {
+  if (!gap_partial || !w1 || !b1 || !w2 || !b2 || !s || !hid || !ca || !g || B <= 0 || parts <= 0) return SISR_ERR_ARG;
+  if (channels != 64 || hidden < 1 || hidden > 16) return SISR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ca_gate_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, gap_partial, parts, inv_hw, w1, b1,
+                     w2, b2, hidden, mul, s, hid, ca, g);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_ca_gate_bwd(const float* dg_partial, int parts, int B, float inv_hw, const float* w1,
+                                const float* w2, int channels, int hidden, const float* s, const float* hid,
+                                const float* ca, const float* mul, float* shift, float* dmul, float* dw1, float* db1,
+                                float* dw2, float* db2, void* stream) {
+  if (!dg_partial || !w1 || !w2 || !s || !hid || !ca || !shift || !dw1 || !db1 || !dw2 || !db2 || B <= 0 || parts <= 0)
+    return SISR_ERR_ARG;
+  if (mul && !dmul) return SISR_ERR_ARG;
+  if (channels != 64 || hidden < 1 || hidden > 16) return SISR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ca_gate_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dg_partial, parts, B, inv_hw, w1, w2,
+                     hidden, s, hid, ca, mul, shift, dmul, dw1, db1, dw2, db2);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_meta_gate_fwd(const float* md, int B, int M, int hidden, int channels, const float* v1,
+                                  const float* c1, const float* v2, const float* c2, int relu, float* hid, float* m,
+                                  void* stream) {
+  if (!md || !v1 || !c1 || !v2 || !c2 || !hid || !m || B <= 0 || M <= 0 || hidden <= 0 || channels <= 0) return SISR_ERR_ARG;
+  if (hidden > 4096) return SISR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(meta_gate_fwd_kernel, dim3(B), dim3(256), hidden * sizeof(float), (hipStream_t)stream, md, M, hidden,
+                     channels, v1, c1, v2, c2, relu, hid, m);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_meta_gate_bwd(const float* dm, const float* m, const float* hid, const float* md, int B, int M,
+                                  int hidden, int channels, const float* v1, const float* v2, int relu, float* dv1,
+                                  float* dc1, float* dv2, float* dc2, float* dmd, void* stream) {
+  if (!dm || !m || !hid || !md || !v1 || !v2 || !dv1 || !dc1 || !dv2 || !dc2 || B <= 0) return SISR_ERR_ARG;
+  if (hidden + channels > 8192) return SISR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(meta_gate_bwd_kernel, dim3(1), dim3(256), (hidden + channels) * sizeof(float), (hipStream_t)stream,
+                     dm, m, hid, md, B, M, hidden, channels, v1, v2, relu, dv1, dc1, dv2, dc2, dmd);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_gate_residual_fwd(const float* t, const float* g, const float* shift, const float* x, float* y,
+                                      int B, long hw, int channels, void* stream) {
+  if (!t || !y || B <= 0 || hw <= 0 || channels <= 0 || (channels & 3)) return SISR_ERR_ARG;
+  if (!sisr_aligned16(t) || !sisr_aligned16(g) || !sisr_aligned16(shift) || !sisr_aligned16(x) || !sisr_aligned16(y))
+    return SISR_ERR_ALIGN;
+  const long total4 = (long)B * hw * (channels >> 2);
+  long blocks = (total4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gate_residual_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, g, shift, x, y,
+                     hw, channels, total4);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_gate_dg_parts(long hw) {
+  long p = (hw + 511) / 512;  // >= 512 pixels per block
+  if (p > 128) p = 128;
+  if (p < 1) p = 1;
+  return (int)p;
+}
+
+extern "C" int sisr_gate_dg_partial(const float* dy, const float* t, float* part, int B, long hw, int channels,
+                                    void* stream) {
+  if (!dy || !part || B <= 0 || hw <= 0) return SISR_ERR_ARG;  /* t may be NULL: plain pixel sums */
+  if (channels != 64) return SISR_ERR_UNSUPPORTED;
+  if (!sisr_aligned16(dy) || !sisr_aligned16(t) || !sisr_aligned16(part)) return SISR_ERR_ALIGN;
+  const int parts = sisr_gate_dg_parts(hw);
+  hipLaunchKernelGGL(gate_dg_partial_kernel, dim3(parts, B), dim3(256), 0, (hipStream_t)stream, dy, t, part, hw, parts);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_sum_partials(const float* part, int parts, int B, int channels, float scale, float* out,
+                                 void* stream) {
+  if (!part || !out || parts <= 0 || B <= 0 || channels <= 0) return SISR_ERR_ARG;
+  const long total = (long)B * channels;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
+                     parts, channels, scale, out, total);
+  return sisr_check_launch();
+}

@@ -1,0 +1,263 @@
+// 3x3 same-convolution over 64-channel chunks, fp32, on the gfx950 matrix cores.
+//
+// Replaces, for every Cin,Cout multiple of 64, the reference's default_conv forward
+// (advanced/common.py:5-8 -> nn.Conv2d(k=3,pad=1)) and -- with flipped / role-swapped packed
+// weights -- its input gradient.  Implicit GEMM: M = pixels, N = 64 output channels per block,
+// K = 9 taps x 64 input channels per chunk, on v_mfma_f32_32x32x2_f32 (exact fp32: bit-identical
+// to a k-ordered fmaf chain, MI355X guide "FP32-input MFMA").
+//
+// Work decomposition (one workgroup = 256 threads = 4 waves):
+//   tile   : 4 rows x 32 cols of output pixels, one 64-wide output-channel chunk (blockIdx.y)
+//   wave   : (ph, ch) -> rows {2ph, 2ph+1} x channels [32ch, 32ch+32): two 32x32 accumulators
+//   LDS    : the 6 x 34 pixel halo of the input chunk, 68-float pixel stride (272 B) so the 16
+//            lanes of a ds_read_b128 group land on 16 distinct 16-B bank slots
+//   A frag : lane (pixel p = l&31, half h = l>>5) reads channels [8j+4h, 8j+4h+4) of its pixel as ONE
+//            ds_read_b128 and feeds four consecutive MFMAs (k=0 <-> ci 8j+e, k=1 <-> ci 8j+4+e)
+//   B frag : the matching 4 weights for output channel n = l&31, pre-packed so a wave's read is two
+//            contiguous 512-B runs; fetched global->VGPR two steps ahead (weights are L2-resident:
+//            147 KB per chunk pair, shared by every workgroup)
+// Fused prologue: per-(b,ci) affine on the input (used for dRes = dOut*g + c in the RCAB backward).
+// Fused epilogue: +bias, ReLU, scalar and per-(b,co) scale, ReLU-mask, residual add, pixel-shuffle
+// address map, and per-wave partial sums for the global average pool.
+#include "sisr_common.h"
+
+#define TH 4
+#define TW 32
+#define HALO_H (TH + 2)
+#define HALO_W (TW + 2)
+#define PSTR 68
+#define HALO_ITEMS (HALO_H * HALO_W * 16)            // float4 items in the halo
+#define STAGE_ITERS ((HALO_ITEMS + 255) / 256)        // 13
+
+struct ConvParams {
+  const float* x;
+  View xv;
+  float* y;
+  View yv;
+  const float* res;
+  const float* mask;
+  const float* w;
+  const float* bias;
+  const float* in_scale;
+  const float* in_shift;
+  const float* out_scale;
+  float* gap;
+  float alpha;
+  int bias_n, bias_q;
+  int B, H, W, cin_chunks, cout_chunks, relu, tiles_w, tiles_h;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int q = blockIdx.y;
+  int bid = blockIdx.x;
+  const int tw = bid % p.tiles_w;
+  bid /= p.tiles_w;
+  const int th = bid % p.tiles_h;
+  const int b = bid / p.tiles_h;
+  const int h0 = th * TH, w0 = tw * TW;
+  const int ph = wave >> 1, ch = wave & 1;
+  const int n = lane & 31, hh = lane >> 5;
+  const int H = p.H, W = p.W;
+
+  f32x16 acc0 = {0}, acc1 = {0};
+
+  for (int c = 0; c < p.cin_chunks; ++c) {
+    if (c) __syncthreads();  // previous chunk's A reads are done before the halo is overwritten
+    // ---- stage the halo of input chunk c: global -> VGPR -> LDS (16 lanes x 16 B per pixel)
+    {
+      // Branch-free: out-of-image taps load a clamped (valid) address and are zeroed by a select, so
+      // all 13 loads of a thread are in flight together.  c4 = tid & 15 is the same for every item.
+      const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(c);
+      const int c4 = tid & 15;
+      f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.in_scale) s4 = *reinterpret_cast<const f32x4*>(p.in_scale + ((long)b * p.cin_chunks + c) * 64 + c4 * 4);
+      if (p.in_shift) t4 = *reinterpret_cast<const f32x4*>(p.in_shift + ((long)b * p.cin_chunks + c) * 64 + c4 * 4);
+      f32x4 v[STAGE_ITERS];
+#pragma unroll
+      for (int it = 0; it < STAGE_ITERS; ++it) {
+        const int pix = (it * 256 + tid) >> 4;
+        const int pr = pix / HALO_W, pc = pix - pr * HALO_W;
+        const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
+        const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
+        const int ch_ = min(max(gh, 0), H - 1), cw_ = min(max(gw, 0), W - 1);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(xb + (long)ch_ * p.xv.sH + (long)cw_ * p.xv.sW + c4 * 4);
+        v[it] = sisr_keep_if(t * s4 + t4, ok);  // zero padding stays zero: the affine is for in-image pixels only
+      }
+#pragma unroll
+      for (int it = 0; it < STAGE_ITERS; ++it) {
+        const int idx = it * 256 + tid;
+        if (idx < HALO_ITEMS) *reinterpret_cast<f32x4*>(lds + (idx >> 4) * PSTR + c4 * 4) = v[it];
+      }
+    }
+    __syncthreads();
+
+    // ---- 72 K-steps (9 taps x 8 octets of input channels), 8 MFMAs each
+    const float* wq = p.w + ((long)q * p.cin_chunks + c) * (9 * 64 * 64) + hh * 256 + (ch * 32 + n) * 4;
+    const float* ab = lds + ((2 * ph) * HALO_W + n) * PSTR + hh * 4;
+#define LOAD_B(s) (*reinterpret_cast<const f32x4*>(wq + (s) * 512))
+#define LOAD_A(m, s) \
+  (*reinterpret_cast<const f32x4*>(ab + ((((s) >> 3) / 3 + (m)) * HALO_W + (((s) >> 3) % 3)) * PSTR + ((s) & 7) * 8))
+    // B ring: 4 steps (32 MFMAs, >= 2048 cycles) ahead of use, so an L2 miss to the Infinity Cache
+    // is still covered; A (LDS) one step ahead.  sched_barrier(0) after every step keeps hipcc from
+    // sinking the prefetches down to their first use (it otherwise emits load; s_waitcnt 0; mfma).
+    f32x4 bq[5];
+    f32x4 aq[2][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bq[s] = LOAD_B(s);
+    aq[0][0] = LOAD_A(0, 0);
+    aq[0][1] = LOAD_A(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 72; ++s) {
+      if (s + 4 < 72) bq[(s + 4) % 5] = LOAD_B(s + 4);
+      if (s + 1 < 72) {
+        aq[(s + 1) & 1][0] = LOAD_A(0, s + 1);
+        aq[(s + 1) & 1][1] = LOAD_A(1, s + 1);
+      }
+      const f32x4 bb = bq[s % 5];
+      const f32x4 a0 = aq[s & 1][0];
+      const f32x4 a1 = aq[s & 1][1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bb[e], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bb[e], acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef LOAD_A
+#undef LOAD_B
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 tile: column (= output channel) on the lane, pixel
+  // (r&3) + 8*(r>>2) + 4*(lane>>5) in register r.
+  const int co = ch * 32 + n;
+  const int Cout = p.cout_chunks * 64;
+  const float bv = p.bias ? p.bias[co * p.bias_n + q * p.bias_q] : 0.f;
+  float os = p.alpha;
+  if (p.out_scale) os *= p.out_scale[(long)b * Cout + q * 64 + co];
+  const long ybase = (long)b * p.yv.sB + p.yv.chunk(q) + co;
+  float gsum = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int row = h0 + 2 * ph + m;
+    const f32x16 acc = m ? acc1 : acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int col = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (row < H && col < W) {
+        float v = acc[r] + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        v *= os;
+        const long off = ybase + (long)row * p.yv.sH + (long)col * p.yv.sW;
+        if (p.mask) v = p.mask[off] > 0.f ? v : 0.f;
+        if (p.res) v += p.res[off];
+        p.y[off] = v;
+        gsum += v;
+      }
+    }
+  }
+  if (p.gap) {
+    gsum += __shfl_xor(gsum, 32);
+    if (hh == 0) {
+      const int tile = th * p.tiles_w + tw;
+      const long parts = (long)p.tiles_w * p.tiles_h * 2;
+      p.gap[(((long)b * parts) + tile * 2 + ph) * Cout + q * 64 + co] = gsum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ weight packing
+// packed[q][c][t][j][h][co][e] = w[o*so + i*si + t'],  o = co*on + q*oq,  i = (8j+4h+e)*in_ + c*iq,
+// t' = flip ? 8-t : t.  One thread per packed element.
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ packed, int cout_chunks,
+                                    int cin_chunks, long so, long si, int flip, int on, int oq, int in_, int iq) {
+  const long total = (long)cout_chunks * cin_chunks * 9 * 4096;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int e = r & 3;
+    r >>= 2;
+    const int co = r & 63;
+    r >>= 6;
+    const int h = r & 1;
+    r >>= 1;
+    const int j = r & 7;
+    r >>= 3;
+    const int t = r % 9;
+    r /= 9;
+    const int c = r % cin_chunks;
+    const int q = r / cin_chunks;
+    const long o = (long)co * on + (long)q * oq;
+    const long i = (long)(8 * j + 4 * h + e) * in_ + (long)c * iq;
+    packed[idx] = w[o * so + i * si + (flip ? 8 - t : t)];
+  }
+}
+
+static View view_from(const int64_t* v) {
+  View r;
+  r.sB = v[0];
+  r.sH = v[1];
+  r.sW = v[2];
+  r.chi = v[3];
+  r.clo = v[4];
+  r.cdiv = (int)v[5];
+  return r;
+}
+
+extern "C" int sisr_pack_conv3x3(const float* w, float* packed, int cout, int cin, int64_t so, int64_t si,
+                                 int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n, int in_perm_q,
+                                 void* stream) {
+  if (!w || !packed || cout <= 0 || cin <= 0 || (cout & 63) || (cin & 63)) return SISR_ERR_ARG;
+  const long total = (long)cout * cin * 9;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cout / 64,
+                     cin / 64, (long)so, (long)si, flip_taps, out_perm_n, out_perm_q, in_perm_n, in_perm_q);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_conv3x3_c64_gap_parts(int H, int W) { return ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * 2; }
+
+extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked, const float* bias,
+                                int bias_n, int bias_q, float* y, const int64_t* yview, const float* res,
+                                const float* mask, const float* in_scale, const float* in_shift,
+                                const float* out_scale, float alpha, int relu, float* gap_partial, int B, int H,
+                                int W, int cin, int cout, void* stream) {
+  if (!x || !wpacked || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
+  if (!sisr_aligned16(x) || !sisr_aligned16(wpacked) || !sisr_aligned16(in_scale) || !sisr_aligned16(in_shift))
+    return SISR_ERR_ALIGN;
+  ConvParams p;
+  p.x = x;
+  p.xv = view_from(xview);
+  p.y = y;
+  p.yv = view_from(yview);
+  if ((p.xv.sB | p.xv.sH | p.xv.sW | p.xv.chi | p.xv.clo) & 3) return SISR_ERR_ALIGN;  // 16-B pixel rows
+  p.res = res;
+  p.mask = mask;
+  p.w = wpacked;
+  p.bias = bias;
+  p.in_scale = in_scale;
+  p.in_shift = in_shift;
+  p.out_scale = out_scale;
+  p.gap = gap_partial;
+  p.alpha = alpha;
+  p.bias_n = bias_n;
+  p.bias_q = bias_q;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.cin_chunks = cin / 64;
+  p.cout_chunks = cout / 64;
+  p.relu = relu;
+  p.tiles_w = (W + TW - 1) / TW;
+  p.tiles_h = (H + TH - 1) / TH;
+  const long nblk = (long)p.tiles_w * p.tiles_h * B;
+  if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
+  const size_t lds_bytes = (size_t)HALO_H * HALO_W * PSTR * sizeof(float);
+  hipLaunchKernelGGL(conv3x3_c64_kernel, dim3((unsigned)nblk, p.cout_chunks), dim3(256), lds_bytes,
+                     (hipStream_t)stream, p);
+  return sisr_check_launch();
+}

@@ -1,0 +1,342 @@
+// 3x3 same-convolutions with a 3-channel side (the RGB ends of the network), fp32 VALU.
+//
+//   conv3x3_cin3  : planar NCHW (B,3,H,W) -> chunked NHWC (B,H,W,64k).   Head conv forward
+//                   (ref: advanced/architectures.py:141 head = default_conv(3, 64)) and the input
+//                   gradient of the tail conv.
+//   conv3x3_cout3 : chunked NHWC (B,H,W,64k) -> planar NCHW (B,3,H,W).   Tail conv forward
+//                   (ref: advanced/architectures.py:150-152 tail[1] = default_conv(64, 3)) and the
+//                   input gradient of the head conv.
+//   corr3x3_c3    : out[a][tap][c] = sum_{b,p} P[b][a][p+off(tap)] * Q[b][p][c], P planar 3-channel,
+//                   Q chunked NHWC -- the weight gradient of both of the above (+ bias sums).
+// K = 27 (or N = 3): far too thin for the matrix cores; these are HBM-bound streaming kernels
+// (the 512x512x64 map at the tail is the largest tensor in the network), written for coalesced
+// 256-B pixel rows.  Weights are addressed through generic (so, si, flip) strides so the same kernel
+// serves a forward pass (OIHW as stored) and a gradient pass (roles swapped, taps flipped).
+#include "sisr_common.h"
+
+static View view_from(const int64_t* v) {
+  View r;
+  r.sB = v[0];
+  r.sH = v[1];
+  r.sW = v[2];
+  r.chi = v[3];
+  r.clo = v[4];
+  r.cdiv = (int)v[5];
+  return r;
+}
+
+// ------------------------------------------------------------------ 3 -> 64k
+struct Cin3Params {
+  const float* x;  // [B][3][H][W]
+  float* y;
+  View yv;
+  const float* w;
+  const float* bias;
+  long so, si;
+  int flip, B, H, W, cout;
+};
+
+__global__ __launch_bounds__(256) void conv3x3_cin3_kernel(Cin3Params p) {
+  extern __shared__ float wl[];  // [27][cout]
+  for (int i = threadIdx.x; i < 27 * p.cout; i += 256) {
+    const int k = i / p.cout, co = i - k * p.cout;
+    const int ci = k / 9, t = k - ci * 9;
+    wl[i] = p.w[(long)co * p.so + (long)ci * p.si + (p.flip ? 8 - t : t)];
+  }
+  __syncthreads();
+  const int groups = p.cout >> 2;  // float4 groups per pixel
+  const long hw = (long)p.H * p.W;
+  const long total = (long)p.B * hw * groups;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long pix = i / groups;
+    const int cg = (int)(i - pix * groups);
+    const long b = pix / hw;
+    const long r = pix - b * hw;
+    const int h = (int)(r / p.W), w = (int)(r - (long)h * p.W);
+    const int co = cg * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) acc = (f32x4){p.bias[co], p.bias[co + 1], p.bias[co + 2], p.bias[co + 3]};
+    const float* xb = p.x + b * 3 * hw;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int gh = h + kh - 1, gw = w + kw - 1;
+          const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+          const float xv = ok ? xb[ci * hw + (long)gh * p.W + gw] : 0.f;
+          acc += xv * *reinterpret_cast<const f32x4*>(wl + (ci * 9 + kh * 3 + kw) * p.cout + co);
+        }
+    const int q = co >> 6;
+    *reinterpret_cast<f32x4*>(p.y + b * p.yv.sB + (long)h * p.yv.sH + (long)w * p.yv.sW + p.yv.chunk(q) + (co & 63)) = acc;
+  }
+}
+
+// ------------------------------------------------------------------ 64k -> 3
+struct Cout3Params {
+  const float* x;
+  View xv;
+  float* y;  // [B][3][H][W]
+  const float* w;
+  const float* bias;  // [3]
+  long so, si;
+  int flip, B, H, W, cin_chunks;
+};
+
+// 16 lanes per pixel, lane owns input channels [4*c4, 4*c4+4) of the current chunk; 108 weights in VGPRs.
+__global__ __launch_bounds__(256) void conv3x3_cout3_kernel(Cout3Params p) {
+  const int c4 = threadIdx.x & 15;
+  const long hw = (long)p.H * p.W;
+  const long npix = (long)p.B * hw;
+  const long gstride = (long)gridDim.x * 16;
+  for (long pix0 = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix0 < ((npix + 15) & ~15L); pix0 += gstride) {
+    const bool live = pix0 < npix;
+    const long pix = live ? pix0 : npix - 1;
+    const long b = pix / hw;
+    const long r = pix - b * hw;
+    const int h = (int)(r / p.W), w = (int)(r - (long)h * p.W);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int c = 0; c < p.cin_chunks; ++c) {
+      const float* xb = p.x + b * p.xv.sB + p.xv.chunk(c) + c4 * 4;
+      const long ci0 = (long)c * 64 + c4 * 4;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int gh = h + t / 3 - 1, gw = w + t % 3 - 1;
+        const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+        const int ch_ = min(max(gh, 0), p.H - 1), cw_ = min(max(gw, 0), p.W - 1);
+        const f32x4 xv = sisr_keep_if(*reinterpret_cast<const f32x4*>(xb + (long)ch_ * p.xv.sH + (long)cw_ * p.xv.sW), ok);
+        const int tt = p.flip ? 8 - t : t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* wp = p.w + (ci0 + e) * p.si + tt;  // L1/L2-resident (1728 floats), re-read per pixel
+          a0 += xv[e] * wp[0];
+          a1 += xv[e] * wp[p.so];
+          a2 += xv[e] * wp[2 * p.so];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      a0 += __shfl_xor(a0, o);
+      a1 += __shfl_xor(a1, o);
+      a2 += __shfl_xor(a2, o);
+    }
+    if (live && c4 < 3) {
+      float v = c4 == 0 ? a0 : (c4 == 1 ? a1 : a2);
+      if (p.bias) v += p.bias[c4];
+      p.y[(b * 3 + c4) * hw + r] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ correlation (weight gradients)
+struct Corr3Params {
+  const float* P;  // [B][3][H][W]
+  const float* Q;
+  View qv;
+  float* part;  // [blocks][chunks][31][64]: rows 0..26 = a*9 + tap, 27 = sum Q, 28..30 = sum P[a]
+  int B, H, W, chunks, blocks;
+};
+#define CORR_ROWS 31
+
+// thread (c = tid&63, pl = tid>>6); block handles a contiguous run of pixels; grid (blocks, chunks)
+__global__ __launch_bounds__(256) void corr3x3_c3_kernel(Corr3Params p) {
+  __shared__ float red[3][CORR_ROWS][64];
+  const int c = threadIdx.x & 63;
+  const int pl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = blockIdx.y;
+  const long hw = (long)p.H * p.W;
+  const long npix = (long)p.B * hw;
+  const long per = (npix + p.blocks - 1) / p.blocks;
+  const long p0 = (long)blockIdx.x * per;
+  const long p1 = p0 + per < npix ? p0 + per : npix;
+  float acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+  float qs = 0.f, ps0 = 0.f, ps1 = 0.f, ps2 = 0.f;
+  for (long pix = p0 + pl; pix < p1; pix += 4) {
+    const long b = pix / hw;
+    const long r = pix - b * hw;
+    const int h = (int)(r / p.W), w = (int)(r - (long)h * p.W);
+    const float qv = p.Q[b * p.qv.sB + (long)h * p.qv.sH + (long)w * p.qv.sW + p.qv.chunk(q) + c];
+    qs += qv;
+    const float* pb = p.P + b * 3 * hw;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int gh = h + t / 3 - 1, gw = w + t % 3 - 1;
+        const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+        const float pv = ok ? pb[a * hw + (long)gh * p.W + gw] : 0.f;  // wave-uniform address
+        acc[a * 9 + t] += pv * qv;
+        if (t == 4) {
+          if (a == 0) ps0 += pv;
+          if (a == 1) ps1 += pv;
+          if (a == 2) ps2 += pv;
+        }
+      }
+  }
+  if (pl > 0) {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) red[pl - 1][k][c] = acc[k];
+    red[pl - 1][27][c] = qs;
+    red[pl - 1][28][c] = ps0;
+    red[pl - 1][29][c] = ps1;
+    red[pl - 1][30][c] = ps2;
+  }
+  __syncthreads();
+  if (pl == 0) {
+    float* out = p.part + ((long)blockIdx.x * p.chunks + q) * CORR_ROWS * 64;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) out[k * 64 + c] = ((acc[k] + red[0][k][c]) + red[1][k][c]) + red[2][k][c];
+    out[27 * 64 + c] = ((qs + red[0][27][c]) + red[1][27][c]) + red[2][27][c];
+    out[28 * 64 + c] = ((ps0 + red[0][28][c]) + red[1][28][c]) + red[2][28][c];
+    out[29 * 64 + c] = ((ps1 + red[0][29][c]) + red[1][29][c]) + red[2][29][c];
+    out[30 * 64 + c] = ((ps2 + red[0][30][c]) + red[1][30][c]) + red[2][30][c];
+  }
+}
+
+struct Corr3Reduce {
+  const float* part;
+  float* dw;
+  float* db;
+  long so, si;
+  float alpha;
+  int blocks, chunks, flip, a_is_out;
+};
+
+// one thread per (chunk q, row k < 27, channel c) plus bias rows
+__global__ void corr3_reduce_kernel(Corr3Reduce p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_chunk = 27 * 64;
+  const int nw = p.chunks * per_chunk;
+  if (i < nw) {
+    const int q = i / per_chunk, r = i - q * per_chunk;
+    const int k = r >> 6, c = r & 63;
+    float s = 0.f;
+    for (int j = 0; j < p.blocks; ++j) s += p.part[((long)j * p.chunks + q) * CORR_ROWS * 64 + k * 64 + c];
+    const int a = k / 9, t = k - a * 9;
+    const long ch = (long)q * 64 + c;
+    const long o = p.a_is_out ? a : ch, ii = p.a_is_out ? ch : a;
+    p.dw[o * p.so + ii * p.si + (p.flip ? 8 - t : t)] = s * p.alpha;
+  } else if (p.db) {
+    const int j0 = i - nw;
+    if (p.a_is_out) {  // bias over the 3-channel side: sums of P (identical in every lane; take chunk 0, c = 0)
+      if (j0 < 3) {
+        float s = 0.f;
+        for (int j = 0; j < p.blocks; ++j) s += p.part[((long)j * p.chunks) * CORR_ROWS * 64 + (28 + j0) * 64];
+        p.db[j0] = s * p.alpha;
+      }
+    } else if (j0 < p.chunks * 64) {
+      const int q = j0 >> 6, c = j0 & 63;
+      float s = 0.f;
+      for (int j = 0; j < p.blocks; ++j) s += p.part[((long)j * p.chunks + q) * CORR_ROWS * 64 + 27 * 64 + c];
+      p.db[j0] = s * p.alpha;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int sisr_conv3x3_cin3(const float* x, const float* w, int64_t so, int64_t si, int flip_taps, const float* bias,
+                                 float* y, const int64_t* yview, int B, int H, int W, int cout, void* stream) {
+  if (!x || !w || !y || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if (cout <= 0 || (cout & 63) || cout > 512) return SISR_ERR_UNSUPPORTED;
+  Cin3Params p;
+  p.x = x;
+  p.y = y;
+  p.yv = view_from(yview);
+  if ((p.yv.sB | p.yv.sH | p.yv.sW | p.yv.chi | p.yv.clo) & 3 || !sisr_aligned16(y)) return SISR_ERR_ALIGN;
+  p.w = w;
+  p.bias = bias;
+  p.so = so;
+  p.si = si;
+  p.flip = flip_taps;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.cout = cout;
+  const long total = (long)B * H * W * (cout >> 2);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv3x3_cin3_kernel, dim3((unsigned)blocks), dim3(256), 27 * cout * sizeof(float),
+                     (hipStream_t)stream, p);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_conv3x3_cout3(const float* x, const int64_t* xview, const float* w, int64_t so, int64_t si,
+                                  int flip_taps, const float* bias, float* y, int B, int H, int W, int cin,
+                                  void* stream) {
+  if (!x || !w || !y || !xview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if (cin <= 0 || (cin & 63)) return SISR_ERR_UNSUPPORTED;
+  Cout3Params p;
+  p.x = x;
+  p.xv = view_from(xview);
+  if ((p.xv.sB | p.xv.sH | p.xv.sW | p.xv.chi | p.xv.clo) & 3 || !sisr_aligned16(x)) return SISR_ERR_ALIGN;
+  p.y = y;
+  p.w = w;
+  p.bias = bias;
+  p.so = so;
+  p.si = si;
+  p.flip = flip_taps;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.cin_chunks = cin / 64;
+  const long npix = (long)B * H * W;
+  long blocks = (npix + 15) / 16;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(conv3x3_cout3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return sisr_check_launch();
+}
+
+static int corr3_blocks(int B, int H, int W) {
+  const long npix = (long)B * H * W;
+  long nb = (npix + 1023) / 1024;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+extern "C" size_t sisr_corr3x3_c3_workspace_bytes(int B, int H, int W, int channels) {
+  if (B <= 0 || H <= 0 || W <= 0 || channels <= 0 || (channels & 63)) return 0;
+  return (size_t)corr3_blocks(B, H, W) * (channels / 64) * CORR_ROWS * 64 * sizeof(float);
+}
+
+// dw element for (3-channel index a, tap t, 64k-channel index c) goes to
+//   dw[o*so + i*si + (flip ? 8-t : t)],  (o,i) = a_is_out ? (a,c) : (c,a)
+// db: a_is_out ? 3 sums of P : `channels` sums of Q.
+extern "C" int sisr_corr3x3_c3(const float* P, const float* Q, const int64_t* qview, float alpha, float* dw, int64_t so,
+                               int64_t si, int flip_taps, int a_is_out, float* dbias, float* workspace,
+                               size_t workspace_bytes, int B, int H, int W, int channels, void* stream) {
+  if (!P || !Q || !qview || !dw || !workspace || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if (channels <= 0 || (channels & 63)) return SISR_ERR_UNSUPPORTED;
+  if (workspace_bytes < sisr_corr3x3_c3_workspace_bytes(B, H, W, channels)) return SISR_ERR_ARG;
+  Corr3Params p;
+  p.P = P;
+  p.Q = Q;
+  p.qv = view_from(qview);
+  p.part = workspace;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.chunks = channels / 64;
+  p.blocks = corr3_blocks(B, H, W);
+  hipLaunchKernelGGL(corr3x3_c3_kernel, dim3(p.blocks, p.chunks), dim3(256), 0, (hipStream_t)stream, p);
+  int rc = sisr_check_launch();
+  if (rc) return rc;
+  Corr3Reduce r;
+  r.part = workspace;
+  r.dw = dw;
+  r.db = dbias;
+  r.so = so;
+  r.si = si;
+  r.alpha = alpha;
+  r.blocks = p.blocks;
+  r.chunks = p.chunks;
+  r.flip = flip_taps;
+  r.a_is_out = a_is_out;
+  const int total = p.chunks * 27 * 64 + (dbias ? (a_is_out ? 3 : channels) : 0);
+  hipLaunchKernelGGL(corr3_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
+  return sisr_check_launch();
+}

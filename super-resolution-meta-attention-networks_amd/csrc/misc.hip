@@ -1,0 +1,103 @@
+// L1 loss (forward value + unit-scale gradient) and a flat fused Adam step, fp32.
+//
+//   L1   (ref: SISR/models/__init__.py:268 nn.L1Loss(), :472 criterion(out, y)):
+//          loss = mean |a - b|;   dloss/da = sign(a - b) / N      (sign(0) = 0, as torch)
+//   Adam (ref: SISR/models/__init__.py:299-308 optim.Adam(lr, betas), no weight decay / amsgrad):
+//          m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//          p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+// Both are single-pass HBM-bound streams; the loss reduction is two-stage and ordered.
+#include "sisr_common.h"
+
+#define L1_BLOCKS 512
+
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ grad, float inv_n, long n,
+                                                         float* __restrict__ part) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    s += fabsf(d);
+    if (grad) grad[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ part, int nparts, float inv_n,
+                                                       float* __restrict__ loss) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = red[0] * inv_n;
+}
+
+extern "C" size_t sisr_l1_loss_workspace_bytes() { return L1_BLOCKS * sizeof(float); }
+
+extern "C" int sisr_l1_loss(const float* a, const float* b, long n, float* loss, float* grad, float* workspace,
+                            void* stream) {
+  if (!a || !b || !loss || !workspace || n <= 0) return SISR_ERR_ARG;
+  long blocks = (n + 255) / 256;
+  if (blocks > L1_BLOCKS) blocks = L1_BLOCKS;
+  const float inv_n = 1.0f / (float)n;
+  hipLaunchKernelGGL(l1_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, grad, inv_n, n,
+                     workspace);
+  int rc = sisr_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, (int)blocks, inv_n, loss);
+  return sisr_check_launch();
+}
+
+// step_size = lr / (1 - b1^t), inv_bc2_sqrt = 1 / sqrt(1 - b2^t) are computed on the host in double.
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long n4, long n,
+                                                        float b1, float b2, float eps, float step_size,
+                                                        float inv_bc2_sqrt, float gscale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 gg = reinterpret_cast<const f32x4*>(g)[i] * gscale;
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+    // torch: exp_avg.lerp_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(grad, grad, 1-b2)
+    mm = mm + (gg - mm) * (1.f - b1);
+    vv = vv * b2 + gg * gg * (1.f - b2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pp[e] -= step_size * (mm[e] / (sqrtf(vv[e]) * inv_bc2_sqrt + eps));
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
+    const long i = (n4 << 2) + threadIdx.x;
+    const float gg = g[i] * gscale;
+    const float mm = m[i] + (gg - m[i]) * (1.f - b1);
+    const float vv = v[i] * b2 + gg * gg * (1.f - b2);
+    p[i] -= step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+
+extern "C" int sisr_adam_flat(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
+                              float step_size, float inv_bc2_sqrt, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || n <= 0) return SISR_ERR_ARG;
+  if (!sisr_aligned16(p) || !sisr_aligned16(g) || !sisr_aligned16(m) || !sisr_aligned16(v)) return SISR_ERR_ALIGN;
+  const long n4 = n >> 2;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
+                     beta2, eps, step_size, inv_bc2_sqrt, grad_scale);
+  return sisr_check_launch();
+}

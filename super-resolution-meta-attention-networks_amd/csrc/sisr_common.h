@@ -1,0 +1,44 @@
+// Shared device/host definitions for the gfx950 SISR kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// A 64-channel-chunked view of an activation in HBM.  Element (b, h, w, chunk q, c) lives at
+//   p + b*sB + h*sH + w*sW + (q / cdiv)*chi + (q % cdiv)*clo + c          (all strides in floats)
+// Plain NHWC with C = 64*k channels: sW = C, cdiv = huge, clo = 64.
+// PixelShuffle(r) output seen as the conv's (B,H,W,64*r*r) result: physical tensor is
+// [B][H*r][W*r][64]; sH = r*(W*r*64), sW = r*64, cdiv = r, chi = W*r*64, clo = 64, and chunk
+// q = i*r + j carries original channels {c*r*r + q}.  The shuffle is therefore free: it is only an
+// address map (ref: advanced/common.py:28-31 conv -> nn.PixelShuffle).
+struct View {
+  long sB, sH, sW;
+  long chi, clo;
+  int cdiv;
+  __host__ __device__ long chunk(int q) const { return (long)(q / cdiv) * chi + (long)(q % cdiv) * clo; }
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// Zero a float4 with a lane mask by bitwise AND: exact zeros even if the (clamped-address) load
+// returned Inf/NaN, and -- unlike `ok ? t : 0` -- hipcc cannot turn it back into a branch around the
+// load (which would serialise the staging loads behind s_waitcnt vmcnt(0)).
+__device__ __forceinline__ f32x4 sisr_keep_if(f32x4 t, bool ok) {
+  const unsigned m = ok ? 0xffffffffu : 0u;
+  u32x4 b = __builtin_bit_cast(u32x4, t);
+  b &= (u32x4){m, m, m, m};
+  return __builtin_bit_cast(f32x4, b);
+}
+
+#define SISR_OK 0
+#define SISR_ERR_ARG (-1)
+#define SISR_ERR_ALIGN (-2)
+#define SISR_ERR_LAUNCH (-3)
+#define SISR_ERR_UNSUPPORTED (-4)
+
+static inline int sisr_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SISR_OK : SISR_ERR_LAUNCH - (int)e * 16;
+}
+static inline bool sisr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

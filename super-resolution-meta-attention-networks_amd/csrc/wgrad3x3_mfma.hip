@@ -1,0 +1,303 @@
+// Weight (and bias) gradient of the 3x3 same-convolution over 64-channel chunks, fp32 MFMA.
+//
+//   dW[co][ci][kh][kw] = alpha * sum_{b,h,w} X[b][h+kh-1][w+kw-1][ci] * dY'[b][h][w][co]
+//   db[co]             = alpha * sum_{b,h,w} dY'[b][h][w][co]
+//   dY' = dY * dy_scale[b][co] + dy_shift[b][co]   (optional; the RCAB backward never materialises
+//                                                  dRes = dOut*g + c, it is rebuilt on load)
+// This is autograd's convolution_backward weight/bias output for the reference's default_conv
+// (advanced/common.py:5-8); GEMM shape M = 32 ci, N = 32 co, K = pixels per quadrant.
+//
+// Decomposition: blockIdx.y = ((cin_chunk*cout_chunks + cout_chunk)*4 + quadrant), quadrant =
+// (ci half, co half); blockIdx.x = K-slice s of S.  A workgroup (4 waves) walks 8x32-pixel tiles
+// s, s+S, ...; per tile it stages the 32-channel halves of the X halo (10x34 px) and of dY (8x32 px)
+// in LDS, and wave w owns tile rows {2w,2w+1}: per pixel pair one B read (dY) and nine A reads (X at
+// the nine taps) feed nine 32x32x2 MFMAs into nine persistent accumulators (144 VGPRs).  After the
+// last tile the four waves' accumulators are summed through LDS in a fixed order and written as one
+// slab; a second kernel adds the S slabs in index order (deterministic, no atomics) and scatters
+// into the OIHW gradient.  Splitting the OUTPUT four ways instead of giving each wave a quadrant
+// cuts the slab traffic 4x (36.9 KB per workgroup) at the price of re-reading the inputs from L2.
+#include "sisr_common.h"
+
+#define WT_H 8
+#define WT_W 32
+#define WH_H (WT_H + 2)
+#define WH_W (WT_W + 2)
+#define WSTR 32                                   // floats per pixel in LDS (32-channel half)
+#define X_ITEMS (WH_H * WH_W * 8)                 // float4 items: 2720
+#define X_ITERS ((X_ITEMS + 255) / 256)           // 11
+#define Y_ITEMS (WT_H * WT_W * 8)                 // 2048
+#define Y_ITERS (Y_ITEMS / 256)                   // 8
+#define LDS_X (WH_H * WH_W * WSTR)                // floats
+#define LDS_Y (WT_H * WT_W * WSTR)
+#define SLAB (9 * 16 * 64)                        // floats per workgroup slab: 9216
+
+struct WgradParams {
+  const float* x;
+  View xv;
+  const float* dy;
+  View yv;
+  const float* dy_scale;
+  const float* dy_shift;
+  float* slabs;      // [S][gridDim.y][SLAB]
+  float* bias_slabs; // [S][cout_chunks*2][32] (written by ci-quadrant 0 of cin chunk 0) or null
+  int B, H, W, cin_chunks, cout_chunks, tiles_w, tiles_h, S;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldx = lds;
+  float* ldy = lds + LDS_X;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int unit = blockIdx.y;
+  const int quad = unit & 3, pair = unit >> 2;
+  const int cq = pair % p.cout_chunks, cc = pair / p.cout_chunks;
+  const int cih = quad >> 1, coh = quad & 1;
+  const int i = lane & 31, kk = lane >> 5;
+  const int H = p.H, W = p.W;
+  const bool do_bias = p.bias_slabs && cc == 0 && cih == 0;
+  const int Cout = p.cout_chunks * 64;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x16){0};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};  // this thread's 4 channels (tid&7) of the dY column sums
+
+  const int tiles_per_img = p.tiles_w * p.tiles_h;
+  const int total = tiles_per_img * p.B;
+  for (int tile = blockIdx.x; tile < total; tile += p.S) {
+    const int b = tile / tiles_per_img;
+    const int tr = tile - b * tiles_per_img;
+    const int th = tr / p.tiles_w, tw = tr - th * p.tiles_w;
+    const int h0 = th * WT_H, w0 = tw * WT_W;
+    __syncthreads();  // previous tile fully consumed
+    {  // branch-free staging: clamped address + select (all loads of a thread in flight together)
+      const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(cc) + cih * 32;
+      const int c4 = tid & 7;  // constant per thread: both item strides (256) are multiples of 8
+      // 144 accumulator VGPRs are live here, so the loads go in batches of <= 6 float4 (24 VGPRs)
+#pragma unroll
+      for (int base = 0; base < X_ITERS; base += 6) {
+        f32x4 v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const int it = base + k;
+          if (it < X_ITERS) {
+            const int pix = (it * 256 + tid) >> 3;
+            const int pr = pix / WH_W, pc = pix - pr * WH_W;
+            const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
+            const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
+            const int ch_ = min(max(gh, 0), H - 1), cw_ = min(max(gw, 0), W - 1);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(xb + (long)ch_ * p.xv.sH + (long)cw_ * p.xv.sW + c4 * 4);
+            v[k] = sisr_keep_if(t, ok);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const int idx = (base + k) * 256 + tid;
+          if (base + k < X_ITERS && idx < X_ITEMS) *reinterpret_cast<f32x4*>(ldx + (idx >> 3) * WSTR + c4 * 4) = v[k];
+        }
+      }
+      const float* yb = p.dy + (long)b * p.yv.sB + p.yv.chunk(cq) + coh * 32;
+      f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.dy_scale) s4 = *reinterpret_cast<const f32x4*>(p.dy_scale + (long)b * Cout + cq * 64 + coh * 32 + c4 * 4);
+      if (p.dy_shift) t4 = *reinterpret_cast<const f32x4*>(p.dy_shift + (long)b * Cout + cq * 64 + coh * 32 + c4 * 4);
+#pragma unroll
+      for (int base = 0; base < Y_ITERS; base += 4) {
+        f32x4 u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int pix = ((base + k) * 256 + tid) >> 3;
+          const int gh = h0 + (pix >> 5), gw = w0 + (pix & 31);
+          const bool ok = gh < H && gw < W;
+          const int ch_ = min(gh, H - 1), cw_ = min(gw, W - 1);
+          const f32x4 t = *reinterpret_cast<const f32x4*>(yb + (long)ch_ * p.yv.sH + (long)cw_ * p.yv.sW + c4 * 4);
+          u[k] = sisr_keep_if(t * s4 + t4, ok);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          *reinterpret_cast<f32x4*>(ldy + (((base + k) * 256 + tid) >> 3) * WSTR + c4 * 4) = u[k];
+          bsum += u[k];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- wave w: rows 2w, 2w+1; 16 pixel pairs per row; K index (lane>>5) = pixel parity
+#pragma unroll 1
+    for (int r = 2 * wave; r < 2 * wave + 2; ++r) {
+      const float* xa = ldx + (r * WH_W + kk) * WSTR + i;      // tap (0,0) of pair u=0
+      const float* yb = ldy + (r * WT_W + kk) * WSTR + i;
+#pragma unroll 4
+      for (int u = 0; u < 16; ++u) {
+        const float bv = yb[u * 2 * WSTR];
+        float av[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) av[t] = xa[((t / 3) * WH_W + (t % 3) + 2 * u) * WSTR];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- sum the four waves' accumulators through LDS (fixed order: ((w0+w2)+(w1+w3)) ), write slab
+  __syncthreads();
+  float* red = lds;  // 2 * SLAB floats = 73.7 KB <= LDS_X + LDS_Y (76.3 KB)
+  if (wave >= 2) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave - 2) * SLAB + (t * 16 + r) * 64 + lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] += red[wave * SLAB + (t * 16 + r) * 64 + lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[t][r];
+  }
+  if (do_bias) *reinterpret_cast<f32x4*>(red + SLAB + tid * 4) = bsum;
+  __syncthreads();
+  if (wave == 0) {
+    float* out = p.slabs + ((long)blockIdx.x * gridDim.y + unit) * SLAB;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64 + lane] = acc[t][r] + red[(t * 16 + r) * 64 + lane];
+  }
+  if (do_bias && tid < 32) {  // channel tid = (c4 = tid>>2, e = tid&3): threads with tid&7 == c4 hold it
+    float s = 0.f;
+    const int c4 = tid >> 2, e = tid & 3;
+    for (int k = 0; k < 32; ++k) s += red[SLAB + (k * 8 + c4) * 4 + e];
+    p.bias_slabs[((long)blockIdx.x * p.cout_chunks * 2 + cq * 2 + coh) * 32 + tid] = s;
+  }
+}
+
+// Sum S slabs per output element in slab order and scatter to dW (generic strides / channel maps):
+// element (unit, tap t, reg r, lane l): ci_local = (r&3) + 8*(r>>2) + 4*(l>>5), co_local = l&31.
+struct ReduceParams {
+  const float* slabs;
+  const float* bias_slabs;
+  float* dw;
+  float* db;
+  long so, si;
+  float alpha;
+  int S, units, cin_chunks, cout_chunks, flip, on, oq, in_, iq, bias_n, bias_q;
+};
+
+__global__ void wgrad_reduce_kernel(ReduceParams p) {
+  const long total = (long)p.units * SLAB;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < total) {
+    const int unit = (int)(gid / SLAB);
+    const int e = (int)(gid - (long)unit * SLAB);
+    float s = 0.f;
+    for (int k = 0; k < p.S; ++k) s += p.slabs[((long)k * p.units + unit) * SLAB + e];
+    const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
+    const int quad = unit & 3, pair = unit >> 2;
+    const int cq = pair % p.cout_chunks, cc = pair / p.cout_chunks;
+    const int ci = (quad >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    const int co = (quad & 1) * 32 + (l & 31);
+    const long o = (long)co * p.on + (long)cq * p.oq;
+    const long ii = (long)ci * p.in_ + (long)cc * p.iq;
+    p.dw[o * p.so + ii * p.si + (p.flip ? 8 - t : t)] = s * p.alpha;
+  } else if (p.db) {
+    const long j = gid - total;  // 0 .. cout-1 in (cq, coh, n) order
+    if (j < (long)p.cout_chunks * 64) {
+      float s = 0.f;
+      for (int k = 0; k < p.S; ++k) s += p.bias_slabs[(long)k * p.cout_chunks * 64 + j];
+      const int cq = (int)(j >> 6), co = (int)(j & 63);
+      p.db[(long)co * p.bias_n + (long)cq * p.bias_q] = s * p.alpha;
+    }
+  }
+}
+
+static View view_from(const int64_t* v) {
+  View r;
+  r.sB = v[0];
+  r.sH = v[1];
+  r.sW = v[2];
+  r.chi = v[3];
+  r.clo = v[4];
+  r.cdiv = (int)v[5];
+  return r;
+}
+
+static int wgrad_split(int B, int H, int W, int units) {
+  const long tiles = (long)B * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+  long S = 512 / units;  // two workgroups per CU resident across the whole grid
+  if (S < 1) S = 1;
+  if (S > tiles) S = tiles;
+  return (int)S;
+}
+
+extern "C" size_t sisr_wgrad3x3_c64_workspace_bytes(int B, int H, int W, int cin, int cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
+  const int units = (cin / 64) * (cout / 64) * 4;
+  const int S = wgrad_split(B, H, W, units);
+  return ((size_t)S * units * SLAB + (size_t)S * cout) * sizeof(float);
+}
+
+extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
+                                 const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so,
+                                 int64_t si, int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n,
+                                 int in_perm_q, float* dbias, int bias_n, int bias_q, float* workspace,
+                                 size_t workspace_bytes, int B, int H, int W, int cin, int cout, void* stream) {
+  if (!x || !dy || !dw || !xview || !dyview || !workspace || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
+  if (workspace_bytes < sisr_wgrad3x3_c64_workspace_bytes(B, H, W, cin, cout)) return SISR_ERR_ARG;
+  if (!sisr_aligned16(x) || !sisr_aligned16(dy) || !sisr_aligned16(workspace) || !sisr_aligned16(dy_scale) ||
+      !sisr_aligned16(dy_shift))
+    return SISR_ERR_ALIGN;
+  WgradParams p;
+  p.x = x;
+  p.xv = view_from(xview);
+  p.dy = dy;
+  p.yv = view_from(dyview);
+  if ((p.xv.sB | p.xv.sH | p.xv.sW | p.xv.chi | p.xv.clo | p.yv.sB | p.yv.sH | p.yv.sW | p.yv.chi | p.yv.clo) & 3)
+    return SISR_ERR_ALIGN;
+  p.dy_scale = dy_scale;
+  p.dy_shift = dy_shift;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.cin_chunks = cin / 64;
+  p.cout_chunks = cout / 64;
+  p.tiles_w = (W + WT_W - 1) / WT_W;
+  p.tiles_h = (H + WT_H - 1) / WT_H;
+  const int units = p.cin_chunks * p.cout_chunks * 4;
+  p.S = wgrad_split(B, H, W, units);
+  p.slabs = workspace;
+  p.bias_slabs = dbias ? workspace + (size_t)p.S * units * SLAB : nullptr;
+  const size_t lds_bytes = (size_t)(LDS_X + LDS_Y) * sizeof(float);
+  hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(p.S, units), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  int rc = sisr_check_launch();
+  if (rc) return rc;
+  ReduceParams r;
+  r.slabs = p.slabs;
+  r.bias_slabs = p.bias_slabs;
+  r.dw = dw;
+  r.db = dbias;
+  r.so = so;
+  r.si = si;
+  r.alpha = alpha;
+  r.S = p.S;
+  r.units = units;
+  r.cin_chunks = p.cin_chunks;
+  r.cout_chunks = p.cout_chunks;
+  r.flip = flip_taps;
+  r.on = out_perm_n;
+  r.oq = out_perm_q;
+  r.in_ = in_perm_n;
+  r.iq = in_perm_q;
+  r.bias_n = bias_n;
+  r.bias_q = bias_q;
+  const long total = (long)units * SLAB + (dbias ? cout : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r);
+  return sisr_check_launch();
+}

@@ -1,0 +1,150 @@
+"""ctypes binding of libsisr_hip.so (the C ABI in include/sisr_hip.h).
+
+This is the only place the package touches native code.  There is no fallback: if the
+library is missing, or a tensor is not on a HIP device, the call raises.  PyTorch is used
+for device memory and streams only (``tensor.data_ptr()``, ``torch.cuda.current_stream()``).
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_long, c_size_t, c_void_p
+
+import torch  # noqa: F401  (must be imported first: libsisr_hip.so binds to torch's libamdhip64.so.7 by SONAME)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsisr_hip.so")
+_lib = None
+
+P = c_void_p
+_SIGS = {
+    "sisr_pack_conv3x3": (c_int, [P, P, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P]),
+    "sisr_conv3x3_c64_gap_parts": (c_int, [c_int, c_int]),
+    "sisr_conv3x3_c64": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, c_float, c_int, P, c_int, c_int, c_int,
+                                 c_int, c_int, P]),
+    "sisr_wgrad3x3_c64_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "sisr_wgrad3x3_c64": (c_int, [P, P, P, P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
+                                  c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+    "sisr_conv3x3_cin3": (c_int, [P, P, c_int64, c_int64, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "sisr_conv3x3_cout3": (c_int, [P, P, P, c_int64, c_int64, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "sisr_corr3x3_c3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sisr_corr3x3_c3": (c_int, [P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, P, P, c_size_t, c_int, c_int, c_int,
+                                c_int, P]),
+    "sisr_ca_gate_fwd": (c_int, [P, c_int, c_int, c_float, P, P, P, P, c_int, c_int, P, P, P, P, P, P]),
+    "sisr_ca_gate_bwd": (c_int, [P, c_int, c_int, c_float, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
+    "sisr_meta_gate_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P]),
+    "sisr_meta_gate_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P]),
+    "sisr_gate_residual_fwd": (c_int, [P, P, P, P, P, c_int, c_long, c_int, P]),
+    "sisr_gate_dg_parts": (c_int, [c_long]),
+    "sisr_gate_dg_partial": (c_int, [P, P, P, c_int, c_long, c_int, P]),
+    "sisr_sum_partials": (c_int, [P, c_int, c_int, c_int, c_float, P, P]),
+    "sisr_l1_loss_workspace_bytes": (c_size_t, []),
+    "sisr_l1_loss": (c_int, [P, P, c_long, P, P, P, P]),
+    "sisr_adam_flat": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_float, P]),
+}
+OPTIONAL_SIGS = {
+    "sisr_lam_workspace_bytes": (c_size_t, [c_int, c_int, c_long]),
+    "sisr_lam_fwd": (c_int, [P, c_float, P, P, P, c_int, c_int, c_long, P]),
+    "sisr_lam_bwd": (c_int, [P, P, c_float, P, P, P, P, c_int, c_int, c_long, P]),
+    "sisr_csam_fwd": (c_int, [P, P, c_float, c_float, P, c_int, c_int, c_int, c_int, P]),
+    "sisr_csam_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sisr_csam_bwd": (c_int, [P, P, c_float, c_float, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+}
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly if the .so was never built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(or csrc/build.sh).  This package has no CPU or PyTorch fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in list(_SIGS.items()) + list(OPTIONAL_SIGS.items()):
+            if name in OPTIONAL_SIGS and not hasattr(L, name):
+                continue
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS) + sorted(k for k in OPTIONAL_SIGS if hasattr(lib(), k))
+
+
+_ERR = {-1: "bad argument", -2: "misaligned pointer or stride (16 B required)", -4: "unsupported shape"}
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = _ERR.get(rc, f"HIP launch failure (hipError {(-rc - 3) // 16})" if rc <= -3 else "error")
+        raise RuntimeError(f"{what} failed: {msg} (rc={rc})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses non-HIP tensors: there is no CPU path."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("sisr HIP kernels need tensors on a HIP device (cuda:N); got a CPU tensor. "
+                           "There is no CPU fallback in this package.")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"sisr HIP kernels are fp32; got {t.dtype}")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_view_cache = {}
+HUGE = 1 << 30
+
+
+def view_plain(H, W, C, sB=None):
+    """NHWC tensor with C (multiple of 64) channels; optional batch stride override (floats)."""
+    key = ("p", H, W, C, sB)
+    v = _view_cache.get(key)
+    if v is None:
+        v = (c_int64 * 6)(H * W * C if sB is None else sB, W * C, C, 0, 64, HUGE)
+        _view_cache[key] = v
+    return v
+
+
+def view_maps(H, W, nmaps, sB=None):
+    """[B][nmaps][H][W][64] stack read as an NHWC tensor with nmaps*64 channels (chunk q = map q)."""
+    key = ("m", H, W, nmaps, sB)
+    v = _view_cache.get(key)
+    if v is None:
+        v = (c_int64 * 6)(nmaps * H * W * 64 if sB is None else sB, W * 64, 64, 0, H * W * 64, HUGE)
+        _view_cache[key] = v
+    return v
+
+
+def view_shuffle(H, W, r):
+    """The (B,H,W,64*r*r) result of a conv whose PixelShuffle(r) output is the [B][rH][rW][64] tensor."""
+    key = ("s", H, W, r)
+    v = _view_cache.get(key)
+    if v is None:
+        rH, rW = r * H, r * W
+        v = (c_int64 * 6)(rH * rW * 64, r * rW * 64, r * 64, rW * 64, 64, r)
+        _view_cache[key] = v
+    return v
+
+
+_workspaces = {}
+
+
+def workspace(device, nbytes):
+    """Grow-only per-device scratch (all kernels of a step run in order on one stream)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=torch.float32, device=device)
+        _workspaces[key] = buf
+    return buf

@@ -1,0 +1,529 @@
+"""Autograd operators over the HIP kernels (host side stays Python, as north_star asks).
+
+Layout contract: feature maps are logical (B, C, H, W) tensors with channels_last strides, i.e.
+physically NHWC, C a multiple of 64; RGB tensors (C == 3) are plain contiguous NCHW.  Every
+operator returns tensors in that contract, so a network never converts layouts internally.
+
+Operators
+  conv3x3        default_conv forward/backward incl. fused residual / scalar scale / PixelShuffle store
+                 (ref: advanced/common.py:5-8, :20-45)
+  res_block      conv-ReLU-conv (+gate) + skip as ONE autograd node: RCAB, QRCAB('standard'), ResBlock,
+                 ParamResBlock (ref: advanced/architectures.py:48-71, advanced/common.py:48-72,
+                 attention_manipulators/architectures.py:145-180, :332-356)
+  meta_gate      ParaCALayer FC stack -> per-(b,c) gate (ref: attention_manipulators/q_layer.py:4-43)
+  ca_layer / gate_mul   stand-alone CALayer / x*gate (ref: advanced/architectures.py:13-32)
+  l1_loss        nn.L1Loss(mean) (ref: SISR/models/__init__.py:268)
+"""
+import torch
+from torch.autograd import Function
+
+from . import hip
+
+CL = torch.channels_last
+
+
+def _cl(x):
+    return x if x.is_contiguous(memory_format=CL) else x.contiguous(memory_format=CL)
+
+
+def _empty_cl(B, C, H, W, device):
+    return torch.empty((B, C, H, W), device=device, dtype=torch.float32, memory_format=CL)
+
+
+def _vec(B, C, device):
+    return torch.empty((B, C), device=device, dtype=torch.float32)
+
+
+# ----------------------------------------------------------------------------- raw launches (no autograd)
+def pack_weight(w, mode, shuffle=1):
+    """OIHW fp32 weight -> B-fragment order of the MFMA conv ('fwd') or of its input gradient ('dgrad')."""
+    cout, cin = w.shape[0], w.shape[1]
+    packed = torch.empty(cout * cin * 9, device=w.device, dtype=torch.float32)
+    rr = shuffle * shuffle
+    if mode == "fwd":
+        on, oq = (rr, 1) if shuffle > 1 else (1, 64)
+        rc = hip.lib().sisr_pack_conv3x3(hip.ptr(w), hip.ptr(packed), cout, cin, cin * 9, 9, 0, on, oq, 1, 64,
+                                         hip.stream())
+    else:
+        in_, iq = (rr, 1) if shuffle > 1 else (1, 64)
+        rc = hip.lib().sisr_pack_conv3x3(hip.ptr(w), hip.ptr(packed), cin, cout, 9, cin * 9, 1, 1, 64, in_, iq,
+                                         hip.stream())
+    hip.check(rc, "sisr_pack_conv3x3")
+    return packed
+
+
+def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=None, mask=None, in_scale=None,
+             in_shift=None, out_scale=None, alpha=1.0, relu=False, gap=None):
+    rc = hip.lib().sisr_conv3x3_c64(hip.ptr(x), xview, hip.ptr(packed), hip.ptr(bias), bias_nq[0], bias_nq[1],
+                                    hip.ptr(y), yview, hip.ptr(res), hip.ptr(mask), hip.ptr(in_scale),
+                                    hip.ptr(in_shift), hip.ptr(out_scale), float(alpha), int(relu), hip.ptr(gap), B, H,
+                                    W, cin, cout, hip.stream())
+    hip.check(rc, "sisr_conv3x3_c64")
+
+
+def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_scale=None, dy_shift=None, shuffle=1):
+    L = hip.lib()
+    nbytes = L.sisr_wgrad3x3_c64_workspace_bytes(B, H, W, cin, cout)
+    ws = hip.workspace(x.device, nbytes)
+    rr = shuffle * shuffle
+    on, oq = (rr, 1) if shuffle > 1 else (1, 64)
+    rc = L.sisr_wgrad3x3_c64(hip.ptr(x), xview, hip.ptr(dy), dyview, hip.ptr(dy_scale), hip.ptr(dy_shift),
+                             float(alpha), hip.ptr(dw), cin * 9, 9, 0, on, oq, 1, 64, hip.ptr(db), on, oq, hip.ptr(ws),
+                             nbytes, B, H, W, cin, cout, hip.stream())
+    hip.check(rc, "sisr_wgrad3x3_c64")
+
+
+def gap_parts(H, W):
+    return hip.lib().sisr_conv3x3_c64_gap_parts(H, W)
+
+
+# ----------------------------------------------------------------------------- conv3x3
+class _Conv3x3(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, alpha, shuffle):
+        cout, cin = weight.shape[0], weight.shape[1]
+        B, _, H, W = x.shape
+        dev = x.device
+        w = weight.contiguous()
+        ctx.alpha, ctx.shuffle, ctx.geom = alpha, shuffle, (B, H, W, cin, cout)
+        ctx.has_res = residual is not None
+        if cin % 64 == 0 and cout % 64 == 0:
+            x = _cl(x)
+            packed = pack_weight(w, "fwd", shuffle)
+            if shuffle > 1:
+                if cout != 64 * shuffle * shuffle:
+                    raise NotImplementedError("fused PixelShuffle needs Cout == 64*r*r")
+                y = _empty_cl(B, 64, H * shuffle, W * shuffle, dev)
+                yview, bnq = hip.view_shuffle(H, W, shuffle), (shuffle * shuffle, 1)
+            else:
+                y = _empty_cl(B, cout, H, W, dev)
+                yview, bnq = hip.view_plain(H, W, cout), (1, 64)
+            res = _cl(residual) if residual is not None else None
+            conv_c64(x, hip.view_plain(H, W, cin), packed, bias, bnq, y, yview, B, H, W, cin, cout, res=res,
+                     alpha=alpha)
+            ctx.kind = "c64"
+        elif cin == 3 and cout % 64 == 0:
+            if shuffle > 1 or residual is not None or alpha != 1.0:
+                raise NotImplementedError("3->64k conv has no fused epilogue")
+            x = x.contiguous()
+            y = _empty_cl(B, cout, H, W, dev)
+            rc = hip.lib().sisr_conv3x3_cin3(hip.ptr(x), hip.ptr(w), 27, 9, 0, hip.ptr(bias), hip.ptr(y),
+                                             hip.view_plain(H, W, cout), B, H, W, cout, hip.stream())
+            hip.check(rc, "sisr_conv3x3_cin3")
+            ctx.kind = "cin3"
+        elif cout == 3 and cin % 64 == 0:
+            if shuffle > 1 or residual is not None or alpha != 1.0:
+                raise NotImplementedError("64k->3 conv has no fused epilogue")
+            x = _cl(x)
+            y = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
+            rc = hip.lib().sisr_conv3x3_cout3(hip.ptr(x), hip.view_plain(H, W, cin), hip.ptr(w), cin * 9, 9, 0,
+                                              hip.ptr(bias), hip.ptr(y), B, H, W, cin, hip.stream())
+            hip.check(rc, "sisr_conv3x3_cout3")
+            ctx.kind = "cout3"
+        else:
+            raise NotImplementedError(
+                f"conv3x3 {cin}->{cout}: the gfx950 kernels cover channel counts that are multiples of 64 and the "
+                f"3-channel RGB ends (the reference's in-scope configs all use n_feats = 64 or 256)")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, H, W, cin, cout = ctx.geom
+        dev = x.device
+        L = hip.lib()
+        need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
+        dx = dw = db = dres = None
+        if ctx.kind == "c64":
+            dy = _cl(dy)
+            r = ctx.shuffle
+            dyview = hip.view_shuffle(H, W, r) if r > 1 else hip.view_plain(H, W, cout)
+            if need_x:
+                packed = pack_weight(w, "dgrad", r)
+                dx = _empty_cl(B, cin, H, W, dev)
+                conv_c64(dy, dyview, packed, None, (1, 64), dx, hip.view_plain(H, W, cin), B, H, W, cout, cin,
+                         alpha=ctx.alpha)
+            if need_w or need_b:
+                dw = torch.empty_like(w)
+                db = torch.empty(cout, device=dev, dtype=torch.float32) if ctx.has_bias else None
+                wgrad_c64(x, hip.view_plain(H, W, cin), dy, dyview, dw, db, B, H, W, cin, cout, alpha=ctx.alpha,
+                          shuffle=r)
+            if ctx.has_res and need_r:
+                dres = dy
+        elif ctx.kind == "cin3":
+            dy = _cl(dy)
+            if need_x:
+                dx = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
+                rc = L.sisr_conv3x3_cout3(hip.ptr(dy), hip.view_plain(H, W, cout), hip.ptr(w), 9, 27, 1, None,
+                                          hip.ptr(dx), B, H, W, cout, hip.stream())
+                hip.check(rc, "sisr_conv3x3_cout3(dgrad)")
+            if need_w or need_b:
+                dw = torch.empty_like(w)
+                db = torch.empty(cout, device=dev, dtype=torch.float32) if ctx.has_bias else None
+                nbytes = L.sisr_corr3x3_c3_workspace_bytes(B, H, W, cout)
+                ws = hip.workspace(dev, nbytes)
+                rc = L.sisr_corr3x3_c3(hip.ptr(x), hip.ptr(dy), hip.view_plain(H, W, cout), 1.0, hip.ptr(dw), 27, 9, 0,
+                                       0, hip.ptr(db), hip.ptr(ws), nbytes, B, H, W, cout, hip.stream())
+                hip.check(rc, "sisr_corr3x3_c3(head)")
+        else:  # cout3
+            dy = dy.contiguous()
+            if need_x:
+                dx = _empty_cl(B, cin, H, W, dev)
+                rc = L.sisr_conv3x3_cin3(hip.ptr(dy), hip.ptr(w), 9, cin * 9, 1, None, hip.ptr(dx),
+                                         hip.view_plain(H, W, cin), B, H, W, cin, hip.stream())
+                hip.check(rc, "sisr_conv3x3_cin3(dgrad)")
+            if need_w or need_b:
+                dw = torch.empty_like(w)
+                db = torch.empty(3, device=dev, dtype=torch.float32) if ctx.has_bias else None
+                nbytes = L.sisr_corr3x3_c3_workspace_bytes(B, H, W, cin)
+                ws = hip.workspace(dev, nbytes)
+                rc = L.sisr_corr3x3_c3(hip.ptr(dy), hip.ptr(x), hip.view_plain(H, W, cin), 1.0, hip.ptr(dw), cin * 9, 9,
+                                       1, 1, hip.ptr(db), hip.ptr(ws), nbytes, B, H, W, cin, hip.stream())
+                hip.check(rc, "sisr_corr3x3_c3(tail)")
+        return dx, dw, db, dres, None, None
+
+
+def conv3x3(x, weight, bias=None, residual=None, alpha=1.0, shuffle=1):
+    """y = conv3x3(x)*alpha + residual, optionally stored through PixelShuffle(shuffle)."""
+    return _Conv3x3.apply(x, weight, bias, residual, float(alpha), int(shuffle))
+
+
+# ----------------------------------------------------------------------------- meta gate (ParaCALayer FC stack)
+class _MetaGate(Function):
+    @staticmethod
+    def forward(ctx, md, v1, c1, v2, c2, relu):
+        B, M = md.shape[0], md.shape[1]
+        md2 = md.reshape(B, M).contiguous()
+        Hd, C = v1.shape[0], v2.shape[0]
+        v1c, v2c = v1.reshape(Hd, M).contiguous(), v2.reshape(C, Hd).contiguous()
+        hid, m = _vec(B, Hd, md.device), _vec(B, C, md.device)
+        rc = hip.lib().sisr_meta_gate_fwd(hip.ptr(md2), B, M, Hd, C, hip.ptr(v1c), hip.ptr(c1.contiguous()),
+                                          hip.ptr(v2c), hip.ptr(c2.contiguous()), int(relu), hip.ptr(hid), hip.ptr(m),
+                                          hip.stream())
+        hip.check(rc, "sisr_meta_gate_fwd")
+        ctx.save_for_backward(md2, v1c, v2c, hid, m)
+        ctx.relu, ctx.shapes = relu, (md.shape, v1.shape, v2.shape)
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        md2, v1c, v2c, hid, m = ctx.saved_tensors
+        B, M = md2.shape
+        Hd, C = v1c.shape[0], v2c.shape[0]
+        dev = md2.device
+        dv1, dc1 = torch.empty_like(v1c), torch.empty(Hd, device=dev)
+        dv2, dc2 = torch.empty_like(v2c), torch.empty(C, device=dev)
+        dmd = torch.empty_like(md2) if ctx.needs_input_grad[0] else None
+        rc = hip.lib().sisr_meta_gate_bwd(hip.ptr(dm.contiguous()), hip.ptr(m), hip.ptr(hid), hip.ptr(md2), B, M, Hd, C,
+                                          hip.ptr(v1c), hip.ptr(v2c), int(ctx.relu), hip.ptr(dv1), hip.ptr(dc1),
+                                          hip.ptr(dv2), hip.ptr(dc2), hip.ptr(dmd), hip.stream())
+        hip.check(rc, "sisr_meta_gate_bwd")
+        s_md, s_v1, s_v2 = ctx.shapes
+        return (dmd.reshape(s_md) if dmd is not None else None, dv1.reshape(s_v1), dc1, dv2.reshape(s_v2), dc2, None)
+
+
+def meta_gate(md, v1, c1, v2, c2, relu):
+    """(B,M,1,1) metadata -> (B,C) sigmoid gate."""
+    return _MetaGate.apply(md, v1, c1, v2, c2, bool(relu))
+
+
+# ----------------------------------------------------------------------------- fused residual block
+class _ResBlock(Function):
+    """y = x + gate * res_scale * conv2(relu(conv1(x)));  gate = CA(GAP(.)) [* m] | m | 1."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, caw1, cab1, caw2, cab2, m, res_scale):
+        B, C, H, W = x.shape
+        if C != 64 or tuple(w1.shape) != (64, 64, 3, 3) or tuple(w2.shape) != (64, 64, 3, 3):
+            raise NotImplementedError("fused residual block is specialised for n_feats = 64")
+        dev = x.device
+        x = _cl(x)
+        w1, w2 = w1.contiguous(), w2.contiguous()
+        v = hip.view_plain(H, W, 64)
+        has_ca, has_m = caw1 is not None, m is not None
+        t1 = _empty_cl(B, 64, H, W, dev)
+        conv_c64(x, v, pack_weight(w1, "fwd"), b1, (1, 64), t1, v, B, H, W, 64, 64, relu=True)
+        y = _empty_cl(B, 64, H, W, dev)
+        p2 = pack_weight(w2, "fwd")
+        saved_vecs = []
+        if not has_ca and not has_m:  # ResBlock: everything fuses into conv2's epilogue
+            conv_c64(t1, v, p2, b2, (1, 64), y, v, B, H, W, 64, 64, res=x, alpha=res_scale)
+            t2 = None
+        else:
+            t2 = _empty_cl(B, 64, H, W, dev)
+            if has_ca:
+                parts = gap_parts(H, W)
+                gap = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
+                conv_c64(t1, v, p2, b2, (1, 64), t2, v, B, H, W, 64, 64, alpha=res_scale, gap=gap)
+                R = caw1.shape[0]
+                caw1c, caw2c = caw1.reshape(R, 64).contiguous(), caw2.reshape(64, R).contiguous()
+                s, hid, ca, g = _vec(B, 64, dev), _vec(B, R, dev), _vec(B, 64, dev), _vec(B, 64, dev)
+                mm = m.contiguous() if has_m else None
+                rc = hip.lib().sisr_ca_gate_fwd(hip.ptr(gap), parts, B, 1.0 / (H * W), hip.ptr(caw1c),
+                                                hip.ptr(cab1.contiguous()), hip.ptr(caw2c), hip.ptr(cab2.contiguous()),
+                                                64, R, hip.ptr(mm), hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(g),
+                                                hip.stream())
+                hip.check(rc, "sisr_ca_gate_fwd")
+                saved_vecs = [caw1c, caw2c, s, hid, ca, g] + ([mm] if has_m else [])
+            else:
+                conv_c64(t1, v, p2, b2, (1, 64), t2, v, B, H, W, 64, 64, alpha=res_scale)
+                g = m.contiguous()
+                saved_vecs = [g]
+            rc = hip.lib().sisr_gate_residual_fwd(hip.ptr(t2), hip.ptr(g), None, hip.ptr(x), hip.ptr(y), B, H * W, 64,
+                                                  hip.stream())
+            hip.check(rc, "sisr_gate_residual_fwd")
+        ctx.save_for_backward(x, w1, w2, t1, *([t2] if t2 is not None else []), *saved_vecs)
+        ctx.cfg = (has_ca, has_m, float(res_scale), (B, H, W), tuple(caw1.shape) if has_ca else None,
+                   tuple(caw2.shape) if has_ca else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        has_ca, has_m, rs, (B, H, W), s_caw1, s_caw2 = ctx.cfg
+        sv = list(ctx.saved_tensors)
+        x, w1, w2, t1 = sv[:4]
+        dev = x.device
+        L = hip.lib()
+        dy = _cl(dy)
+        v = hip.view_plain(H, W, 64)
+        hw = H * W
+        dcaw1 = dcab1 = dcaw2 = dcab2 = dm = None
+        scale = shift = None
+        if has_ca or has_m:
+            t2 = sv[4]
+            parts = L.sisr_gate_dg_parts(hw)
+            dgp = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
+            hip.check(L.sisr_gate_dg_partial(hip.ptr(dy), hip.ptr(t2), hip.ptr(dgp), B, hw, 64, hip.stream()),
+                      "sisr_gate_dg_partial")
+            if has_ca:
+                caw1c, caw2c, s, hid, ca, g = sv[5:11]
+                mm = sv[11] if has_m else None
+                R = caw1c.shape[0]
+                shift = _vec(B, 64, dev)
+                dmv = _vec(B, 64, dev) if has_m else None
+                dcaw1, dcab1 = torch.empty_like(caw1c), torch.empty(R, device=dev)
+                dcaw2, dcab2 = torch.empty_like(caw2c), torch.empty(64, device=dev)
+                rc = L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
+                                        hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
+                                        hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
+                                        hip.stream())
+                hip.check(rc, "sisr_ca_gate_bwd")
+                dcaw1, dcaw2 = dcaw1.reshape(s_caw1), dcaw2.reshape(s_caw2)
+                dm, scale = dmv, g
+            else:
+                g = sv[5]
+                dm = _vec(B, 64, dev)
+                hip.check(L.sisr_sum_partials(hip.ptr(dgp), parts, B, 64, 1.0, hip.ptr(dm), hip.stream()),
+                          "sisr_sum_partials")
+                scale = g
+        # conv2 backward: dt2 = dy*scale + shift is rebuilt on load, never stored
+        dt1 = _empty_cl(B, 64, H, W, dev)
+        conv_c64(dy, v, pack_weight(w2, "dgrad"), None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1, in_scale=scale,
+                 in_shift=shift, alpha=rs)
+        dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
+        wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, alpha=rs, dy_scale=scale, dy_shift=shift)
+        # conv1 backward (+ skip connection gradient)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty_cl(B, 64, H, W, dev)
+            conv_c64(dt1, v, pack_weight(w1, "dgrad"), None, (1, 64), dx, v, B, H, W, 64, 64, res=dy)
+        dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
+        wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64)
+        return dx, dw1, db1, dw2, db2, dcaw1, dcab1, dcaw2, dcab2, (dm if has_m else None), None
+
+
+def res_block(x, w1, b1, w2, b2, ca=None, m=None, res_scale=1.0):
+    """ca = (w1,b1,w2,b2) of the CA squeeze/excite 1x1 convs or None; m = (B,64) meta gate or None."""
+    caw1, cab1, caw2, cab2 = ca if ca is not None else (None, None, None, None)
+    return _ResBlock.apply(x, w1, b1, w2, b2, caw1, cab1, caw2, cab2, m, float(res_scale))
+
+
+class _ConvReluConv(Function):
+    """t2 = conv2(relu(conv1(x))) without gate/skip (used by the metadata-mixing QCALayer styles)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        B, C, H, W = x.shape
+        if C != 64:
+            raise NotImplementedError("fused conv pair is specialised for n_feats = 64")
+        x = _cl(x)
+        w1, w2 = w1.contiguous(), w2.contiguous()
+        v = hip.view_plain(H, W, 64)
+        t1, t2 = _empty_cl(B, 64, H, W, x.device), _empty_cl(B, 64, H, W, x.device)
+        conv_c64(x, v, pack_weight(w1, "fwd"), b1, (1, 64), t1, v, B, H, W, 64, 64, relu=True)
+        conv_c64(t1, v, pack_weight(w2, "fwd"), b2, (1, 64), t2, v, B, H, W, 64, 64)
+        ctx.save_for_backward(x, w1, w2, t1)
+        return t2
+
+    @staticmethod
+    def backward(ctx, dt2):
+        x, w1, w2, t1 = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dev = x.device
+        dt2 = _cl(dt2)
+        v = hip.view_plain(H, W, 64)
+        dt1 = _empty_cl(B, 64, H, W, dev)
+        conv_c64(dt2, v, pack_weight(w2, "dgrad"), None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1)
+        dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
+        wgrad_c64(t1, v, dt2, v, dw2, db2, B, H, W, 64, 64)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty_cl(B, 64, H, W, dev)
+            conv_c64(dt1, v, pack_weight(w1, "dgrad"), None, (1, 64), dx, v, B, H, W, 64, 64)
+        dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
+        wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64)
+        return dx, dw1, db1, dw2, db2
+
+
+def res_block_convs(x, w1, b1, w2, b2):
+    return _ConvReluConv.apply(x, w1, b1, w2, b2)
+
+
+# ----------------------------------------------------------------------------- stand-alone gates
+def _pixel_sums(t, other, B, H, W):
+    """[B][parts][64] ordered partial sums of t*other (other None: of t)."""
+    L = hip.lib()
+    parts = L.sisr_gate_dg_parts(H * W)
+    part = torch.empty((B, parts, 64), device=t.device, dtype=torch.float32)
+    hip.check(L.sisr_gate_dg_partial(hip.ptr(t), hip.ptr(other), hip.ptr(part), B, H * W, 64, hip.stream()),
+              "sisr_gate_dg_partial")
+    return part, parts
+
+
+def _affine(t, g, shift, x, B, H, W, C):
+    y = _empty_cl(B, C, H, W, t.device)
+    hip.check(hip.lib().sisr_gate_residual_fwd(hip.ptr(t), hip.ptr(g), hip.ptr(shift), hip.ptr(x), hip.ptr(y), B,
+                                               H * W, C, hip.stream()), "sisr_gate_residual_fwd")
+    return y
+
+
+class _CALayer(Function):
+    """y = x * sigmoid(W2 relu(W1 mean_hw(x) + b1) + b2)   (ref: advanced/architectures.py:29-32)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        B, C, H, W = x.shape
+        if C != 64:
+            raise NotImplementedError("channel attention kernels are specialised for 64 channels")
+        x = _cl(x)
+        dev = x.device
+        R = w1.shape[0]
+        w1c, w2c = w1.reshape(R, 64).contiguous(), w2.reshape(64, R).contiguous()
+        part, parts = _pixel_sums(x, None, B, H, W)
+        s, hid, ca, g = _vec(B, 64, dev), _vec(B, R, dev), _vec(B, 64, dev), _vec(B, 64, dev)
+        hip.check(hip.lib().sisr_ca_gate_fwd(hip.ptr(part), parts, B, 1.0 / (H * W), hip.ptr(w1c),
+                                             hip.ptr(b1.contiguous()), hip.ptr(w2c), hip.ptr(b2.contiguous()), 64, R,
+                                             None, hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(g), hip.stream()),
+                  "sisr_ca_gate_fwd")
+        ctx.save_for_backward(x, w1c, w2c, s, hid, ca)
+        ctx.shapes = (w1.shape, w2.shape)
+        return _affine(x, g, None, None, B, H, W, 64)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1c, w2c, s, hid, ca = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dev = x.device
+        R = w1c.shape[0]
+        dy = _cl(dy)
+        dgp, parts = _pixel_sums(dy, x, B, H, W)
+        shift = _vec(B, 64, dev)
+        dw1, db1 = torch.empty_like(w1c), torch.empty(R, device=dev)
+        dw2, db2 = torch.empty_like(w2c), torch.empty(64, device=dev)
+        hip.check(hip.lib().sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / (H * W), hip.ptr(w1c), hip.ptr(w2c), 64, R,
+                                             hip.ptr(s), hip.ptr(hid), hip.ptr(ca), None, hip.ptr(shift), None,
+                                             hip.ptr(dw1), hip.ptr(db1), hip.ptr(dw2), hip.ptr(db2), hip.stream()),
+                  "sisr_ca_gate_bwd")
+        dx = _affine(dy, ca, shift, None, B, H, W, 64)
+        return dx, dw1.reshape(ctx.shapes[0]), db1, dw2.reshape(ctx.shapes[1]), db2
+
+
+def ca_layer(x, w1, b1, w2, b2):
+    return _CALayer.apply(x, w1, b1, w2, b2)
+
+
+class _GateMul(Function):
+    """y = t * g[b,c] (+ x)."""
+
+    @staticmethod
+    def forward(ctx, t, g, x):
+        B, C, H, W = t.shape
+        t = _cl(t)
+        g2 = g.reshape(B, C).contiguous()
+        y = _affine(t, g2, None, _cl(x) if x is not None else None, B, H, W, C)
+        ctx.save_for_backward(t, g2)
+        ctx.gshape, ctx.has_x = g.shape, x is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        t, g2 = ctx.saved_tensors
+        B, C, H, W = t.shape
+        if C != 64:
+            raise NotImplementedError("gate backward is specialised for 64 channels")
+        dy = _cl(dy)
+        dt = _affine(dy, g2, None, None, B, H, W, C)
+        dgp, parts = _pixel_sums(dy, t, B, H, W)
+        dg = _vec(B, C, t.device)
+        hip.check(hip.lib().sisr_sum_partials(hip.ptr(dgp), parts, B, C, 1.0, hip.ptr(dg), hip.stream()),
+                  "sisr_sum_partials")
+        return dt, dg.reshape(ctx.gshape), (dy if ctx.has_x else None)
+
+
+def gate_mul(t, g, x=None):
+    return _GateMul.apply(t, g, x)
+
+
+class _GlobalAvgPool(Function):
+    """(B,64,H,W) -> (B,64,1,1) mean over pixels (ordered two-stage sum)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        B, C, H, W = t.shape
+        if C != 64:
+            raise NotImplementedError("GAP kernel is specialised for 64 channels")
+        t = _cl(t)
+        part, parts = _pixel_sums(t, None, B, H, W)
+        s = _vec(B, C, t.device)
+        hip.check(hip.lib().sisr_sum_partials(hip.ptr(part), parts, B, C, 1.0 / (H * W), hip.ptr(s), hip.stream()),
+                  "sisr_sum_partials")
+        ctx.geom = (B, C, H, W)
+        return s.reshape(B, C, 1, 1)
+
+    @staticmethod
+    def backward(ctx, ds):
+        B, C, H, W = ctx.geom
+        dt = (ds.reshape(B, C, 1, 1) / (H * W)).expand(B, C, H, W).contiguous(memory_format=CL)
+        return dt
+
+
+def global_avg_pool(t):
+    return _GlobalAvgPool.apply(t)
+
+
+# ----------------------------------------------------------------------------- L1 loss
+class _L1Loss(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        if a.shape != b.shape:
+            raise RuntimeError(f"l1_loss shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+        L = hip.lib()
+        loss = torch.empty((), device=a.device, dtype=torch.float32)
+        grad = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        ws = hip.workspace(a.device, L.sisr_l1_loss_workspace_bytes())
+        hip.check(L.sisr_l1_loss(hip.ptr(a), hip.ptr(b), a.numel(), hip.ptr(loss), hip.ptr(grad), hip.ptr(ws),
+                                 hip.stream()), "sisr_l1_loss")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        (grad,) = ctx.saved_tensors
+        return grad * go, None
+
+
+def l1_loss(a, b):
+    return _L1Loss.apply(a, b)

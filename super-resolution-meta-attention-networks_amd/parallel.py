@@ -1,0 +1,151 @@
+"""Data parallelism: one process per GPU, RCCL gradient all-reduce over xGMI.
+
+Replaces the reference's single-process ``nn.DataParallel`` (ref: Code/SISR/models/__init__.py:344-347,
+triggered by gpu='multi' at :121-122).  Tiles of a minibatch are independent (no BatchNorm on the path;
+GAP/LAM/CSAM reduce within a sample), so the only exchange is one gradient average per step:
+
+  * every rank holds a full replica and runs forward/backward on its shard of the global batch;
+  * parameters are grouped into ~8 MB buckets in REVERSE registration order (≈ the order backward
+    produces their gradients); as soon as the last gradient of a bucket is accumulated a
+    post-accumulate-grad hook flattens the bucket and issues ``all_reduce`` on a side HIP stream, so the
+    collective overlaps the rest of backward (62 MB fp32 for RCAN ≈ 0.1-0.7 ms on 7 xGMI links versus
+    tens of ms of backward);
+  * ``reduce()`` (called by ``standard_update`` between backward and the optimiser step) joins the side
+    stream and writes grad / world_size back.  L1 'mean' over equal shards makes mean-of-means exact.
+
+Works unchanged on CPU tensors with the gloo backend (used by the world_size-2 tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from torchrun's environment; returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_batch(batch, rank, world):
+    """Contiguous rank slice of a collated batch dict (ref schema: sr_tools/data_handler.py:516-525).
+    'metadata_keys' is default_collate's list[M] of B-tuples, so it is sliced per entry."""
+    def sl(n):
+        if n % world:
+            raise ValueError(f"global batch {n} is not divisible by world size {world}")
+        per = n // world
+        return slice(rank * per, (rank + 1) * per)
+
+    out = {}
+    n = None
+    for k, v in batch.items():
+        if torch.is_tensor(v) and v.dim() > 0:
+            n = v.shape[0]
+            break
+    for k, v in batch.items():
+        if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n:
+            out[k] = v[sl(n)]
+        elif k == "metadata_keys" and isinstance(v, (list, tuple)):
+            out[k] = [tuple(e[sl(n)]) if isinstance(e, (list, tuple)) and len(e) == n else e for e in v]
+        elif isinstance(v, (list, tuple)) and len(v) == n:
+            out[k] = list(v[sl(n)])
+        else:
+            out[k] = v
+    return out
+
+
+class GradReducer:
+    def __init__(self, net, bucket_mb=8.0, process_group=None, overlap=True):
+        if not dist.is_initialized():
+            raise RuntimeError("gpu='multi' runs one process per GPU: launch with "
+                               "`python -m torch.distributed.run --nproc-per-node N ...` "
+                               "(see parallel.init_distributed)")
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        self.cuda = self.params[0].is_cuda
+        cap = int(bucket_mb * (1 << 20) / 4)
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel()
+            if size >= cap:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        dev = self.params[0].device
+        self.flat = [torch.zeros(sum(p.numel() for p in b), device=dev) for b in self.buckets]
+        self.bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                self.bucket_of[p] = bi
+        self.pending = [len(b) for b in self.buckets]
+        self.works = [None] * len(self.buckets)
+        self.launched = [False] * len(self.buckets)
+        self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
+        self.overlap = overlap
+        self.handles = []
+        if overlap:
+            for p in self.params:
+                self.handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        # replicas must start identical (the reference's DataParallel re-broadcasts every step)
+        for p in net.parameters():
+            dist.broadcast(p.data, src=0, group=process_group)
+        for b in net.buffers():
+            dist.broadcast(b.data, src=0, group=process_group)
+
+    def _on_grad(self, p):
+        bi = self.bucket_of[p]
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        bucket, flat = self.buckets[bi], self.flat[bi]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                torch._foreach_copy_(list(flat.split([p.numel() for p in bucket])), [g.reshape(-1) for g in grads])
+                self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            torch._foreach_copy_(list(flat.split([p.numel() for p in bucket])), [g.reshape(-1) for g in grads])
+            self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.launched[bi] = True
+
+    def reduce(self):
+        """Join: every bucket reduced (launching those whose hooks did not fire), grads <- sum / world."""
+        for bi in range(len(self.buckets)):
+            if not self.launched[bi]:
+                self._launch(bi)
+        inv = 1.0 / self.world
+        for bi, bucket in enumerate(self.buckets):
+            self.works[bi].wait()
+            if self.cuda:
+                torch.cuda.current_stream().wait_stream(self.stream)
+            pieces = self.flat[bi].split([p.numel() for p in bucket])
+            for p, piece in zip(bucket, pieces):
+                g = piece.view_as(p) * inv
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.copy_(g)
+            self.pending[bi] = len(bucket)
+            self.launched[bi] = False
+            self.works[bi] = None
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
