@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LR-patches/s (128x128x3 -> x4) for one training step on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step is BaseModel.train_step on the full-depth network: forward + L1 + backward + Adam + scheduler step
+(the reference's run_train, Code/SISR/models/__init__.py:466-489, minus its per-step D2H copies), on
+synthetic inputs already resident in HBM.  Per-GPU batch is fixed, so scaling is weak;
+value = all patches of all ranks / max-over-ranks wall time of exactly K steps.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel (conv3x3_c64_kernel, 64->64 body shape): algorithmic FLOPs per launch
+                divided by its mean launch duration, measured with HIP events around every launch of that
+                shape during the last timed step, against the 157.3 TFLOP/s fp32 matrix/vector peak.
+  cpu_baseline  rank 0, N=1 only: the CPU oracle (a restatement of the reference proven equal to it by the
+                golden vectors) doing the same step at batch 1 on the host cores -- a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONV_BODY_FLOP_PER_PIXEL = 2 * 64 * 64 * 9
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
+WORKLOADS = {
+    # name: (registry name, handler kwargs, fwd+bwd algorithmic TFLOP per LR patch)
+    "rcan": ("rcan", {}, 1.565),
+    "qrcan": ("qrcan", {"metadata": ["blur_kernel"], "style": "standard", "include_q_layer": True}, 1.565),
+    "edsr": ("edsr", {}, 0.195),
+    "qedsr": ("qedsr", {"metadata": ["blur_kernel"]}, 0.195),
+    "han": ("han", {}, 1.614),
+    "qhan": ("qhan", {"metadata": ["blur_kernel"]}, 1.614),
+}
+
+
+class ConvTimer:
+    """HIP-event timing of every 64->64 body conv launch (recorded on the launch stream)."""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.events, self.on = ops, ops.conv_c64, [], False
+
+    def install(self):
+        def timed(x, xview, packed, bias, bnq, y, yview, B, H, W, cin, cout, **kw):
+            if self.on and cin == 64 and cout == 64:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.orig(x, xview, packed, bias, bnq, y, yview, B, H, W, cin, cout, **kw)
+                e1.record()
+                self.events.append((e0, e1, B * H * W))
+            else:
+                self.orig(x, xview, packed, bias, bnq, y, yview, B, H, W, cin, cout, **kw)
+        self.ops.conv_c64 = timed
+
+    def summary(self):
+        if not self.events:
+            return None
+        ms = [a.elapsed_time(b) for a, b, _ in self.events]
+        flop = [p * CONV_BODY_FLOP_PER_PIXEL for _, _, p in self.events]
+        return {"launches": len(ms), "avg_us": 1e3 * sum(ms) / len(ms), "tflops": sum(flop) / (sum(ms) * 1e-3) / 1e12,
+                "flop_per_launch": sum(flop) / len(flop)}
+
+
+def cpu_baseline(workload, seconds_budget=30.0):
+    """Oracle (CPU restatement of the reference) timed on the host cores: same step, batch 1."""
+    import importlib
+    from oracle import sisr_oracle as O
+    sisr = importlib.import_module("sisr_amd")
+    name, params, _ = WORKLOADS[workload]
+    torch.manual_seed(8)
+    h = sisr.available_models[name](device=torch.device("cpu"), model_save_dir="/tmp", eval_mode=False, scale=4, **params)
+    cfg = {"rcan": dict(n_resgroups=10, n_resblocks=20, scale=4), "edsr": dict(num_blocks=16, scale=4, res_scale=0.1),
+           "qrcan": dict(n_resgroups=10, n_resblocks=20, scale=4, style="standard", include_q_layer=True),
+           "qedsr": dict(num_blocks=16, scale=4, res_scale=0.1, q_layer_nonlinearity=False),
+           "han": dict(n_resgroups=10, n_resblocks=20, scale=4), "qhan": dict(n_resgroups=10, n_resblocks=20, scale=4)}[name]
+    tr = O.Trainer(name, h.net.state_dict(), lr=1e-4, **cfg)
+    g = torch.Generator().manual_seed(8)
+    x, y = torch.rand(1, 3, 128, 128, generator=g), torch.rand(1, 3, 512, 512, generator=g)
+    md = (torch.rand(1, 10, 1, 1, generator=g) * 0.4) if name in O.META_NETS else None
+    tr.step(x, y, md)  # warm-up
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 and (time.perf_counter() - t_all) < seconds_budget:
+        t0 = time.perf_counter()
+        tr.step(x, y, md)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{name} x4 full depth, batch 1, 128x128 LR tile, fwd+L1+bwd+Adam, median of {len(times)} "
+                      f"timed steps after 1 warm-up (oracle/sisr_oracle.py on torch CPU kernels)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="LR patches per GPU per step")
+    ap.add_argument("--workload", default="rcan", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import importlib
+    sisr = importlib.import_module("sisr_amd")
+    rank, world, local = sisr.parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    name, params, tflop_per_patch = WORKLOADS[args.workload]
+    if name not in sisr.available_models:
+        raise SystemExit(f"workload {name} is not built yet")
+
+    torch.manual_seed(8)
+    h = sisr.available_models[name](device=local, model_save_dir="/tmp", eval_mode=False, scale=4, lr=1e-4,
+                                    scheduler="cosine_annealing_warm_restarts",
+                                    scheduler_params={"t_mult": 1, "restart_period": 125000, "lr_min": 1e-7}, **params)
+    if world > 1:
+        h.set_multi_gpu()
+    B = args.batch
+    g = torch.Generator().manual_seed(8 + rank)
+    x = torch.rand(B, 3, 128, 128, generator=g).to(dev)
+    y = torch.rand(B, 3, 512, 512, generator=g).to(dev)
+    kw = {}
+    if "metadata" in params:
+        kw["extra_channels"] = (torch.rand(B, 10, 1, 1, generator=g) * 0.4).to(dev)
+
+    timer = ConvTimer(sisr.ops)
+    if not args.no_kernel_timing:
+        timer.install()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        h.train_step(x, y, **kw)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        timer.on = (i == args.steps - 1)
+        loss, _ = h.train_step(x, y, **kw)
+    timer.on = False
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        line = {
+            "metric": "LR-patches/sec (128x128x3, x4) fwd+bwd", "value": value, "unit": "patches/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name.upper()} x4 full depth, 128x128 LR -> 512x512 tiles, train step = "
+                                   f"fwd + L1 + bwd + Adam + scheduler", "per_gpu_batch": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}", "final_loss": loss_val,
+                       "algorithmic_tflops": value * tflop_per_patch},
+        }
+        ks = timer.summary()
+        if ks:
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "traffic_conv3x3_c64.json")
+            if os.path.exists(tj):
+                with open(tj) as f:
+                    traffic = json.load(f).get(str(B))
+            line["roofline"] = {"bound": "mfma", "kernel": "conv3x3_c64_kernel (64->64 fwd/dgrad)",
+                                "achieved": ks["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ks["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                                "avg_launch_us": ks["avg_us"], "launches_timed": ks["launches"],
+                                "flop_per_launch": ks["flop_per_launch"]}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -257,6 +257,7 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   const long nblk = (long)p.tiles_w * p.tiles_h * B;
   if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
   const size_t lds_bytes = (size_t)HALO_H * HALO_W * PSTR * sizeof(float);
+  SISR_ALLOW_LDS(conv3x3_c64_kernel, lds_bytes);
   hipLaunchKernelGGL(conv3x3_c64_kernel, dim3((unsigned)nblk, p.cout_chunks), dim3(256), lds_bytes,
                      (hipStream_t)stream, p);
   return sisr_check_launch();

@@ -41,4 +41,16 @@ static inline int sisr_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SISR_OK : SISR_ERR_LAUNCH - (int)e * 16;
 }
+// Dynamic LDS above 64 KB needs an explicit opt-in on the kernel (gfx950 has 160 KB per CU).  Idempotent,
+// so the unsynchronised once-flag is safe.
+#define SISR_ALLOW_LDS(kernel, bytes)                                                                       \
+  do {                                                                                                      \
+    static bool done_ = false;                                                                              \
+    if (!done_) {                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));                  \
+      done_ = true;                                                                                         \
+    }                                                                                                       \
+  } while (0)
+
 static inline bool sisr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

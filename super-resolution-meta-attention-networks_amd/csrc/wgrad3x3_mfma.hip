@@ -275,6 +275,7 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   p.slabs = workspace;
   p.bias_slabs = dbias ? workspace + (size_t)p.S * units * SLAB : nullptr;
   const size_t lds_bytes = (size_t)(LDS_X + LDS_Y) * sizeof(float);
+  SISR_ALLOW_LDS(wgrad3x3_c64_kernel, lds_bytes);
   hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(p.S, units), dim3(256), lds_bytes, (hipStream_t)stream, p);
   int rc = sisr_check_launch();
   if (rc) return rc;

@@ -151,7 +151,9 @@ class BaseModel(nn.Module):
         return state
 
     # -- train / eval steps (ref :466-533)
-    def run_train(self, x, y, tag=None, mask=None, keep_on_device=False, *args, **kwargs):
+    def train_step(self, x, y, tag=None, **kwargs):
+        """run_train without its host round trips: returns (loss, out) as device tensors and never
+        synchronises, so consecutive steps queue back to back on the stream."""
         if self.eval_mode:
             raise RuntimeError('Model initialized in eval mode, training not possible.')
         self.net.train()
@@ -159,9 +161,13 @@ class BaseModel(nn.Module):
         out = self.run_model(x, image_names=tag, **kwargs)
         loss = self.criterion(out, y)
         self.standard_update(loss)
+        return loss.detach(), out.detach()
+
+    def run_train(self, x, y, tag=None, mask=None, keep_on_device=False, *args, **kwargs):
+        loss, out = self.train_step(x, y, tag=tag, **kwargs)
         if keep_on_device:
-            return loss.detach().cpu().numpy(), out.detach()
-        return loss.detach().cpu().numpy(), out.detach().cpu()
+            return loss.cpu().numpy(), out
+        return loss.cpu().numpy(), out.cpu()
 
     def standard_update(self, loss):
         self.optimizer.zero_grad()
@@ -270,6 +276,13 @@ class QModel(BaseModel):
     def run_train(self, x, y, metadata=None, extra_channels=None, metadata_keys=None, *args, **kwargs):
         input_data, extra_channels = self.channel_concat_logic(x, extra_channels, metadata, metadata_keys)
         return super().run_train(input_data, y, extra_channels=extra_channels, **kwargs)
+
+    def train_step(self, x, y, metadata=None, extra_channels=None, metadata_keys=None, **kwargs):
+        if extra_channels is None and metadata is None:
+            raise RuntimeError('Metadata needs to be specified for this network to run properly.')
+        if extra_channels is None:
+            x, extra_channels = self.channel_concat_logic(x, None, metadata, metadata_keys)
+        return super().train_step(x, y, extra_channels=extra_channels, **kwargs)
 
     def run_eval(self, x, y=None, request_loss=False, metadata=None, metadata_keys=None, extra_channels=None, *args,
                  **kwargs):
