@@ -45,7 +45,11 @@ extern "C" {
  *   gap_partial   : [B][sisr_conv3x3_c64_gap_parts(H,W)][cout] (nullable) */
 int sisr_pack_conv3x3(const float* w, float* packed, int cout, int cin, int64_t so, int64_t si, int flip_taps,
                       int out_perm_n, int out_perm_q, int in_perm_n, int in_perm_q, void* stream);
+/* forward and input-gradient packings of one weight in one launch (shuffle_r > 1: conv feeds PixelShuffle(r)) */
+int sisr_pack_conv3x3_both(const float* w, float* packed_fwd, float* packed_dgrad, int cout, int cin, int shuffle_r,
+                           void* stream);
 int sisr_conv3x3_c64_gap_parts(int H, int W);
+int sisr_conv3x3_c64_set_variant(int v); /* tuning knob: 0 padded LDS, 1 + deeper A prefetch, 2 swizzled LDS, 3 WG/CU */
 int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked, const float* bias, int bias_n,
                      int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,
                      const float* in_scale, const float* in_shift, const float* out_scale, float alpha, int relu,
@@ -80,9 +84,11 @@ int sisr_corr3x3_c3(const float* P, const float* Q, const int64_t* qview, float 
 int sisr_ca_gate_fwd(const float* gap_partial, int parts, int B, float inv_hw, const float* w1, const float* b1,
                      const float* w2, const float* b2, int channels, int hidden, const float* mul, float* s,
                      float* hid, float* ca, float* g, void* stream);
+size_t sisr_ca_gate_bwd_workspace_bytes(int B);
 int sisr_ca_gate_bwd(const float* dg_partial, int parts, int B, float inv_hw, const float* w1, const float* w2,
                      int channels, int hidden, const float* s, const float* hid, const float* ca, const float* mul,
-                     float* shift, float* dmul, float* dw1, float* db1, float* dw2, float* db2, void* stream);
+                     float* shift, float* dmul, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
+                     void* stream);
 
 /* ---- meta-attention gate --------------------------------------------------------------------------
  * ref: attention_manipulators/q_layer.py:4-43 ParaCALayer: m = sigmoid(V2 act(V1 md + c1) + c2) */

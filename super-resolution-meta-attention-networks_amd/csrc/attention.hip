@@ -18,18 +18,37 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 __device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
 
-// ---------------------------------------------------------------- CA gate forward (C = 64, one wave per sample)
-// part: [B][parts][64] partial sums.  Outputs s, ca, g: [B][64]; hid: [B][R].
-__global__ __launch_bounds__(64) void ca_gate_fwd_kernel(const float* __restrict__ part, int parts, float inv_hw,
-                                                         const float* __restrict__ w1, const float* __restrict__ b1,
-                                                         const float* __restrict__ w2, const float* __restrict__ b2,
-                                                         int R, const float* __restrict__ mul, float* __restrict__ s_out,
-                                                         float* __restrict__ hid_out, float* __restrict__ ca_out,
-                                                         float* __restrict__ g_out) {
-  const int b = blockIdx.x, c = threadIdx.x;
-  const float* pp = part + (long)b * parts * 64 + c;
+// Sum `parts` rows of 64 floats with the whole 256-thread block: wave w takes rows w, w+4, ... (8 loads
+// in flight), then the four per-wave sums are added in wave order.  Result valid in wave 0 (all lanes).
+__device__ __forceinline__ float block_sum_parts(const float* __restrict__ pp, int parts, float* red) {
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
   float s = 0.f;
-  for (int k = 0; k < parts; ++k) s += pp[(long)k * 64];
+  int k = w;
+  for (; k + 28 < parts; k += 32) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = pp[(long)(k + 4 * u) * 64 + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; k < parts; k += 4) s += pp[(long)k * 64 + c];
+  red[w * 64 + c] = s;
+  __syncthreads();
+  return ((red[c] + red[64 + c]) + red[128 + c]) + red[192 + c];
+}
+
+// ---------------------------------------------------------------- CA gate forward (C = 64, one block per sample)
+// part: [B][parts][64] partial sums.  Outputs s, ca, g: [B][64]; hid: [B][R].
+__global__ __launch_bounds__(256) void ca_gate_fwd_kernel(const float* __restrict__ part, int parts, float inv_hw,
+                                                          const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          int R, const float* __restrict__ mul, float* __restrict__ s_out,
+                                                          float* __restrict__ hid_out, float* __restrict__ ca_out,
+                                                          float* __restrict__ g_out) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, c = threadIdx.x & 63;
+  float s = block_sum_parts(part + (long)b * parts * 64, parts, red);
+  if (threadIdx.x >= 64) return;
   s *= inv_hw;
   s_out[b * 64 + c] = s;
   float z = b2[c];
@@ -45,57 +64,65 @@ __global__ __launch_bounds__(64) void ca_gate_fwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------- CA gate backward
-// dgpart: [B][parts][64] partial sums of dg = sum_hw dOut*t.  One wave; loops over the batch so the
-// weight gradients are summed in batch order.  Outputs: shift[b][c] = dL/ds * inv_hw (the GAP backward
-// broadcast, consumed as the dgrad/wgrad prologue shift), dmul = dg*ca, and dW1,db1,dW2,db2.
-__global__ __launch_bounds__(64) void ca_gate_bwd_kernel(const float* __restrict__ dgpart, int parts, int B,
-                                                         float inv_hw, const float* __restrict__ w1,
-                                                         const float* __restrict__ w2, int R,
-                                                         const float* __restrict__ s_in, const float* __restrict__ hid,
-                                                         const float* __restrict__ ca_in, const float* __restrict__ mul,
-                                                         float* __restrict__ shift, float* __restrict__ dmul,
-                                                         float* __restrict__ dw1, float* __restrict__ db1,
-                                                         float* __restrict__ dw2, float* __restrict__ db2) {
-  const int c = threadIdx.x;
-  float adb2 = 0.f;
-  float adw2[16], adw1[16], adb1[16];  // R <= 16 (reduction 16 on 64..256 channels; launcher checks)
-#pragma unroll
-  for (int j = 0; j < 16; ++j) adw2[j] = adw1[j] = adb1[j] = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float* pp = dgpart + (long)b * parts * 64 + c;
-    float dg = 0.f;
-    for (int k = 0; k < parts; ++k) dg += pp[(long)k * 64];
-    const float ca = ca_in[b * 64 + c];
-    float dca = dg;
-    if (mul) {
-      dmul[b * 64 + c] = dg * ca;
-      dca = dg * mul[b * 64 + c];
-    }
-    const float dz2 = dca * ca * (1.f - ca);
-    adb2 += dz2;
-    const float s = s_in[b * 64 + c];
-    float ds = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (j < R) {
-        const float h = hid[b * R + j];
-        adw2[j] += dz2 * h;
-        float dh = wave_sum(w2[c * R + j] * dz2);
-        const float dz1 = h > 0.f ? dh : 0.f;
-        adb1[j] += dz1;
-        adw1[j] += dz1 * s;
-        ds += w1[j * 64 + c] * dz1;
-      }
-    }
-    shift[b * 64 + c] = ds * inv_hw;
+// Stage 1 (one block per sample): dg = sum of the partials of sum_hw dOut*t, then the per-sample chain
+//   dca = dg*mul; dz2 = dca*ca*(1-ca); dh = W2^T dz2; dz1 = dh*[hid>0]; ds = W1^T dz1
+// -> shift[b][c] = ds*inv_hw (the GAP backward broadcast, consumed as the dgrad/wgrad prologue shift),
+//    dmul = dg*ca, and the per-sample dz2 [B][64], dz1 [B][R] for stage 2.
+// Stage 2 (one block): parameter gradients summed over the batch in batch order.
+__global__ __launch_bounds__(256) void ca_gate_bwd_sample_kernel(const float* __restrict__ dgpart, int parts,
+                                                                 float inv_hw, const float* __restrict__ w1,
+                                                                 const float* __restrict__ w2, int R,
+                                                                 const float* __restrict__ hid,
+                                                                 const float* __restrict__ ca_in,
+                                                                 const float* __restrict__ mul, float* __restrict__ shift,
+                                                                 float* __restrict__ dmul, float* __restrict__ dz2_out,
+                                                                 float* __restrict__ dz1_out) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, c = threadIdx.x & 63;
+  const float dg = block_sum_parts(dgpart + (long)b * parts * 64, parts, red);
+  if (threadIdx.x >= 64) return;
+  const float ca = ca_in[b * 64 + c];
+  float dca = dg;
+  if (mul) {
+    dmul[b * 64 + c] = dg * ca;
+    dca = dg * mul[b * 64 + c];
   }
-  db2[c] = adb2;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    if (j < R) {
-      dw2[c * R + j] = adw2[j];
-      dw1[j * 64 + c] = adw1[j];
-      if (c == 0) db1[j] = adb1[j];
+  const float dz2 = dca * ca * (1.f - ca);
+  dz2_out[b * 64 + c] = dz2;
+  float ds = 0.f;
+  for (int j = 0; j < R; ++j) {
+    const float dh = wave_sum(w2[c * R + j] * dz2);
+    const float dz1 = hid[b * R + j] > 0.f ? dh : 0.f;
+    if (c == 0) dz1_out[b * R + j] = dz1;
+    ds += w1[j * 64 + c] * dz1;
+  }
+  shift[b * 64 + c] = ds * inv_hw;
+}
+
+__global__ __launch_bounds__(256) void ca_gate_bwd_param_kernel(const float* __restrict__ dz2, const float* __restrict__ dz1,
+                                                                const float* __restrict__ s_in,
+                                                                const float* __restrict__ hid, int B, int R,
+                                                                float* __restrict__ dw1, float* __restrict__ db1,
+                                                                float* __restrict__ dw2, float* __restrict__ db2) {
+  const int n = 64 * R;
+  for (int i = threadIdx.x; i < 2 * n + 64 + R; i += 256) {
+    float acc = 0.f;
+    if (i < n) {  // dw2[c][j] = sum_b dz2[b][c] * hid[b][j]
+      const int c = i / R, j = i - c * R;
+      for (int b = 0; b < B; ++b) acc += dz2[b * 64 + c] * hid[b * R + j];
+      dw2[i] = acc;
+    } else if (i < 2 * n) {  // dw1[j][c] = sum_b dz1[b][j] * s[b][c]
+      const int k = i - n, j = k >> 6, c = k & 63;
+      for (int b = 0; b < B; ++b) acc += dz1[b * R + j] * s_in[b * 64 + c];
+      dw1[k] = acc;
+    } else if (i < 2 * n + 64) {
+      const int c = i - 2 * n;
+      for (int b = 0; b < B; ++b) acc += dz2[b * 64 + c];
+      db2[c] = acc;
+    } else {
+      const int j = i - 2 * n - 64;
+      for (int b = 0; b < B; ++b) acc += dz1[b * R + j];
+      db1[j] = acc;
     }
   }
 }
@@ -240,21 +267,30 @@ extern "C" int sisr_ca_gate_fwd(const float* gap_partial, int parts, int B, floa
                                 const float* mul, float* s, float* hid, float* ca, float* g, void* stream) {
   if (!gap_partial || !w1 || !b1 || !w2 || !b2 || !s || !hid || !ca || !g || B <= 0 || parts <= 0) return SISR_ERR_ARG;
   if (channels != 64 || hidden < 1 || hidden > 16) return SISR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(ca_gate_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, gap_partial, parts, inv_hw, w1, b1,
+  hipLaunchKernelGGL(ca_gate_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, gap_partial, parts, inv_hw, w1, b1,
                      w2, b2, hidden, mul, s, hid, ca, g);
   return sisr_check_launch();
 }
 
+extern "C" size_t sisr_ca_gate_bwd_workspace_bytes(int B) { return B > 0 ? (size_t)B * 80 * sizeof(float) : 0; }
+
 extern "C" int sisr_ca_gate_bwd(const float* dg_partial, int parts, int B, float inv_hw, const float* w1,
                                 const float* w2, int channels, int hidden, const float* s, const float* hid,
                                 const float* ca, const float* mul, float* shift, float* dmul, float* dw1, float* db1,
-                                float* dw2, float* db2, void* stream) {
-  if (!dg_partial || !w1 || !w2 || !s || !hid || !ca || !shift || !dw1 || !db1 || !dw2 || !db2 || B <= 0 || parts <= 0)
+                                float* dw2, float* db2, float* workspace, void* stream) {
+  if (!dg_partial || !w1 || !w2 || !s || !hid || !ca || !shift || !dw1 || !db1 || !dw2 || !db2 || !workspace || B <= 0 ||
+      parts <= 0)
     return SISR_ERR_ARG;
   if (mul && !dmul) return SISR_ERR_ARG;
   if (channels != 64 || hidden < 1 || hidden > 16) return SISR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(ca_gate_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dg_partial, parts, B, inv_hw, w1, w2,
-                     hidden, s, hid, ca, mul, shift, dmul, dw1, db1, dw2, db2);
+  float* dz2 = workspace;
+  float* dz1 = workspace + (size_t)B * 64;
+  hipLaunchKernelGGL(ca_gate_bwd_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dg_partial, parts, inv_hw, w1,
+                     w2, hidden, hid, ca, mul, shift, dmul, dz2, dz1);
+  int rc = sisr_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(ca_gate_bwd_param_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dz2, dz1, s, hid, B, hidden,
+                     dw1, db1, dw2, db2);
   return sisr_check_launch();
 }
 

@@ -25,7 +25,6 @@
 #define TW 32
 #define HALO_H (TH + 2)
 #define HALO_W (TW + 2)
-#define PSTR 68
 #define HALO_ITEMS (HALO_H * HALO_W * 16)            // float4 items in the halo
 #define STAGE_ITERS ((HALO_ITEMS + 255) / 256)        // 13
 
@@ -47,13 +46,28 @@ struct ConvParams {
   int B, H, W, cin_chunks, cout_chunks, relu, tiles_w, tiles_h;
 };
 
-__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvParams p) {
+// Variants (A/B-able in one process through sisr_conv3x3_c64_set_variant; the default is the fastest measured):
+//   0  padded LDS (68-float pixel stride), A fragments one step ahead, 2 workgroups per CU
+//   1  as 0 with A fragments two steps ahead
+//   2  XOR-swizzled LDS (64-float stride: 16-B chunk k of halo pixel p lives at slot k ^ (p & 15)),
+//      52 KB per workgroup so THREE workgroups fit a CU (register budget 168), A two steps ahead
+template <int V>
+__global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(ConvParams p) {
+  constexpr int PSTR = (V == 2) ? 64 : 68;
+  constexpr int AD = (V == 0) ? 1 : 2;  // A prefetch distance in K-steps
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int q = blockIdx.y;
-  int bid = blockIdx.x;
+  // Workgroups are dealt round-robin over the 8 XCDs (block b -> b % 8, a speed-only assumption): give each
+  // XCD a contiguous run of tiles so vertically adjacent tiles, which share two halo rows, meet in one L2.
+  int bid;
+  {
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const unsigned qn = nb >> 3, rn = nb & 7;
+    bid = (int)((xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx);
+  }
   const int tw = bid % p.tiles_w;
   bid /= p.tiles_w;
   const int th = bid % p.tiles_h;
@@ -71,15 +85,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvParams p) {
     {
       // Branch-free: out-of-image taps load a clamped (valid) address and are zeroed by a select, so
       // all 13 loads of a thread are in flight together.  c4 = tid & 15 is the same for every item.
+      // `tl` launders tid once per chunk: without it hipcc hoists the 13 chunk-invariant halo addresses,
+      // clamps and masks out of the chunk loop and keeps ~60 VGPRs live across the whole MFMA loop.
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
       const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(c);
-      const int c4 = tid & 15;
+      const int c4 = tl & 15;
       f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
       if (p.in_scale) s4 = *reinterpret_cast<const f32x4*>(p.in_scale + ((long)b * p.cin_chunks + c) * 64 + c4 * 4);
       if (p.in_shift) t4 = *reinterpret_cast<const f32x4*>(p.in_shift + ((long)b * p.cin_chunks + c) * 64 + c4 * 4);
       f32x4 v[STAGE_ITERS];
 #pragma unroll
       for (int it = 0; it < STAGE_ITERS; ++it) {
-        const int pix = (it * 256 + tid) >> 4;
+        const int pix = (it * 256 + tl) >> 4;
         const int pr = pix / HALO_W, pc = pix - pr * HALO_W;
         const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
         const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
@@ -89,47 +107,63 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvParams p) {
       }
 #pragma unroll
       for (int it = 0; it < STAGE_ITERS; ++it) {
-        const int idx = it * 256 + tid;
-        if (idx < HALO_ITEMS) *reinterpret_cast<f32x4*>(lds + (idx >> 4) * PSTR + c4 * 4) = v[it];
+        const int idx = it * 256 + tl;
+        const int pix = idx >> 4;
+        const int slot = (V == 2) ? (c4 ^ (pix & 15)) : c4;
+        if (idx < HALO_ITEMS) *reinterpret_cast<f32x4*>(lds + pix * PSTR + slot * 4) = v[it];
       }
     }
     __syncthreads();
 
     // ---- 72 K-steps (9 taps x 8 octets of input channels), 8 MFMAs each
     const float* wq = p.w + ((long)q * p.cin_chunks + c) * (9 * 64 * 64) + hh * 256 + (ch * 32 + n) * 4;
-    const float* ab = lds + ((2 * ph) * HALO_W + n) * PSTR + hh * 4;
-#define LOAD_B(s) (*reinterpret_cast<const f32x4*>(wq + (s) * 512))
-#define LOAD_A(m, s) \
-  (*reinterpret_cast<const f32x4*>(ab + ((((s) >> 3) / 3 + (m)) * HALO_W + (((s) >> 3) % 3)) * PSTR + ((s) & 7) * 8))
-    // B ring: 4 steps (32 MFMAs, >= 2048 cycles) ahead of use, so an L2 miss to the Infinity Cache
-    // is still covered; A (LDS) one step ahead.  sched_barrier(0) after every step keeps hipcc from
-    // sinking the prefetches down to their first use (it otherwise emits load; s_waitcnt 0; mfma).
-    f32x4 bq[5];
-    f32x4 aq[2][2];
+    const int pix0 = (2 * ph) * HALO_W + n;  // halo pixel of (row 2ph, col n) at tap (0,0)
+    // A fragment of M-tile m, tap t, octet j: channels [8j+4hh, 8j+4hh+4) of halo pixel pix0 + m*34 + offset(t)
+    auto load_a = [&](int m, int t, int j) -> f32x4 {
+      const int pix = pix0 + (t / 3 + m) * HALO_W + (t % 3);
+      const int slot = (V == 2) ? ((2 * j + hh) ^ (pix & 15)) : (2 * j + hh);
+      return *reinterpret_cast<const f32x4*>(lds + pix * PSTR + slot * 4);
+    };
+    auto load_b = [&](int s) -> f32x4 {  // K-step s = tap*8 + j; clamped so the run-ahead never leaves the buffer
+      return *reinterpret_cast<const f32x4*>(wq + min(s, 71) * 512);
+    };
+    // Software pipeline over K-steps s = tap*8 + j (8 MFMAs each): B (global/L2) four steps ahead in an
+    // 8-slot ring, A (LDS) AD steps ahead in a 4-slot ring; both ring indices depend on j only, so the tap
+    // loop stays rolled (64-MFMA body, addresses recomputed per tap instead of 144 live address registers).
+    // sched_barrier(0) after every step keeps hipcc from sinking the prefetches down to their first use
+    // (it otherwise emits load; s_waitcnt 0; mfma).
+    f32x4 bq[8];
+    f32x4 aq[4][2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bq[s] = LOAD_B(s);
-    aq[0][0] = LOAD_A(0, 0);
-    aq[0][1] = LOAD_A(1, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < 4; ++s) bq[s] = load_b(s);
 #pragma unroll
-    for (int s = 0; s < 72; ++s) {
-      if (s + 4 < 72) bq[(s + 4) % 5] = LOAD_B(s + 4);
-      if (s + 1 < 72) {
-        aq[(s + 1) & 1][0] = LOAD_A(0, s + 1);
-        aq[(s + 1) & 1][1] = LOAD_A(1, s + 1);
-      }
-      const f32x4 bb = bq[s % 5];
-      const f32x4 a0 = aq[s & 1][0];
-      const f32x4 a1 = aq[s & 1][1];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bb[e], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bb[e], acc1, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < AD; ++s) {
+      aq[s][0] = load_a(0, 0, s);
+      aq[s][1] = load_a(1, 0, s);
     }
-#undef LOAD_A
-#undef LOAD_B
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int tnext = min(tap + 1, 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bq[(j + 4) & 7] = load_b(tap * 8 + j + 4);
+        {
+          const int ja = j + AD;  // step s + AD: same tap while ja < 8, else the next tap's first octets
+          aq[ja & 3][0] = load_a(0, ja < 8 ? tap : tnext, ja & 7);
+          aq[ja & 3][1] = load_a(1, ja < 8 ? tap : tnext, ja & 7);
+        }
+        const f32x4 bb = bq[j];
+        const f32x4 a0 = aq[j & 3][0];
+        const f32x4 a1 = aq[j & 3][1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bb[e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bb[e], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
 
   // ---- epilogue.  C/D map of the 32x32 tile: column (= output channel) on the lane, pixel
@@ -196,6 +230,42 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+// Both packings of one OIHW weight in a single launch: the forward B-fragment order (q = output chunk)
+// and the input-gradient order (roles swapped, taps flipped).  r > 1: the conv feeds PixelShuffle(r), so
+// its output channels are regrouped as chunk q = i*r+j <- {c*r*r + q}.
+__global__ void pack_conv3x3_both_kernel(const float* __restrict__ w, float* __restrict__ pf, float* __restrict__ pd,
+                                         int cout, int cin, int r) {
+  const long total = (long)cout * cin * 9;
+  const int rr = r * r;
+  const int oc = cout >> 6, ic = cin >> 6;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t_ = idx;
+    const int e = t_ & 3;
+    t_ >>= 2;
+    const int n = t_ & 63;
+    t_ >>= 6;
+    const int h = t_ & 1;
+    t_ >>= 1;
+    const int j = t_ & 7;
+    t_ >>= 3;
+    const int t = t_ % 9;
+    t_ /= 9;
+    const int k8 = 8 * j + 4 * h + e;
+    {  // forward: [q < oc][c < ic]; o = (n, q) through the shuffle map, i = c*64 + k8
+      const int c = t_ % ic, q = t_ / ic;
+      const long o = r > 1 ? (long)n * rr + q : (long)q * 64 + n;
+      const long i = (long)c * 64 + k8;
+      pf[idx] = w[(o * cin + i) * 9 + t];
+    }
+    {  // dgrad: [q < ic][c < oc]; output = original input channel q*64+n, input = original output (k8, c)
+      const int c = t_ % oc, q = t_ / oc;
+      const long i = (long)q * 64 + n;
+      const long o = r > 1 ? (long)k8 * rr + c : (long)c * 64 + k8;
+      pd[idx] = w[(o * cin + i) * 9 + (8 - t)];
+    }
+  }
+}
+
 static View view_from(const int64_t* v) {
   View r;
   r.sB = v[0];
@@ -216,6 +286,26 @@ extern "C" int sisr_pack_conv3x3(const float* w, float* packed, int cout, int ci
   hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cout / 64,
                      cin / 64, (long)so, (long)si, flip_taps, out_perm_n, out_perm_q, in_perm_n, in_perm_q);
   return sisr_check_launch();
+}
+
+extern "C" int sisr_pack_conv3x3_both(const float* w, float* packed_fwd, float* packed_dgrad, int cout, int cin,
+                                      int shuffle_r, void* stream) {
+  if (!w || !packed_fwd || !packed_dgrad || cout <= 0 || cin <= 0 || (cout & 63) || (cin & 63) || shuffle_r < 1)
+    return SISR_ERR_ARG;
+  if (shuffle_r > 1 && cout != 64 * shuffle_r * shuffle_r) return SISR_ERR_UNSUPPORTED;
+  const long total = (long)cout * cin * 9;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_conv3x3_both_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed_fwd,
+                     packed_dgrad, cout, cin, shuffle_r);
+  return sisr_check_launch();
+}
+
+// Tuning knob (process-wide, read-only during launches): which conv3x3_c64 variant to run.
+static int g_conv_variant = 2;
+extern "C" int sisr_conv3x3_c64_set_variant(int v) {
+  if (v < 0 || v > 2) return SISR_ERR_ARG;
+  g_conv_variant = v;
+  return SISR_OK;
 }
 
 extern "C" int sisr_conv3x3_c64_gap_parts(int H, int W) { return ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * 2; }
@@ -256,9 +346,20 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   p.tiles_h = (H + TH - 1) / TH;
   const long nblk = (long)p.tiles_w * p.tiles_h * B;
   if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
-  const size_t lds_bytes = (size_t)HALO_H * HALO_W * PSTR * sizeof(float);
-  SISR_ALLOW_LDS(conv3x3_c64_kernel, lds_bytes);
-  hipLaunchKernelGGL(conv3x3_c64_kernel, dim3((unsigned)nblk, p.cout_chunks), dim3(256), lds_bytes,
-                     (hipStream_t)stream, p);
+  const dim3 grid((unsigned)nblk, p.cout_chunks);
+  switch (g_conv_variant) {
+    case 0:
+      hipLaunchKernelGGL(conv3x3_c64_kernel<0>, grid, dim3(256), HALO_H * HALO_W * 68 * sizeof(float),
+                         (hipStream_t)stream, p);
+      break;
+    case 1:
+      hipLaunchKernelGGL(conv3x3_c64_kernel<1>, grid, dim3(256), HALO_H * HALO_W * 68 * sizeof(float),
+                         (hipStream_t)stream, p);
+      break;
+    default:
+      hipLaunchKernelGGL(conv3x3_c64_kernel<2>, grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float),
+                         (hipStream_t)stream, p);
+      break;
+  }
   return sisr_check_launch();
 }

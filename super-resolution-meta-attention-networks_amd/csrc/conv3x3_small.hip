@@ -36,15 +36,17 @@ struct Cin3Params {
   int flip, B, H, W, cout;
 };
 
+// thread = (pixel, 16 consecutive output channels): the 27 input taps are loaded once per 16 outputs, the
+// weights come from LDS as float4 (4 distinct addresses per wave), the store is 64 B per lane / 256 B per pixel.
 __global__ __launch_bounds__(256) void conv3x3_cin3_kernel(Cin3Params p) {
-  extern __shared__ float wl[];  // [27][cout]
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [27][cout]
   for (int i = threadIdx.x; i < 27 * p.cout; i += 256) {
     const int k = i / p.cout, co = i - k * p.cout;
     const int ci = k / 9, t = k - ci * 9;
     wl[i] = p.w[(long)co * p.so + (long)ci * p.si + (p.flip ? 8 - t : t)];
   }
   __syncthreads();
-  const int groups = p.cout >> 2;  // float4 groups per pixel
+  const int groups = p.cout >> 4;  // 16-channel groups per pixel
   const long hw = (long)p.H * p.W;
   const long total = (long)p.B * hw * groups;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -53,23 +55,31 @@ __global__ __launch_bounds__(256) void conv3x3_cin3_kernel(Cin3Params p) {
     const long b = pix / hw;
     const long r = pix - b * hw;
     const int h = (int)(r / p.W), w = (int)(r - (long)h * p.W);
-    const int co = cg * 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) acc = (f32x4){p.bias[co], p.bias[co + 1], p.bias[co + 2], p.bias[co + 3]};
+    const int co = cg * 16;
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      acc[u] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + co + 4 * u) : (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* xb = p.x + b * 3 * hw;
+    float xv[27];
 #pragma unroll
-    for (int ci = 0; ci < 3; ++ci)
+    for (int k = 0; k < 27; ++k) {
+      const int ci = k / 9, t = k % 9;
+      const int gh = h + t / 3 - 1, gw = w + t % 3 - 1;
+      const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+      const int ch_ = min(max(gh, 0), p.H - 1), cw_ = min(max(gw, 0), p.W - 1);
+      const float v = xb[ci * hw + (long)ch_ * p.W + cw_];
+      xv[k] = ok ? v : 0.f;
+    }
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+    for (int k = 0; k < 27; ++k) {
+      const f32x4* wr = reinterpret_cast<const f32x4*>(wl + k * p.cout + co);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int gh = h + kh - 1, gw = w + kw - 1;
-          const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
-          const float xv = ok ? xb[ci * hw + (long)gh * p.W + gw] : 0.f;
-          acc += xv * *reinterpret_cast<const f32x4*>(wl + (ci * 9 + kh * 3 + kw) * p.cout + co);
-        }
-    const int q = co >> 6;
-    *reinterpret_cast<f32x4*>(p.y + b * p.yv.sB + (long)h * p.yv.sH + (long)w * p.yv.sW + p.yv.chunk(q) + (co & 63)) = acc;
+      for (int u = 0; u < 4; ++u) acc[u] += xv[k] * wr[u];
+    }
+    float* yo = p.y + b * p.yv.sB + (long)h * p.yv.sH + (long)w * p.yv.sW + p.yv.chunk(co >> 6) + (co & 63);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) reinterpret_cast<f32x4*>(yo)[u] = acc[u];
   }
 }
 
@@ -84,48 +94,64 @@ struct Cout3Params {
   int flip, B, H, W, cin_chunks;
 };
 
-// 16 lanes per pixel, lane owns input channels [4*c4, 4*c4+4) of the current chunk; 108 weights in VGPRs.
+// 16 lanes per pixel; a lane owns input channels [4*c4, 4*c4+4) of each chunk and keeps its 108 weights
+// (9 taps x 4 ch x 3 outputs) in VGPRs across the whole pixel loop; the 16 partial dots are combined with
+// four xor-shuffles.  Per pixel: nine coalesced 256-B row reads, 108 FMAs per lane.
 __global__ __launch_bounds__(256) void conv3x3_cout3_kernel(Cout3Params p) {
   const int c4 = threadIdx.x & 15;
   const long hw = (long)p.H * p.W;
   const long npix = (long)p.B * hw;
   const long gstride = (long)gridDim.x * 16;
-  for (long pix0 = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix0 < ((npix + 15) & ~15L); pix0 += gstride) {
-    const bool live = pix0 < npix;
-    const long pix = live ? pix0 : npix - 1;
-    const long b = pix / hw;
-    const long r = pix - b * hw;
-    const int h = (int)(r / p.W), w = (int)(r - (long)h * p.W);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int c = 0; c < p.cin_chunks; ++c) {
+  const long pend = (npix + 15) & ~15L;
+  for (int c = 0; c < p.cin_chunks; ++c) {
+    float wr[9][4][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+          wr[t][e][o] = p.w[(long)o * p.so + ((long)c * 64 + c4 * 4 + e) * p.si + (p.flip ? 8 - t : t)];
+    for (long pix0 = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix0 < pend; pix0 += gstride) {
+      const bool live = pix0 < npix;
+      const long pix = live ? pix0 : npix - 1;
+      const long b = pix / hw;
+      const long r = pix - b * hw;
+      const int h = (int)(r / p.W), w = (int)(r - (long)h * p.W);
       const float* xb = p.x + b * p.xv.sB + p.xv.chunk(c) + c4 * 4;
-      const long ci0 = (long)c * 64 + c4 * 4;
+      f32x4 xv[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int gh = h + t / 3 - 1, gw = w + t % 3 - 1;
         const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
         const int ch_ = min(max(gh, 0), p.H - 1), cw_ = min(max(gw, 0), p.W - 1);
-        const f32x4 xv = sisr_keep_if(*reinterpret_cast<const f32x4*>(xb + (long)ch_ * p.xv.sH + (long)cw_ * p.xv.sW), ok);
-        const int tt = p.flip ? 8 - t : t;
+        xv[t] = sisr_keep_if(*reinterpret_cast<const f32x4*>(xb + (long)ch_ * p.xv.sH + (long)cw_ * p.xv.sW), ok);
+      }
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float* wp = p.w + (ci0 + e) * p.si + tt;  // L1/L2-resident (1728 floats), re-read per pixel
-          a0 += xv[e] * wp[0];
-          a1 += xv[e] * wp[p.so];
-          a2 += xv[e] * wp[2 * p.so];
+          a0 += xv[t][e] * wr[t][e][0];
+          a1 += xv[t][e] * wr[t][e][1];
+          a2 += xv[t][e] * wr[t][e][2];
         }
-      }
-    }
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      a0 += __shfl_xor(a0, o);
-      a1 += __shfl_xor(a1, o);
-      a2 += __shfl_xor(a2, o);
-    }
-    if (live && c4 < 3) {
-      float v = c4 == 0 ? a0 : (c4 == 1 ? a1 : a2);
-      if (p.bias) v += p.bias[c4];
-      p.y[(b * 3 + c4) * hw + r] = v;
+      for (int o = 1; o < 16; o <<= 1) {
+        a0 += __shfl_xor(a0, o);
+        a1 += __shfl_xor(a1, o);
+        a2 += __shfl_xor(a2, o);
+      }
+      if (live && c4 < 3) {
+        float v = c4 == 0 ? a0 : (c4 == 1 ? a1 : a2);
+        float* yo = p.y + (b * 3 + c4) * hw + r;
+        if (c == 0) {
+          if (p.bias) v += p.bias[c4];
+        } else {
+          v += *yo;  // later chunks accumulate (same thread wrote it: no race)
+        }
+        *yo = v;
+      }
     }
   }
 }
@@ -140,43 +166,77 @@ struct Corr3Params {
 };
 #define CORR_ROWS 31
 
-// thread (c = tid&63, pl = tid>>6); block handles a contiguous run of pixels; grid (blocks, chunks)
+// Persistent blocks walk 4x64-pixel tiles (tile = blockIdx.x, += gridDim.x).  Per tile the 3-channel halo
+// (3 x 6 x 66 floats, zero padded) is staged in LDS; wave w owns tile row w, lane c owns channel c of the
+// 64-channel chunk blockIdx.y: per pixel one coalesced 256-B Q row (8 rows in flight) and 27 broadcast LDS
+// reads feed 27 FMAs into per-lane accumulators.  Waves are combined through LDS in wave order at the end.
+#define CT_H 4
+#define CT_W 64
+#define CP_W (CT_W + 2)
+#define CP_N (3 * (CT_H + 2) * CP_W)
 __global__ __launch_bounds__(256) void corr3x3_c3_kernel(Corr3Params p) {
+  __shared__ float ph[CP_N];
   __shared__ float red[3][CORR_ROWS][64];
   const int c = threadIdx.x & 63;
-  const int pl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = blockIdx.y;
   const long hw = (long)p.H * p.W;
-  const long npix = (long)p.B * hw;
-  const long per = (npix + p.blocks - 1) / p.blocks;
-  const long p0 = (long)blockIdx.x * per;
-  const long p1 = p0 + per < npix ? p0 + per : npix;
+  const int tiles_w = (p.W + CT_W - 1) / CT_W, tiles_h = (p.H + CT_H - 1) / CT_H;
+  const int per_img = tiles_w * tiles_h;
+  const int total = per_img * p.B;
   float acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.f;
   float qs = 0.f, ps0 = 0.f, ps1 = 0.f, ps2 = 0.f;
-  for (long pix = p0 + pl; pix < p1; pix += 4) {
-    const long b = pix / hw;
-    const long r = pix - b * hw;
-    const int h = (int)(r / p.W), w = (int)(r - (long)h * p.W);
-    const float qv = p.Q[b * p.qv.sB + (long)h * p.qv.sH + (long)w * p.qv.sW + p.qv.chunk(q) + c];
-    qs += qv;
-    const float* pb = p.P + b * 3 * hw;
+  for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const int b = tile / per_img;
+    const int tr = tile - b * per_img;
+    const int th = tr / tiles_w, tw = tr - th * tiles_w;
+    const int h0 = th * CT_H, w0 = tw * CT_W;
+    __syncthreads();
+    for (int i = threadIdx.x; i < CP_N; i += 256) {
+      const int a = i / ((CT_H + 2) * CP_W);
+      const int r = i - a * ((CT_H + 2) * CP_W);
+      const int pr = r / CP_W, pc = r - pr * CP_W;
+      const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
+      const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+      ph[i] = ok ? p.P[((long)b * 3 + a) * hw + (long)gh * p.W + gw] : 0.f;
+    }
+    __syncthreads();
+    const int gh = h0 + wv;
+    if (gh < p.H) {
+      const float* qrow = p.Q + (long)b * p.qv.sB + (long)gh * p.qv.sH + p.qv.chunk(q) + c;
+      const float* prow = ph + wv * CP_W;  // tap (0,0) of tile column 0, channel 0
+#pragma unroll 1
+      for (int x0 = 0; x0 < CT_W; x0 += 8) {
+        float qv[8];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+        for (int u = 0; u < 8; ++u) {
+          const int gw = w0 + x0 + u;
+          const float v = qrow[(long)min(gw, p.W - 1) * p.qv.sW];
+          qv[u] = gw < p.W ? v : 0.f;
+        }
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int gh = h + t / 3 - 1, gw = w + t % 3 - 1;
-        const bool ok = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
-        const float pv = ok ? pb[a * hw + (long)gh * p.W + gw] : 0.f;  // wave-uniform address
-        acc[a * 9 + t] += pv * qv;
-        if (t == 4) {
-          if (a == 0) ps0 += pv;
-          if (a == 1) ps1 += pv;
-          if (a == 2) ps2 += pv;
+        for (int u = 0; u < 8; ++u) {
+          qs += qv[u];
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+              const float pv = prow[a * ((CT_H + 2) * CP_W) + (t / 3) * CP_W + (t % 3) + x0 + u];
+              acc[a * 9 + t] += pv * qv[u];
+            }
+          if (w0 + x0 + u < p.W) {  // centre tap = the pixel itself: bias sums of P
+            ps0 += prow[0 * ((CT_H + 2) * CP_W) + CP_W + 1 + x0 + u];
+            ps1 += prow[1 * ((CT_H + 2) * CP_W) + CP_W + 1 + x0 + u];
+            ps2 += prow[2 * ((CT_H + 2) * CP_W) + CP_W + 1 + x0 + u];
+          }
         }
       }
+    }
   }
+  const int pl = wv;
+  __syncthreads();
   if (pl > 0) {
 #pragma unroll
     for (int k = 0; k < 27; ++k) red[pl - 1][k][c] = acc[k];
@@ -242,6 +302,7 @@ extern "C" int sisr_conv3x3_cin3(const float* x, const float* w, int64_t so, int
                                  float* y, const int64_t* yview, int B, int H, int W, int cout, void* stream) {
   if (!x || !w || !y || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
   if (cout <= 0 || (cout & 63) || cout > 512) return SISR_ERR_UNSUPPORTED;
+  if (!sisr_aligned16(bias)) return SISR_ERR_ALIGN;
   Cin3Params p;
   p.x = x;
   p.y = y;
@@ -256,9 +317,9 @@ extern "C" int sisr_conv3x3_cin3(const float* x, const float* w, int64_t so, int
   p.H = H;
   p.W = W;
   p.cout = cout;
-  const long total = (long)B * H * W * (cout >> 2);
+  const long total = (long)B * H * W * (cout >> 4);
   long blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(conv3x3_cin3_kernel, dim3((unsigned)blocks), dim3(256), 27 * cout * sizeof(float),
                      (hipStream_t)stream, p);
   return sisr_check_launch();
@@ -291,9 +352,8 @@ extern "C" int sisr_conv3x3_cout3(const float* x, const int64_t* xview, const fl
 }
 
 static int corr3_blocks(int B, int H, int W) {
-  const long npix = (long)B * H * W;
-  long nb = (npix + 1023) / 1024;
-  if (nb > 1024) nb = 1024;
+  long nb = (long)B * ((H + CT_H - 1) / CT_H) * ((W + CT_W - 1) / CT_W);
+  if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   return (int)nb;
 }

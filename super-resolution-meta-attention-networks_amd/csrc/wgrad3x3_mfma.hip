@@ -190,14 +190,37 @@ struct ReduceParams {
   int S, units, cin_chunks, cout_chunks, flip, on, oq, in_, iq, bias_n, bias_q;
 };
 
-__global__ void wgrad_reduce_kernel(ReduceParams p) {
+// blockDim = (64, 4): x = element within a 64-run (coalesced across slabs), y = slab group (S split 4 ways,
+// 8 loads in flight); the four group sums are added in group order through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceParams p) {
+  __shared__ float red[4][64];
   const long total = (long)p.units * SLAB;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid < total) {
+  const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+  const int grp = threadIdx.y;
+  float s = 0.f;
+  const bool is_w = gid < total;
+  const long j = gid - total;
+  const bool is_b = !is_w && p.db && j < (long)p.cout_chunks * 64;
+  if (is_w || is_b) {
+    const float* src = is_w ? p.slabs + gid : p.bias_slabs + j;
+    const long stride = is_w ? (long)p.units * SLAB : (long)p.cout_chunks * 64;
+    int k = grp;
+    for (; k + 28 < p.S; k += 32) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = src[(long)(k + 4 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; k < p.S; k += 4) s += src[(long)k * stride];
+  }
+  red[grp][threadIdx.x] = s;
+  __syncthreads();
+  if (grp != 0) return;
+  s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  if (is_w) {
     const int unit = (int)(gid / SLAB);
     const int e = (int)(gid - (long)unit * SLAB);
-    float s = 0.f;
-    for (int k = 0; k < p.S; ++k) s += p.slabs[((long)k * p.units + unit) * SLAB + e];
     const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
     const int quad = unit & 3, pair = unit >> 2;
     const int cq = pair % p.cout_chunks, cc = pair / p.cout_chunks;
@@ -206,14 +229,9 @@ __global__ void wgrad_reduce_kernel(ReduceParams p) {
     const long o = (long)co * p.on + (long)cq * p.oq;
     const long ii = (long)ci * p.in_ + (long)cc * p.iq;
     p.dw[o * p.so + ii * p.si + (p.flip ? 8 - t : t)] = s * p.alpha;
-  } else if (p.db) {
-    const long j = gid - total;  // 0 .. cout-1 in (cq, coh, n) order
-    if (j < (long)p.cout_chunks * 64) {
-      float s = 0.f;
-      for (int k = 0; k < p.S; ++k) s += p.bias_slabs[(long)k * p.cout_chunks * 64 + j];
-      const int cq = (int)(j >> 6), co = (int)(j & 63);
-      p.db[(long)co * p.bias_n + (long)cq * p.bias_q] = s * p.alpha;
-    }
+  } else if (is_b) {
+    const int cq = (int)(j >> 6), co = (int)(j & 63);
+    p.db[(long)co * p.bias_n + (long)cq * p.bias_q] = s * p.alpha;
   }
 }
 
@@ -299,6 +317,6 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   r.bias_n = bias_n;
   r.bias_q = bias_q;
   const long total = (long)units * SLAB + (dbias ? cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, 4), 0, (hipStream_t)stream, r);
   return sisr_check_launch();
 }

@@ -17,7 +17,9 @@ _lib = None
 P = c_void_p
 _SIGS = {
     "sisr_pack_conv3x3": (c_int, [P, P, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P]),
+    "sisr_pack_conv3x3_both": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "sisr_conv3x3_c64_gap_parts": (c_int, [c_int, c_int]),
+    "sisr_conv3x3_c64_set_variant": (c_int, [c_int]),
     "sisr_conv3x3_c64": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, c_float, c_int, P, c_int, c_int, c_int,
                                  c_int, c_int, P]),
     "sisr_wgrad3x3_c64_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -29,7 +31,8 @@ _SIGS = {
     "sisr_corr3x3_c3": (c_int, [P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, P, P, c_size_t, c_int, c_int, c_int,
                                 c_int, P]),
     "sisr_ca_gate_fwd": (c_int, [P, c_int, c_int, c_float, P, P, P, P, c_int, c_int, P, P, P, P, P, P]),
-    "sisr_ca_gate_bwd": (c_int, [P, c_int, c_int, c_float, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
+    "sisr_ca_gate_bwd_workspace_bytes": (c_size_t, [c_int]),
+    "sisr_ca_gate_bwd": (c_int, [P, c_int, c_int, c_float, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
     "sisr_meta_gate_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P]),
     "sisr_meta_gate_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P]),
     "sisr_gate_residual_fwd": (c_int, [P, P, P, P, P, c_int, c_long, c_int, P]),

@@ -52,6 +52,15 @@ def pack_weight(w, mode, shuffle=1):
     return packed
 
 
+def pack_pair(w, shuffle=1):
+    """(forward packing, input-gradient packing) of one weight, one launch."""
+    cout, cin = w.shape[0], w.shape[1]
+    buf = torch.empty(2, cout * cin * 9, device=w.device, dtype=torch.float32)
+    hip.check(hip.lib().sisr_pack_conv3x3_both(hip.ptr(w), hip.ptr(buf[0]), hip.ptr(buf[1]), cout, cin, shuffle,
+                                               hip.stream()), "sisr_pack_conv3x3_both")
+    return buf[0], buf[1]
+
+
 def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=None, mask=None, in_scale=None,
              in_shift=None, out_scale=None, alpha=1.0, relu=False, gap=None):
     rc = hip.lib().sisr_conv3x3_c64(hip.ptr(x), xview, hip.ptr(packed), hip.ptr(bias), bias_nq[0], bias_nq[1],
@@ -89,7 +98,10 @@ class _Conv3x3(Function):
         ctx.has_res = residual is not None
         if cin % 64 == 0 and cout % 64 == 0:
             x = _cl(x)
-            packed = pack_weight(w, "fwd", shuffle)
+            if ctx.needs_input_grad[0]:
+                packed, ctx.packed_dgrad = pack_pair(w, shuffle)
+            else:
+                packed, ctx.packed_dgrad = pack_weight(w, "fwd", shuffle), None
             if shuffle > 1:
                 if cout != 64 * shuffle * shuffle:
                     raise NotImplementedError("fused PixelShuffle needs Cout == 64*r*r")
@@ -141,7 +153,7 @@ class _Conv3x3(Function):
             r = ctx.shuffle
             dyview = hip.view_shuffle(H, W, r) if r > 1 else hip.view_plain(H, W, cout)
             if need_x:
-                packed = pack_weight(w, "dgrad", r)
+                packed = ctx.packed_dgrad if ctx.packed_dgrad is not None else pack_weight(w, "dgrad", r)
                 dx = _empty_cl(B, cin, H, W, dev)
                 conv_c64(dy, dyview, packed, None, (1, 64), dx, hip.view_plain(H, W, cin), B, H, W, cout, cin,
                          alpha=ctx.alpha)
@@ -244,9 +256,13 @@ class _ResBlock(Function):
         v = hip.view_plain(H, W, 64)
         has_ca, has_m = caw1 is not None, m is not None
         t1 = _empty_cl(B, 64, H, W, dev)
-        conv_c64(x, v, pack_weight(w1, "fwd"), b1, (1, 64), t1, v, B, H, W, 64, 64, relu=True)
+        if any(ctx.needs_input_grad):
+            p1, ctx.pd1 = pack_pair(w1)
+            p2, ctx.pd2 = pack_pair(w2)
+        else:
+            p1, p2 = pack_weight(w1, "fwd"), pack_weight(w2, "fwd")
+        conv_c64(x, v, p1, b1, (1, 64), t1, v, B, H, W, 64, 64, relu=True)
         y = _empty_cl(B, 64, H, W, dev)
-        p2 = pack_weight(w2, "fwd")
         saved_vecs = []
         if not has_ca and not has_m:  # ResBlock: everything fuses into conv2's epilogue
             conv_c64(t1, v, p2, b2, (1, 64), y, v, B, H, W, 64, 64, res=x, alpha=res_scale)
@@ -308,7 +324,7 @@ class _ResBlock(Function):
                 rc = L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
                                         hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
                                         hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
-                                        hip.stream())
+                                        hip.ptr(_vec(B, 80, dev)), hip.stream())
                 hip.check(rc, "sisr_ca_gate_bwd")
                 dcaw1, dcaw2 = dcaw1.reshape(s_caw1), dcaw2.reshape(s_caw2)
                 dm, scale = dmv, g
@@ -320,15 +336,15 @@ class _ResBlock(Function):
                 scale = g
         # conv2 backward: dt2 = dy*scale + shift is rebuilt on load, never stored
         dt1 = _empty_cl(B, 64, H, W, dev)
-        conv_c64(dy, v, pack_weight(w2, "dgrad"), None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1, in_scale=scale,
-                 in_shift=shift, alpha=rs)
+        conv_c64(dy, v, ctx.pd2, None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1, in_scale=scale, in_shift=shift,
+                 alpha=rs)
         dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
         wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, alpha=rs, dy_scale=scale, dy_shift=shift)
         # conv1 backward (+ skip connection gradient)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _empty_cl(B, 64, H, W, dev)
-            conv_c64(dt1, v, pack_weight(w1, "dgrad"), None, (1, 64), dx, v, B, H, W, 64, 64, res=dy)
+            conv_c64(dt1, v, ctx.pd1, None, (1, 64), dx, v, B, H, W, 64, 64, res=dy)
         dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
         wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64)
         return dx, dw1, db1, dw2, db2, dcaw1, dcab1, dcaw2, dcab2, (dm if has_m else None), None
@@ -434,7 +450,8 @@ class _CALayer(Function):
         dw2, db2 = torch.empty_like(w2c), torch.empty(64, device=dev)
         hip.check(hip.lib().sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / (H * W), hip.ptr(w1c), hip.ptr(w2c), 64, R,
                                              hip.ptr(s), hip.ptr(hid), hip.ptr(ca), None, hip.ptr(shift), None,
-                                             hip.ptr(dw1), hip.ptr(db1), hip.ptr(dw2), hip.ptr(db2), hip.stream()),
+                                             hip.ptr(dw1), hip.ptr(db1), hip.ptr(dw2), hip.ptr(db2),
+                                             hip.ptr(_vec(B, 80, dev)), hip.stream()),
                   "sisr_ca_gate_bwd")
         dx = _affine(dy, ca, shift, None, B, H, W, 64)
         return dx, dw1.reshape(ctx.shapes[0]), db1, dw2.reshape(ctx.shapes[1]), db2

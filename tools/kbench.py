@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the hot kernels through the C ABI (HIP-event timing, one process).
+
+    python tools/kbench.py [--batch 8] [--iters 20] [--only conv,wgrad,...]
+Prints one JSON line per kernel: mean launch time and achieved TFLOP/s (or GB/s) on 128x128x64 maps.
+Used for interleaved A/B of kernel variants and as the target of rocprofv3 --pmc passes.
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import sisr_amd  # noqa: E402
+
+ops, hip = sisr_amd.ops, sisr_amd.hip
+
+
+def timeit(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--hw", type=int, default=128)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--variants", default="0,1,2")
+    a = ap.parse_args()
+    only = set(a.only.split(",")) if a.only else None
+    B, H, W = a.batch, a.hw, a.hw
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    cl = torch.channels_last
+    x = torch.randn(B, 64, H, W, generator=g).to(dev).contiguous(memory_format=cl)
+    dy = torch.randn(B, 64, H, W, generator=g).to(dev).contiguous(memory_format=cl)
+    t1 = torch.relu(torch.randn(B, 64, H, W, generator=g)).to(dev).contiguous(memory_format=cl)
+    y = torch.empty_like(x)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev)
+    b = torch.randn(64, generator=g).to(dev)
+    sc = torch.rand(B, 64, generator=g).to(dev)
+    sh = torch.rand(B, 64, generator=g).to(dev)
+    v = hip.view_plain(H, W, 64)
+    pk = ops.pack_weight(w, "fwd")
+    gap = torch.empty(B, ops.gap_parts(H, W), 64, device=dev)
+    dw, db = torch.empty_like(w), torch.empty(64, device=dev)
+    flop = 2.0 * B * H * W * 64 * 64 * 9
+    fm = B * H * W * 64 * 4
+    res = {}
+
+    def run(name, fn, work, unit):
+        if only and name not in only and name.split("_v")[0] not in only:
+            return
+        t = timeit(fn, a.iters)
+        res[name] = {"us": t * 1e6, unit: work / t / (1e12 if unit == "TFLOP/s" else 1e9)}
+        print(json.dumps({"kernel": name, "batch": B, **res[name]}), flush=True)
+
+    for var in [int(t) for t in a.variants.split(",")]:
+        hip.lib().sisr_conv3x3_c64_set_variant(var)
+        run(f"conv_v{var}", lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64), flop, "TFLOP/s")
+        run(f"conv_dgrad2_v{var}", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1,
+                                                        in_scale=sc, in_shift=sh), flop, "TFLOP/s")
+    hip.lib().sisr_conv3x3_c64_set_variant(int(a.variants.split(",")[-1]))
+    run("conv_relu_gap", lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64, relu=True, gap=gap), flop,
+        "TFLOP/s")
+    run("conv_dgrad2", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1, in_scale=sc,
+                                            in_shift=sh), flop, "TFLOP/s")
+    run("conv_res", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, res=x), flop, "TFLOP/s")
+    run("wgrad", lambda: ops.wgrad_c64(x, v, dy, v, dw, db, B, H, W, 64, 64), flop, "TFLOP/s")
+    run("wgrad_affine", lambda: ops.wgrad_c64(x, v, dy, v, dw, db, B, H, W, 64, 64, dy_scale=sc, dy_shift=sh), flop,
+        "TFLOP/s")
+    run("pack", lambda: ops.pack_weight(w, "fwd"), 2 * 36864 * 4, "GB/s")
+    L = hip.lib()
+    parts = L.sisr_gate_dg_parts(H * W)
+    dgp = torch.empty(B, parts, 64, device=dev)
+    run("gate_dg_partial", lambda: L.sisr_gate_dg_partial(hip.ptr(dy), hip.ptr(x), hip.ptr(dgp), B, H * W, 64,
+                                                          hip.stream()), 2 * fm, "GB/s")
+    run("gate_residual", lambda: L.sisr_gate_residual_fwd(hip.ptr(dy), hip.ptr(sc), None, hip.ptr(x), hip.ptr(y), B,
+                                                          H * W, 64, hip.stream()), 3 * fm, "GB/s")
+    # tail-side kernels on the 4x upsampled map
+    Ht, Wt = 4 * H, 4 * W
+    Bt = max(1, B // 4)
+    xt = torch.randn(Bt, 64, Ht, Wt, generator=g).to(dev).contiguous(memory_format=cl)
+    wt = (torch.randn(3, 64, 3, 3, generator=g) * 0.05).to(dev).requires_grad_(True)
+    bt = torch.randn(3, generator=g).to(dev).requires_grad_(True)
+    xt.requires_grad_(True)
+    fmt = Bt * Ht * Wt * 64 * 4
+    run("tail_fwd", lambda: ops.conv3x3(xt, wt, bt), fmt, "GB/s")
+    if not only or "tail_bwd" in only:
+        yt = ops.conv3x3(xt, wt, bt)
+        cot = torch.randn_like(yt)
+        run("tail_bwd", lambda: torch.autograd.grad(yt, (xt, wt, bt), cot, retain_graph=True), 2 * fmt, "GB/s")
+    return res
+
+
+if __name__ == "__main__":
+    main()
