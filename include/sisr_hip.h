@@ -107,6 +107,22 @@ int sisr_gate_dg_parts(long hw);
 int sisr_gate_dg_partial(const float* dy, const float* t, float* part, int B, long hw, int channels, void* stream);
 int sisr_sum_partials(const float* part, int parts, int B, int channels, float scale, float* out, void* stream);
 
+/* ---- HAN attention modules ---------------------------------------------------------------------
+ * ref: advanced/HAN_blocks.py:7-37 LAM_Module: x [B][N][chw] (N layer maps, any common layout);
+ *      attn = softmax_j(max_j E_ij - E_ij), E = X X^T;  y = gamma*attn X + x.   N in {2..6, 8, 11}.
+ * ref: advanced/HAN_blocks.py:40-76 CSAM_Module: x NHWC 64 channels; w27 = Conv3d weight [dc][dh][dw];
+ *      y = x*(1 + gamma*sigmoid(conv3d(x) + bias)).  gamma / bias are DEVICE pointers (1-element parameters). */
+size_t sisr_lam_workspace_bytes(int B, int N, long chw);
+int sisr_lam_fwd(const float* x, const float* gamma, float* y, float* attn, float* workspace, int B, int N, long chw,
+                 void* stream);
+int sisr_lam_bwd(const float* x, const float* attn, const float* gamma, const float* dy, float* dx, float* dgamma,
+                 float* workspace, int B, int N, long chw, void* stream);
+int sisr_csam_fwd(const float* x, const float* w27, const float* bias, const float* gamma, float* y, int B, int H,
+                  int W, int C, void* stream);
+size_t sisr_csam_bwd_workspace_bytes(int B, int H, int W, int C);
+int sisr_csam_bwd(const float* x, const float* w27, const float* bias, const float* gamma, const float* dy, float* dx,
+                  float* dw27, float* dbias, float* dgamma, float* workspace, int B, int H, int W, int C, void* stream);
+
 /* ---- loss and optimiser ---------------------------------------------------------------------------
  * ref: SISR/models/__init__.py:268 nn.L1Loss, :299-308 optim.Adam, :481-489 standard_update */
 size_t sisr_l1_loss_workspace_bytes(void);

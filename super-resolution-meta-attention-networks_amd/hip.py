@@ -43,14 +43,15 @@ _SIGS = {
     "sisr_l1_loss": (c_int, [P, P, c_long, P, P, P, P]),
     "sisr_adam_flat": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_float, P]),
 }
-OPTIONAL_SIGS = {
+OPTIONAL_SIGS = {}
+_SIGS.update({
     "sisr_lam_workspace_bytes": (c_size_t, [c_int, c_int, c_long]),
-    "sisr_lam_fwd": (c_int, [P, c_float, P, P, P, c_int, c_int, c_long, P]),
-    "sisr_lam_bwd": (c_int, [P, P, c_float, P, P, P, P, c_int, c_int, c_long, P]),
-    "sisr_csam_fwd": (c_int, [P, P, c_float, c_float, P, c_int, c_int, c_int, c_int, P]),
+    "sisr_lam_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_long, P]),
+    "sisr_lam_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_long, P]),
+    "sisr_csam_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "sisr_csam_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "sisr_csam_bwd": (c_int, [P, P, c_float, c_float, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
-}
+    "sisr_csam_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+})
 
 
 class HipLibraryMissing(ImportError):

@@ -520,6 +520,130 @@ def global_avg_pool(t):
     return _GlobalAvgPool.apply(t)
 
 
+# ----------------------------------------------------------------------------- HAN attention modules
+class _LAM(Function):
+    """Layer attention over a [B][N][H][W][64] stack (ref: advanced/HAN_blocks.py:16-37)."""
+
+    @staticmethod
+    def forward(ctx, stack, gamma):
+        B, N = stack.shape[0], stack.shape[1]
+        chw = stack[0, 0].numel()
+        stack = stack.contiguous()
+        L = hip.lib()
+        nbytes = L.sisr_lam_workspace_bytes(B, N, chw)
+        if nbytes == 0:
+            raise NotImplementedError(f"LAM kernel: unsupported shape B={B} N={N} chw={chw}")
+        ws = hip.workspace(stack.device, nbytes)
+        y = torch.empty_like(stack)
+        attn = torch.empty((B, N, N), device=stack.device, dtype=torch.float32)
+        g = gamma.reshape(1).contiguous()
+        hip.check(L.sisr_lam_fwd(hip.ptr(stack), hip.ptr(g), hip.ptr(y), hip.ptr(attn), hip.ptr(ws), B, N, chw,
+                                 hip.stream()), "sisr_lam_fwd")
+        ctx.save_for_backward(stack, attn, g)
+        ctx.gshape = gamma.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stack, attn, g = ctx.saved_tensors
+        B, N = stack.shape[0], stack.shape[1]
+        chw = stack[0, 0].numel()
+        L = hip.lib()
+        nbytes = L.sisr_lam_workspace_bytes(B, N, chw)
+        ws = hip.workspace(stack.device, nbytes)
+        dy = dy.contiguous()
+        dx = torch.empty_like(stack)
+        dg = torch.empty(1, device=stack.device, dtype=torch.float32)
+        hip.check(L.sisr_lam_bwd(hip.ptr(stack), hip.ptr(attn), hip.ptr(g), hip.ptr(dy), hip.ptr(dx), hip.ptr(dg),
+                                 hip.ptr(ws), B, N, chw, hip.stream()), "sisr_lam_bwd")
+        return dx, dg.reshape(ctx.gshape)
+
+
+def lam(stack, gamma):
+    return _LAM.apply(stack, gamma)
+
+
+class _CSAM(Function):
+    """x * (1 + gamma * sigmoid(conv3d(x))) on a channels-last 64-channel map (ref: advanced/HAN_blocks.py:58-76)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma):
+        B, C, H, W = x.shape
+        if C != 64:
+            raise NotImplementedError("CSAM kernel is specialised for 64 channels")
+        x = _cl(x)
+        w27 = w.reshape(27).contiguous()
+        bb, g = b.reshape(1).contiguous(), gamma.reshape(1).contiguous()
+        y = _empty_cl(B, C, H, W, x.device)
+        hip.check(hip.lib().sisr_csam_fwd(hip.ptr(x), hip.ptr(w27), hip.ptr(bb), hip.ptr(g), hip.ptr(y), B, H, W, C,
+                                          hip.stream()), "sisr_csam_fwd")
+        ctx.save_for_backward(x, w27, bb, g)
+        ctx.shapes = (w.shape, b.shape, gamma.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w27, bb, g = ctx.saved_tensors
+        B, C, H, W = x.shape
+        L = hip.lib()
+        dy = _cl(dy)
+        nbytes = L.sisr_csam_bwd_workspace_bytes(B, H, W, C)
+        ws = hip.workspace(x.device, nbytes)
+        dx = _empty_cl(B, C, H, W, x.device)
+        dw, db, dg = (torch.empty(n, device=x.device, dtype=torch.float32) for n in (27, 1, 1))
+        hip.check(L.sisr_csam_bwd(hip.ptr(x), hip.ptr(w27), hip.ptr(bb), hip.ptr(g), hip.ptr(dy), hip.ptr(dx),
+                                  hip.ptr(dw), hip.ptr(db), hip.ptr(dg), hip.ptr(ws), B, H, W, C, hip.stream()),
+                  "sisr_csam_bwd")
+        sw, sb, sg = ctx.shapes
+        return dx, dw.reshape(sw), db.reshape(sb), dg.reshape(sg)
+
+
+def csam(x, w, b, gamma):
+    return _CSAM.apply(x, w, b, gamma)
+
+
+class _ConvStack(Function):
+    """3x3 conv 64*N -> 64 reading a [B][N][H][W][64] map stack as N channel chunks (HAN last_conv /
+    last, ref: advanced/architectures.py:349-350,366-371) -- torch.cat is never materialised."""
+
+    @staticmethod
+    def forward(ctx, stack, weight, bias):
+        B, N, H, W, C = stack.shape
+        if C != 64 or weight.shape[0] != 64 or weight.shape[1] != 64 * N:
+            raise NotImplementedError("stack conv expects N maps of 64 channels -> 64 channels")
+        stack = stack.contiguous()
+        w = weight.contiguous()
+        if ctx.needs_input_grad[0]:
+            packed, ctx.pd = pack_pair(w)
+        else:
+            packed, ctx.pd = pack_weight(w, "fwd"), None
+        y = _empty_cl(B, 64, H, W, stack.device)
+        conv_c64(stack, hip.view_maps(H, W, N), packed, bias, (1, 64), y, hip.view_plain(H, W, 64), B, H, W, 64 * N, 64)
+        ctx.save_for_backward(stack, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stack, w = ctx.saved_tensors
+        B, N, H, W, C = stack.shape
+        dev = stack.device
+        dy = _cl(dy)
+        dstack = None
+        if ctx.needs_input_grad[0]:
+            dstack = torch.empty_like(stack)
+            conv_c64(dy, hip.view_plain(H, W, 64), ctx.pd, None, (1, 64), dstack, hip.view_maps(H, W, N), B, H, W, 64,
+                     64 * N)
+        dw = torch.empty_like(w)
+        db = torch.empty(64, device=dev, dtype=torch.float32) if ctx.has_bias else None
+        wgrad_c64(stack, hip.view_maps(H, W, N), dy, hip.view_plain(H, W, 64), dw, db, B, H, W, 64 * N, 64)
+        return dstack, dw, db
+
+
+def conv3x3_stack(stack, weight, bias):
+    return _ConvStack.apply(stack, weight, bias)
+
+
 # ----------------------------------------------------------------------------- L1 loss
 class _L1Loss(Function):
     @staticmethod

@@ -182,6 +182,33 @@ def test_g1_paramresblock(nl):
     run_block(f"g1_paramresblock_nl{nl}", m, 2, call=lambda mod, i: mod((i[0], i[1]))[0])
 
 
+def test_g1_han_modules():
+    H = sisr_amd.han
+    run_block("g1_lam", H.LAM_Module(16), 1, rtol=5e-4, atol=5e-5)
+    run_block("g1_csam_c64", H.CSAM_Module(64), 1, rtol=5e-4, atol=5e-5)
+
+
+def test_lam_full_size_vs_oracle():
+    """11 maps of 64x32x32: the production map count, gamma != 0 so the attention branch is live."""
+    H = sisr_amd.han
+    m = H.LAM_Module(64)
+    with torch.no_grad():
+        m.gamma.fill_(0.5)
+    x = rnd(2, 11, 64, 32, 32, seed=40, scale=0.05)
+    xo = x.clone().requires_grad_(True)
+    sd = {"la.gamma": m.gamma.detach().clone().requires_grad_(True)}
+    ref = O.lam_module(sd, "la", xo)
+    cot = rnd(*ref.shape, seed=41)
+    ref.backward(cot)
+    m.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out = m(xg)
+    out.backward(cot.to(DEV))
+    close(out, ref, 5e-4, 5e-5)
+    close(xg.grad, xo.grad, 2e-3, 2e-4)
+    close(m.gamma.grad, sd["la.gamma"].grad, 2e-3, 2e-4)
+
+
 # ----------------------------------------------------------------------------- reduced-depth nets (n_feats = 64) vs the oracle
 def net_vs_oracle(net, name, cfg, x, md=None, rtol=5e-4, atol=5e-5):
     torch.manual_seed(8)
@@ -219,6 +246,27 @@ def test_qrcan_reduced_vs_oracle():
     cfg = dict(n_resgroups=2, n_resblocks=3, scale=4, style="standard", include_q_layer=True,
                selective_meta_blocks=[True, False], num_q_layers_inner_residual=2)
     net_vs_oracle(net, "qrcan", cfg, rnd(2, 3, 12, 34, seed=33, scale=0.5), rnd(2, 10, 1, 1, seed=34, scale=0.3))
+
+
+def _live_gammas(net):
+    with torch.no_grad():  # zero-initialised gammas would switch both attention branches off
+        net.la.gamma.fill_(0.37)
+        net.csa.gamma.fill_(0.37)
+
+
+def test_han_reduced_vs_oracle():
+    torch.manual_seed(8)
+    net = sisr_amd.han.HAN(n_resgroups=10, n_resblocks=1, n_feats=64, scale=4)
+    _live_gammas(net)
+    net_vs_oracle(net, "han", dict(n_resgroups=10, n_resblocks=1, scale=4), rnd(1, 3, 12, 20, seed=37, scale=0.5))
+
+
+def test_qhan_reduced_vs_oracle():
+    torch.manual_seed(8)
+    net = sisr_amd.han.QHAN(n_resgroups=10, n_resblocks=1, n_feats=64, num_metadata=10, scale=4)
+    _live_gammas(net)
+    net_vs_oracle(net, "qhan", dict(n_resgroups=10, n_resblocks=1, scale=4), rnd(2, 3, 12, 20, seed=38, scale=0.5),
+                  rnd(2, 10, 1, 1, seed=39, scale=0.3))
 
 
 def test_qedsr_reduced_vs_oracle():
