@@ -1,0 +1,199 @@
+"""Paired LR/HR image dataset producing the reference's batch-dict schema (host-side, CPU/PIL).
+
+ref: Code/sr_tools/data_handler.py:147-528 (SuperResImages; __getitem__ :433-525, read_augmentation_list :62-144),
+     Code/sr_tools/image_manipulation.py:233-257 (matched random crop, flip/rotate),
+     Code/SISR/training/data_setup.py:9-125 (sisr_data_setup).
+This is the caller side of the hot path: it is reproduced (same file ordering, same Python `random` call
+order, same dict keys), not accelerated.  Options outside the in-scope configs (online degradations, masks,
+CelebA attribute files, QPI group filters, Y-only inputs) raise NotImplementedError.
+"""
+import glob
+import json
+import os
+import random
+import re
+
+import numpy as np
+import torch
+from torch.utils.data import ConcatDataset, DataLoader, Dataset
+
+DATA_SPLITS = {'celeba': {'train': (0, 162770), 'eval': (162770, 182637), 'test': (182637, 202599)},
+               'div2k': {'train': (0, 800), 'eval': (800, 900)}, 'flickr2k': {'train': (0, 2650)}}
+
+
+def image_names(folder, recursive=False):
+    names = []
+    for ext in ('*.jpg', '*.png', '*.bmp', '*.tif'):
+        pat = os.path.join(folder, '**', ext) if recursive else os.path.join(folder, ext)
+        names.extend(glob.glob(pat, recursive=recursive))
+    names.sort()
+    return names
+
+
+def to_tensor(pil_image):
+    """torchvision ToTensor for uint8 RGB: HWC uint8 -> CHW float32 / 255."""
+    arr = np.asarray(pil_image)
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    return torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1))).to(torch.float32).div(255)
+
+
+def read_image(filename):
+    import PIL.Image
+    im = PIL.Image.open(filename)
+    if im.mode in ('RGBA', 'L'):
+        im = im.convert('RGB')
+    return im
+
+
+def center_crop(image, height, width):
+    left = int(round((image.width - width) / 2.))
+    top = int(round((image.height - height) / 2.))
+    return image.crop((left, top, left + width, top + height))
+
+
+def random_flip_rotate(lr, hr):
+    """Three draws from `random` in the reference's order (hflip, vflip, rot90)."""
+    hflip = random.random() < 0.5
+    vflip = random.random() < 0.5
+    rot90 = random.random() < 0.5
+
+    def aug(img):
+        if hflip:
+            img = torch.flip(img, [2])
+        if vflip:
+            img = torch.flip(img, [1])
+        if rot90:
+            img = torch.transpose(img, 1, 2)
+        return img
+    return aug(lr), aug(hr)
+
+
+def random_matched_crop(lr, hr, crop_size, scale):
+    rnd_h = random.randint(0, max(0, lr.size()[1] - crop_size))
+    rnd_w = random.randint(0, max(0, lr.size()[2] - crop_size))
+    c_lr = lr[:, rnd_h:rnd_h + crop_size, rnd_w:rnd_w + crop_size]
+    gh, gw = int(rnd_h * scale), int(rnd_w * scale)
+    c_hr = hr[:, gh:gh + int(crop_size * scale), gw:gw + int(crop_size * scale)]
+    return c_lr, c_hr
+
+
+def read_degradation_metadata(metadata_file, filenames):
+    """CSV (index = image name) -> ({name: vector}, keys).  List columns (JSON) expand to repeated keys; integer
+    columns are min-max normalised (QPI over the fixed 20..40 range)."""
+    import pandas as pd
+    keys = []
+    data = pd.read_csv(metadata_file, header=0, index_col=0)
+    for col in data:
+        if data[col].dtype == object:
+            data[col] = data[col].apply(json.loads)
+            keys.extend([col.lower()] * len(data[col].iloc[0]))
+        elif data[col].dtype == int:
+            data[col] = data[col].astype(float)
+            keys.append(col.lower())
+            lo, hi = (20, 40) if col == 'QPI' else (data[col].min(), data[col].max())
+            data[col] = (data[col] - lo) / (hi - lo)
+        else:
+            raise RuntimeError('Unidentified datatype in metadata file.')
+    table = data.T.to_dict('list')
+    out = {}
+    for name in filenames:
+        vec = []
+        for v in table[name]:
+            vec.extend(v) if isinstance(v, list) else vec.append(v)
+        out[name] = np.array(vec)
+    return out, keys
+
+
+class SuperResImages(Dataset):
+    def __init__(self, lr_dir=None, hr_dir=None, dataset=None, split=None, custom_split=None, recursive_search=False,
+                 input='unmodified', colorspace='rgb', scale=4, degradation_metadata_file=None, metadata=None,
+                 random_augments=None, random_crop=None, **unsupported):
+        super().__init__()
+        if split not in ['train', 'eval', 'test', 'all', None]:
+            raise RuntimeError('"Split" must be one of: train | eval | test | all | None')
+        if input != 'unmodified' or 'rgb' not in colorspace:
+            raise NotImplementedError('only unmodified RGB inputs are in scope (EDSR/RCAN/HAN families)')
+        for k in ('online_degradations', 'mask_data', 'halfway_data', 'blacklist', 'data_attributes', 'image_shortlist',
+                  'legacy_blur_kernels', 'request_crops', 'group_select', 'attribute_amplification'):
+            if unsupported.get(k):
+                raise NotImplementedError(f'data option {k!r} is outside the HIP hot-path scope')
+        self.scale, self.patch_crop, self.random_augment = scale, random_crop, random_augments
+        self.lr_base, self.hr_base = lr_dir, hr_dir
+        groups = {}
+        for f in image_names(lr_dir, recursive_search):
+            rel = os.path.relpath(f, lr_dir)
+            parts = re.split(r"_q(.*)(?=\.)", rel)
+            base = parts[0] + parts[2] if len(parts) > 1 else parts[0]
+            groups.setdefault(base, []).append(rel)
+        items = list(groups.items())
+        if custom_split is not None or (split != 'all' and len(items) != 1):
+            start, end = custom_split if custom_split is not None else DATA_SPLITS[dataset][split]
+            items = items[start:end]
+        self.lr_filenames = [f for _, fs in items for f in fs]
+        self.base_filenames = [b for b, fs in items for _ in fs]
+        if not self.lr_filenames:
+            raise RuntimeError('No images were supplied or all images were filtered out!')
+        self.metadata, self.metadata_keys = None, []
+        if degradation_metadata_file is not None:
+            table, self.metadata_keys = read_degradation_metadata(degradation_metadata_file, self.lr_filenames)
+            self.metadata = [table[n] for n in self.lr_filenames]
+        self.image_count = len(self.lr_filenames)
+        print('Initialized %s data with %d image%s.' % (dataset if dataset is not None else 'image', self.image_count,
+                                                        's' if self.image_count > 1 else ''))
+
+    def __len__(self):
+        return self.image_count
+
+    def __getitem__(self, index):
+        base_name, image_name = self.base_filenames[index], self.lr_filenames[index]
+        lr_im = read_image(os.path.join(self.lr_base, image_name))
+        metadata = self.metadata[index] if self.metadata is not None else np.array(0)
+        if self.hr_base is not None:
+            hr_im = read_image(os.path.join(self.hr_base, base_name))
+            h, w = lr_im.height * self.scale, lr_im.width * self.scale
+            if hr_im.width != w or hr_im.height != h:
+                hr_im = center_crop(hr_im, height=h, width=w)
+            hr_im = to_tensor(hr_im)
+        else:
+            hr_im = np.array(0)
+        lr_im = to_tensor(lr_im)
+        if self.random_augment is not None:
+            lr_im, hr_im = random_flip_rotate(lr_im, hr_im)
+        if self.patch_crop is not None:
+            lr_im, hr_im = random_matched_crop(lr_im, hr_im, crop_size=self.patch_crop, scale=self.scale)
+        return {'lr': lr_im, 'hr': hr_im, 'tag': image_name, 'hr_tag': base_name, 'mask': np.array(0),
+                'halfway_data': np.array(0), 'metadata': metadata, 'metadata_keys': self.metadata_keys,
+                'blur_kernels': np.array(0)}
+
+
+def sisr_data_setup(training_sets, eval_sets, batch_size=16, eval_batch_size=1, dataloader_threads=8,
+                    drop_last_training_batch=False, **common):
+    """TOML [data] block -> (train DataLoader, val DataLoader).  ref: training/data_setup.py:9-125"""
+    common = {k: v for k, v in common.items() if k in ('scale', 'input', 'colorspace')}
+
+    def setup(ds, split):
+        custom = None
+        if ds.get('cutoff') is not None:
+            custom = ds['cutoff'] if isinstance(ds['cutoff'], list) else (0, ds['cutoff'])
+        elif ds.get('name') is None:
+            split = 'all'
+        meta_file = ds.get('degradation_metadata') or ds.get('qpi_values')
+        if meta_file == 'on_site':
+            meta_file = os.path.join(ds['lr'], 'degradation_metadata.csv')
+            if not os.path.isfile(meta_file):
+                meta_file = os.path.join(ds['lr'], 'qpi_slices.csv')
+        extra = {k: ds.get(k) for k in ('online_degradations', 'image_shortlist', 'legacy_blur_kernels', 'request_crops',
+                                        'attribute_amplification')}
+        return SuperResImages(lr_dir=ds['lr'], hr_dir=ds.get('hr'), dataset=ds.get('name'), split=split,
+                              custom_split=custom, degradation_metadata_file=meta_file, metadata=ds.get('metadata'),
+                              random_crop=ds.get('crop'), random_augments=ds.get('random_augment'),
+                              recursive_search=bool(ds.get('recursive_search')), **extra, **common)
+
+    train = [setup(d, 'train') for d in training_sets.values()]
+    val = [setup(d, 'eval') for d in eval_sets.values()]
+    train = train[0] if len(train) == 1 else ConcatDataset(train)
+    val = val[0] if len(val) == 1 else ConcatDataset(val)
+    train_loader = DataLoader(dataset=train, batch_size=batch_size, shuffle=True, num_workers=dataloader_threads,
+                              pin_memory=torch.cuda.is_available(), drop_last=drop_last_training_batch)
+    return train_loader, DataLoader(dataset=val, batch_size=eval_batch_size)

@@ -1,0 +1,99 @@
+"""BASELINE config 0 through our own train entry point vs the reference's TrainingHandler (fixture G5).
+
+CPU variant: the handler's parameter holders are driven by the ORACLE forward (test-only monkeypatch), which
+isolates everything around the kernels -- TOML plumbing, dataset ordering, Python/torch RNG call order,
+collation, Adam/scheduler, Y-PSNR validation, summary.csv, checkpoints -- and pins it to the reference run.
+GPU variant (pytest -m gpu): the same experiment on the HIP kernels.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sisr_amd
+from conftest import GOLDEN, golden_json
+from oracle import sisr_oracle as O
+
+
+def _config(name, tmp_path):
+    cfg = copy.deepcopy(golden_json("g5_train_sisr")[name]["config"])
+    cfg["experiment_save_loc"] = str(tmp_path)
+    for part in ("training_sets", "eval_sets"):
+        for d in cfg["data"][part].values():
+            d["lr"] = d["lr"].replace("SET5", os.path.join(GOLDEN, "set5"))
+            d["hr"] = d["hr"].replace("SET5", os.path.join(GOLDEN, "set5"))
+    return cfg
+
+
+def _oracle_drive(handler, name):
+    net = handler.net
+    cfg = dict(num_blocks=2, scale=4, res_scale=0.1)
+    if name == "qedsr":
+        cfg["q_layer_nonlinearity"] = False
+        net.forward = lambda x, metadata=None: O.qedsr(dict(net.state_dict(keep_vars=True)), x, metadata, **cfg)
+    else:
+        net.forward = lambda x: O.edsr(dict(net.state_dict(keep_vars=True)), x, **cfg)
+    handler.criterion = torch.nn.L1Loss()
+
+
+@pytest.mark.parametrize("name", ["edsr", "qedsr"])
+def test_train_loop_matches_reference_with_oracle_net(name, tmp_path, monkeypatch):
+    ref = golden_json("g5_train_sisr")[name]["summary"]
+    cfg = _config(name, tmp_path)
+    real_init = sisr_amd.cli.ModelInterface.__init__
+
+    def patched(self, *a, **k):
+        real_init(self, *a, **k)
+        _oracle_drive(self.model, name)
+    monkeypatch.setattr(sisr_amd.cli.ModelInterface, "__init__", patched)
+    total = sisr_amd.cli.train_sisr(cfg)
+    for key in ("train-loss", "val-loss", "val-PSNR", "learning-rate"):
+        np.testing.assert_allclose(total[key], ref[key], rtol=2e-5, atol=2e-6, err_msg=key)
+    assert list(total["epoch"]) == [0, 1]
+    exp = os.path.join(str(tmp_path), cfg["experiment"])
+    assert os.path.isfile(os.path.join(exp, "config.toml"))
+    assert os.path.isfile(os.path.join(exp, "result_outputs", "summary.csv"))
+    assert os.path.isfile(os.path.join(exp, "saved_models", "train_model_1"))
+    # overwrite guard (ref: models/__init__.py:175-179)
+    with pytest.raises(RuntimeError, match="overwriting existing data"):
+        sisr_amd.cli.train_sisr(_config(name, tmp_path))
+
+
+def test_batch_dict_schema():
+    d = os.path.join(GOLDEN, "set5")
+    ds = sisr_amd.data.SuperResImages(os.path.join(d, "lr_random_blur"), os.path.join(d, "hr"), split="all", scale=4,
+                                      degradation_metadata_file=os.path.join(d, "lr_random_blur", "degradation_metadata.csv"),
+                                      random_crop=16, random_augments=True)
+    assert len(ds) == 5 and ds.metadata_keys == ["blur_kernel"] * 10
+    loader = torch.utils.data.DataLoader(ds, batch_size=2)
+    b = next(iter(loader))
+    assert set(b) == {"lr", "hr", "tag", "hr_tag", "mask", "halfway_data", "metadata", "metadata_keys", "blur_kernels"}
+    assert b["lr"].shape == (2, 3, 16, 16) and b["hr"].shape == (2, 3, 64, 64) and b["lr"].dtype == torch.float32
+    assert b["metadata"].dtype == torch.float64 and b["metadata"].shape == (2, 10)
+    assert len(b["metadata_keys"]) == 10 and b["metadata_keys"][0] == ("blur_kernel", "blur_kernel")
+    assert b["tag"] == ["baby.png", "bird.png"]
+    with pytest.raises(NotImplementedError):
+        sisr_amd.data.SuperResImages(os.path.join(d, "lr_random_blur"), os.path.join(d, "hr"), split="all",
+                                     online_degradations=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["edsr", "qedsr"])
+def test_train_and_eval_entry_points_on_hip(name, tmp_path):
+    ref = golden_json("g5_train_sisr")[name]["summary"]
+    cfg = _config(name, tmp_path)
+    cfg["training"]["gpu"] = "single"
+    cfg["training"]["sp_gpu"] = 0
+    total = sisr_amd.cli.train_sisr(cfg)
+    np.testing.assert_allclose(total["train-loss"], ref["train-loss"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(total["val-loss"], ref["val-loss"], rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(total["val-PSNR"], ref["val-PSNR"], rtol=0, atol=5e-3)  # dB
+    # eval_sisr on the epoch-1 checkpoint reproduces the last validation PSNR
+    d = os.path.join(GOLDEN, "set5")
+    df, avg = sisr_amd.cli.eval_sisr(model_and_epoch=[[cfg["experiment"], "1"]], model_loc=str(tmp_path), gpu=True,
+                                     hr_dir=os.path.join(d, "hr"), lr_dir=os.path.join(d, "lr_random_blur"),
+                                     full_directory=True, scale=4, out_loc=str(tmp_path), results_name="ev")
+    assert len(df) == 5 and abs(float(avg["PSNR"].iloc[0]) - ref["val-PSNR"][1]) < 5e-3
+    assert os.path.isfile(os.path.join(str(tmp_path), "ev", "standard_metrics", "average_metrics.csv"))

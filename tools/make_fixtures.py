@@ -345,3 +345,47 @@ if __name__ == "__main__":
                     ("g7", make_g7)):
         if tag in which:
             fn()
+
+
+def make_g5():
+    """BASELINE config 0: the reference's own train loop (TrainingHandler) on the Set5 example data, CPU, EDSR."""
+    import random
+    import tempfile
+    from collections import defaultdict
+    import pandas as pd
+    from SISR.training.training_handler import TrainingHandler
+    from sr_tools.helper_functions import convert_default_none_dict
+    tmp = tempfile.mkdtemp()
+    ds = {"name": None, "lr": os.path.join(SET5, "lr_random_blur"), "hr": os.path.join(SET5, "hr"),
+          "degradation_metadata": "on_site", "metadata": ["blur_kernel"]}
+    out = {}
+    for model_name, internal in (("edsr", {"scale": 4, "lr": 1e-4, "num_blocks": 2}),
+                                 ("qedsr", {"scale": 4, "lr": 1e-4, "num_blocks": 2, "metadata": ["blur_kernel"]})):
+        params = {
+            "experiment": "g5_" + model_name, "experiment_save_loc": tmp,
+            "data": {"batch_size": 2, "dataloader_threads": 0,
+                     "training_sets": {"data_1": dict(ds, crop=32, random_augment=True)},
+                     "eval_sets": {"data_1": dict(ds)}},
+            "model": {"name": model_name, "internal_params": dict(internal)},
+            "training": {"gpu": "off", "seed": 8, "num_epochs": 2, "metrics": ["PSNR"], "logging": "text",
+                         "save_samples": False},
+        }
+        cfg = json.loads(json.dumps(params))
+        p = convert_default_none_dict(params)
+        exp = TrainingHandler(experiment_name=p["experiment"], save_loc=p["experiment_save_loc"],
+                              model_params=p["model"], **p["training"], data_params={**p["data"]})
+        exp.run_experiment()
+        summ = pd.read_csv(os.path.join(exp.model.logs, "summary.csv"))
+        out[model_name] = {"config": cfg, "summary": {k: [float(v) for v in summ[k]] for k in summ.columns}}
+        print("g5", model_name, out[model_name]["summary"])
+    for m in out.values():  # paths in the stored config are rewritten by the tests
+        for part in ("training_sets", "eval_sets"):
+            for d in m["config"]["data"][part].values():
+                d["lr"], d["hr"] = "SET5/lr_random_blur", "SET5/hr"
+        m["config"]["experiment_save_loc"] = "TMP"
+    with open(os.path.join(OUT, "g5_train_sisr.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__" and "g5" in sys.argv[1:]:
+    make_g5()
