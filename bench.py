@@ -116,6 +116,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}")
+    if os.environ.get("SISR_BENCH_SHARE_GPU"):  # rehearsal on a 1-GPU box: every rank on cuda:0 (gloo backend)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     name, params, tflop_per_patch = WORKLOADS[args.workload]

@@ -44,6 +44,7 @@ struct ConvParams {
   float alpha;
   int bias_n, bias_q;
   int B, H, W, cin_chunks, cout_chunks, relu, tiles_w, tiles_h;
+  int stagger;  // first-round workgroups sharing a CU start (slot * stagger) * ~3.5 us apart (0 = off)
 };
 
 // Variants (A/B-able in one process through sisr_conv3x3_c64_set_variant; the default is the fastest measured):
@@ -55,6 +56,7 @@ template <int V>
 __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(ConvParams p) {
   constexpr int PSTR = (V == 2) ? 64 : 68;
   constexpr int AD = (V == 0) ? 1 : 2;  // A prefetch distance in K-steps
+  constexpr int BD = (V == 2) ? 6 : 4;  // B prefetch distance in K-steps (8-slot ring)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -78,6 +80,15 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
   const int H = p.H, W = p.W;
 
   f32x16 acc0 = {0}, acc1 = {0};
+
+  // All workgroups do identical work, so the three that share a CU would otherwise run in lockstep and
+  // their halo-load / store phases would coincide instead of hiding under each other's MFMA phase.
+  // First-round waves start (hardware wave slot on their SIMD) x stagger apart; the slot id comes from
+  // HW_REG_HW_ID[3:0], so co-resident waves always differ whatever the block -> CU placement is.  Speed only.
+  if (p.stagger > 0 && blockIdx.y == 0 && blockIdx.x < 768) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3;  // size 4, offset 0, HW_ID
+    for (unsigned k = 0; k < slot * p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+  }
 
   for (int c = 0; c < p.cin_chunks; ++c) {
     if (c) __syncthreads();  // previous chunk's A reads are done before the halo is overwritten
@@ -127,15 +138,15 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
     auto load_b = [&](int s) -> f32x4 {  // K-step s = tap*8 + j; clamped so the run-ahead never leaves the buffer
       return *reinterpret_cast<const f32x4*>(wq + min(s, 71) * 512);
     };
-    // Software pipeline over K-steps s = tap*8 + j (8 MFMAs each): B (global/L2) four steps ahead in an
-    // 8-slot ring, A (LDS) AD steps ahead in a 4-slot ring; both ring indices depend on j only, so the tap
+    // Software pipeline over K-steps s = tap*8 + j (8 MFMAs each): B (global/L2) BD steps ahead in an
+    // 8-slot ring (BD steps), A (LDS) AD steps ahead in a 4-slot ring; both ring indices depend on j only, so the tap
     // loop stays rolled (64-MFMA body, addresses recomputed per tap instead of 144 live address registers).
     // sched_barrier(0) after every step keeps hipcc from sinking the prefetches down to their first use
     // (it otherwise emits load; s_waitcnt 0; mfma).
     f32x4 bq[8];
     f32x4 aq[4][2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bq[s] = load_b(s);
+    for (int s = 0; s < BD; ++s) bq[s] = load_b(s);
 #pragma unroll
     for (int s = 0; s < AD; ++s) {
       aq[s][0] = load_a(0, 0, s);
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
       const int tnext = min(tap + 1, 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        bq[(j + 4) & 7] = load_b(tap * 8 + j + 4);
+        bq[(j + BD) & 7] = load_b(tap * 8 + j + BD);
         {
           const int ja = j + AD;  // step s + AD: same tap while ja < 8, else the next tap's first octets
           aq[ja & 3][0] = load_a(0, ja < 8 ? tap : tnext, ja & 7);
@@ -302,6 +313,12 @@ extern "C" int sisr_pack_conv3x3_both(const float* w, float* packed_fwd, float* 
 
 // Tuning knob (process-wide, read-only during launches): which conv3x3_c64 variant to run.
 static int g_conv_variant = 2;
+static int g_conv_stagger = 0;  // measured: no gain once clocks are warm (profiles/r01 notes)
+extern "C" int sisr_conv3x3_c64_set_stagger(int units) {
+  if (units < 0 || units > 64) return SISR_ERR_ARG;
+  g_conv_stagger = units;
+  return SISR_OK;
+}
 extern "C" int sisr_conv3x3_c64_set_variant(int v) {
   if (v < 0 || v > 2) return SISR_ERR_ARG;
   g_conv_variant = v;
@@ -344,6 +361,7 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   p.relu = relu;
   p.tiles_w = (W + TW - 1) / TW;
   p.tiles_h = (H + TH - 1) / TH;
+  p.stagger = g_conv_stagger;
   const long nblk = (long)p.tiles_w * p.tiles_h * B;
   if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
   const dim3 grid((unsigned)nblk, p.cout_chunks);

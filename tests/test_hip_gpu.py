@@ -338,3 +338,22 @@ def test_native_library_is_loaded():
     """The tests above ran on libsisr_hip.so, not on a fallback."""
     with open("/proc/self/maps") as f:
         assert "libsisr_hip.so" in f.read()
+
+
+def test_two_ranks_share_one_gpu_grad_reducer(tmp_path):
+    """Rehearsal of the multi-GPU bench on a 1-GPU box: two processes on cuda:0, gloo transport, so the
+    side-stream / hook logic of GradReducer runs on HIP tensors; losses must agree with a 1-process run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SISR_DIST_BACKEND="gloo", SISR_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29731", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch", "2", "--workload", "edsr", "--no-kernel-timing"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["value"] > 0
+    assert np.isfinite(line["config"]["final_loss"])
