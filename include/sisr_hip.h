@@ -132,6 +132,9 @@ int sisr_l1_loss(const float* a, const float* b, long n, float* loss, float* gra
 int sisr_adam_flat(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
                    float step_size, float inv_bc2_sqrt, float grad_scale, void* stream);
 
+/* ---- diagnostics (not on the product path): sustained fp32-MFMA rate and in-kernel clock ---------- */
+int sisr_diag_mfma_peak(int blocks, int iters, float* out, unsigned long long* clk, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,7 +52,11 @@ struct ConvParams {
 //   1  as 0 with A fragments two steps ahead
 //   2  XOR-swizzled LDS (64-float stride: 16-B chunk k of halo pixel p lives at slot k ^ (p & 15)),
 //      52 KB per workgroup so THREE workgroups fit a CU (register budget 168), A two steps ahead
-template <int V>
+// ABL (diagnostic builds only, selected with variant ids 10+): 1 no B loads, 2 no A reads, 3 neither,
+// 4 no halo staging loads, 5 no epilogue stores, 6 phase stamps (s_memtime at start / after staging / after
+// the K loop / at the end, written per workgroup into the gap buffer as uint32 cycles).  Outputs of ablated
+// builds are meaningless.
+template <int V, int ABL = 0, bool PRIO = true>
 __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(ConvParams p) {
   constexpr int PSTR = (V == 2) ? 64 : 68;
   constexpr int AD = (V == 0) ? 1 : 2;  // A prefetch distance in K-steps
@@ -80,6 +84,8 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
   const int H = p.H, W = p.W;
 
   f32x16 acc0 = {0}, acc1 = {0};
+  unsigned long long st0 = 0, st1 = 0, st2 = 0;
+  if (ABL == 6) st0 = __builtin_amdgcn_s_memtime();
 
   // All workgroups do identical work, so the three that share a CU would otherwise run in lockstep and
   // their halo-load / store phases would coincide instead of hiding under each other's MFMA phase.
@@ -90,8 +96,17 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
     for (unsigned k = 0; k < slot * p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
   }
 
+  // Issue priority.  Measured with in-kernel stamps (tools/conv_phases.py): while the other two waves of a
+  // SIMD stream fp32 MFMAs, a wave in its staging or store phase got roughly one VALU/VMEM issue slot per
+  // MFMA and those phases took 49k + 28k cycles of a 130k-cycle workgroup lifetime (K loop: 53k), leaving
+  // the matrix pipe idle ~20 % of the time.  Raising the priority of the short non-MFMA phases lets them
+  // take the issue slots between the older waves' MFMAs (separate pipes) and get out of the way.
+  if (V == 2 && PRIO) __builtin_amdgcn_s_setprio(3);
   for (int c = 0; c < p.cin_chunks; ++c) {
-    if (c) __syncthreads();  // previous chunk's A reads are done before the halo is overwritten
+    if (c) {
+      __syncthreads();  // previous chunk's A reads are done before the halo is overwritten
+      if (V == 2 && PRIO) __builtin_amdgcn_s_setprio(3);
+    }
     // ---- stage the halo of input chunk c: global -> VGPR -> LDS (16 lanes x 16 B per pixel)
     {
       // Branch-free: out-of-image taps load a clamped (valid) address and are zeroed by a select, so
@@ -113,7 +128,8 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
         const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
         const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
         const int ch_ = min(max(gh, 0), H - 1), cw_ = min(max(gw, 0), W - 1);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(xb + (long)ch_ * p.xv.sH + (long)cw_ * p.xv.sW + c4 * 4);
+        f32x4 t = {1.f, 2.f, 3.f, 4.f};
+        if (ABL != 4) t = *reinterpret_cast<const f32x4*>(xb + (long)ch_ * p.xv.sH + (long)cw_ * p.xv.sW + c4 * 4);
         v[it] = sisr_keep_if(t * s4 + t4, ok);  // zero padding stays zero: the affine is for in-image pixels only
       }
 #pragma unroll
@@ -125,6 +141,8 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
       }
     }
     __syncthreads();
+    if (V == 2 && PRIO) __builtin_amdgcn_s_setprio(0);
+    if (ABL == 6) st1 = __builtin_amdgcn_s_memtime();
 
     // ---- 72 K-steps (9 taps x 8 octets of input channels), 8 MFMAs each
     const float* wq = p.w + ((long)q * p.cin_chunks + c) * (9 * 64 * 64) + hh * 256 + (ch * 32 + n) * 4;
@@ -133,9 +151,11 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
     auto load_a = [&](int m, int t, int j) -> f32x4 {
       const int pix = pix0 + (t / 3 + m) * HALO_W + (t % 3);
       const int slot = (V == 2) ? ((2 * j + hh) ^ (pix & 15)) : (2 * j + hh);
+      if (ABL == 2 || ABL == 3) return (f32x4){(float)pix, 1.f, (float)slot, 2.f};
       return *reinterpret_cast<const f32x4*>(lds + pix * PSTR + slot * 4);
     };
     auto load_b = [&](int s) -> f32x4 {  // K-step s = tap*8 + j; clamped so the run-ahead never leaves the buffer
+      if (ABL == 1 || ABL == 3) return (f32x4){(float)s, 1.f, (float)hh, 3.f};
       return *reinterpret_cast<const f32x4*>(wq + min(s, 71) * 512);
     };
     // Software pipeline over K-steps s = tap*8 + j (8 MFMAs each): B (global/L2) BD steps ahead in an
@@ -177,6 +197,8 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
     }
   }
 
+  if (ABL == 6) st2 = __builtin_amdgcn_s_memtime();
+  if (V == 2 && PRIO) __builtin_amdgcn_s_setprio(3);
   // ---- epilogue.  C/D map of the 32x32 tile: column (= output channel) on the lane, pixel
   // (r&3) + 8*(r>>2) + 4*(lane>>5) in register r.
   const int co = ch * 32 + n;
@@ -200,8 +222,201 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
         const long off = ybase + (long)row * p.yv.sH + (long)col * p.yv.sW;
         if (p.mask) v = p.mask[off] > 0.f ? v : 0.f;
         if (p.res) v += p.res[off];
-        p.y[off] = v;
+        if (ABL != 5) p.y[off] = v;
         gsum += v;
+      }
+    }
+  }
+  if (ABL == 6) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && p.gap) {
+      unsigned* dbg = reinterpret_cast<unsigned*>(p.gap) + ((long)blockIdx.x * 4 + wave) * 4;
+      dbg[0] = (unsigned)(st1 - st0);
+      dbg[1] = (unsigned)(st2 - st1);
+      dbg[2] = (unsigned)(st3 - st2);
+      dbg[3] = (unsigned)(st0 & 0xffffffffu);
+    }
+    return;
+  }
+  if (p.gap) {
+    gsum += __shfl_xor(gsum, 32);
+    if (hh == 0) {
+      const int tile = th * p.tiles_w + tw;
+      const long parts = (long)p.tiles_w * p.tiles_h * 2;
+      p.gap[(((long)b * parts) + tile * 2 + ph) * Cout + q * 64 + co] = gsum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ issue-lean kernel ("v4")
+// In-kernel stamps and the pure-MFMA ceiling (tools/conv_phases.py, tools/mfma_peak.py) showed that the fp32
+// MFMA holds its SIMD's issue port for the whole 64 cycles: every other instruction a co-resident wave
+// issues is paid on top, so throughput = 64 / (64 + 4 * non-MFMA instructions per MFMA).  conv3x3_c64_kernel
+// spent ~4.6 such instructions per MFMA (82 % ceiling).  This variant keeps the same tile / wave / LDS
+// geometry and cuts them to ~1.3:
+//   * halo staging walks (row, 16-column block) pairs: row base is scalar, the lane's column offset is one
+//     of three precomputed VGPRs -> one global_load (saddr+voffset) + one mask op + one ds_write per item;
+//   * the LDS swizzle uses the halo COLUMN (slot = chunk ^ (col & 15)), so the 24 (kw, octet) A addresses
+//     are lane constants computed once; tap row and M-tile enter as ds_read immediates (fully unrolled K loop);
+//   * B fragments: scalar base + one lane offset VGPR + immediate;
+//   * bias is the accumulator's initial value; stores use scalar row/column bases + one lane offset; interior
+//     tiles take a predicate-free path.
+// Covers the block-hot combinations (plain/ReLU/scale, +GAP, +residual, +mask, +mask+affine prologue); anything
+// else is routed to conv3x3_c64_kernel.  Results are bit-identical to it (same MFMA order).
+template <bool AFFINE, bool MASK, bool RES>
+__global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = blockIdx.y;
+  int bid;
+  {
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const unsigned qn = nb >> 3, rn = nb & 7;
+    bid = (int)((xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx);
+  }
+  const int tw = bid % p.tiles_w;
+  bid /= p.tiles_w;
+  const int th = bid % p.tiles_h;
+  const int b = bid / p.tiles_h;
+  const int h0 = th * TH, w0 = tw * TW;
+  const int ph = __builtin_amdgcn_readfirstlane(wave >> 1), ch = __builtin_amdgcn_readfirstlane(wave & 1);
+  const int n = lane & 31, hh = lane >> 5;
+  const int H = p.H, W = p.W;
+  const int co = ch * 32 + n;
+  const int Cout = p.cout_chunks * 64;
+
+  const float bv = p.bias ? p.bias[co * p.bias_n + q * p.bias_q] : 0.f;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = bv;
+
+  // lane constants for the A reads: float offset of (halo row 2ph, col n+kw, slot (2j+hh)^((n+kw)&15))
+  unsigned aoff[3][8];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      aoff[kw][j] = ((2 * ph) * HALO_W + n + kw) * 64 + (((2 * j + hh) ^ ((n + kw) & 15)) << 2);
+  const unsigned boff = hh * 256 + co * 4;
+
+  for (int c = 0; c < p.cin_chunks; ++c) {
+    if (c) __syncthreads();
+    {  // ---- halo staging: thread = (chunk c4, column pcol + {0,16,32}), rows 0..5
+      int tl = tid;
+      asm volatile("" : "+v"(tl));  // keep the per-chunk address math out of the K loop's live ranges
+      const int c4 = tl & 15, pcol = tl >> 4;
+      const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(c);
+      f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+      if (AFFINE) {
+        s4 = *reinterpret_cast<const f32x4*>(p.in_scale + ((long)b * p.cin_chunks + c) * 64 + c4 * 4);
+        if (p.in_shift) t4 = *reinterpret_cast<const f32x4*>(p.in_shift + ((long)b * p.cin_chunks + c) * 64 + c4 * 4);
+      }
+      unsigned goff[3], loff[3];
+      bool cok[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int col = pcol + 16 * k;
+        const int gw = w0 - 1 + col;
+        cok[k] = gw >= 0 && gw < W && col < HALO_W;
+        goff[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c4 * 4);
+        loff[k] = col * 64 + ((c4 ^ (col & 15)) << 2);
+      }
+      f32x4 v[HALO_H][3];
+#pragma unroll
+      for (int r = 0; r < HALO_H; ++r) {
+        const int gh = h0 - 1 + r;
+        const float* xrow = xb + (long)min(max(gh, 0), H - 1) * p.xv.sH;  // scalar
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < 2 || pcol < 2) v[r][k] = *reinterpret_cast<const f32x4*>(xrow + goff[k]);
+      }
+#pragma unroll
+      for (int r = 0; r < HALO_H; ++r) {
+        const int gh = h0 - 1 + r;
+        const bool rok = gh >= 0 && gh < H;  // scalar
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < 2 || pcol < 2) {
+            f32x4 t = v[r][k];
+            if (AFFINE) t = t * s4 + t4;
+            *reinterpret_cast<f32x4*>(lds + r * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
+          }
+      }
+    }
+    __syncthreads();
+
+    // ---- K loop, fully unrolled: 72 steps x 8 MFMAs; every address is lane constant + immediate
+    const float* wq = p.w + ((long)q * p.cin_chunks + c) * (9 * 64 * 64);  // scalar
+#define V4_LOAD_B(s) (*reinterpret_cast<const f32x4*>(wq + (s) * 512 + boff))
+#define V4_LOAD_A(m, s) \
+  (*reinterpret_cast<const f32x4*>(lds + ((((s) >> 3) / 3 + (m)) * (HALO_W * 64)) + aoff[((s) >> 3) % 3][(s) & 7]))
+    f32x4 bq[8];
+    f32x4 aq[4][2];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) bq[s] = V4_LOAD_B(s);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      aq[s][0] = V4_LOAD_A(0, s);
+      aq[s][1] = V4_LOAD_A(1, s);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 72; ++s) {
+      if (s + 6 < 72) bq[(s + 6) & 7] = V4_LOAD_B(s + 6);
+      if (s + 2 < 72) {
+        aq[(s + 2) & 3][0] = V4_LOAD_A(0, s + 2);
+        aq[(s + 2) & 3][1] = V4_LOAD_A(1, s + 2);
+      }
+      const f32x4 bb = bq[s & 7];
+      const f32x4 a0 = aq[s & 3][0];
+      const f32x4 a1 = aq[s & 3][1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bb[e], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bb[e], acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef V4_LOAD_A
+#undef V4_LOAD_B
+  }
+
+  // ---- epilogue
+  float os = p.alpha;
+  if (p.out_scale) os *= p.out_scale[(long)b * Cout + q * 64 + co];
+  const float lo = p.relu ? 0.f : -3.402823466e38f;
+  const unsigned loff_y = (unsigned)(co + 4 * hh * (int)p.yv.sW);  // lane part of every output address
+  const long tile_base = (long)b * p.yv.sB + p.yv.chunk(q) + (long)w0 * p.yv.sW;  // scalar
+  const bool full = (h0 + TH <= H) && (w0 + TW <= W);                              // scalar
+  float gsum = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int row = h0 + 2 * ph + m;
+    const f32x16 acc = m ? acc1 : acc0;
+    const long row_base = tile_base + (long)row * p.yv.sH;  // scalar
+    if (full) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long off = row_base + (long)((r & 3) + 8 * (r >> 2)) * p.yv.sW;  // scalar
+        float v = fmaxf(acc[r], lo) * os;
+        if (MASK) v = (p.mask + off)[loff_y] > 0.f ? v : 0.f;
+        if (RES) v += (p.res + off)[loff_y];
+        (p.y + off)[loff_y] = v;
+        gsum += v;
+      }
+    } else if (row < H) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cr = (r & 3) + 8 * (r >> 2);
+        if (w0 + cr + 4 * hh < W) {
+          const long off = row_base + (long)cr * p.yv.sW;
+          float v = fmaxf(acc[r], lo) * os;
+          if (MASK) v = (p.mask + off)[loff_y] > 0.f ? v : 0.f;
+          if (RES) v += (p.res + off)[loff_y];
+          (p.y + off)[loff_y] = v;
+          gsum += v;
+        }
       }
     }
   }
@@ -312,7 +527,7 @@ extern "C" int sisr_pack_conv3x3_both(const float* w, float* packed_fwd, float* 
 }
 
 // Tuning knob (process-wide, read-only during launches): which conv3x3_c64 variant to run.
-static int g_conv_variant = 2;
+static int g_conv_variant = 4;
 static int g_conv_stagger = 0;  // measured: no gain once clocks are warm (profiles/r01 notes)
 extern "C" int sisr_conv3x3_c64_set_stagger(int units) {
   if (units < 0 || units > 64) return SISR_ERR_ARG;
@@ -320,7 +535,7 @@ extern "C" int sisr_conv3x3_c64_set_stagger(int units) {
   return SISR_OK;
 }
 extern "C" int sisr_conv3x3_c64_set_variant(int v) {
-  if (v < 0 || v > 2) return SISR_ERR_ARG;
+  if (!((v >= 0 && v <= 4) || (v >= 11 && v <= 17))) return SISR_ERR_ARG;
   g_conv_variant = v;
   return SISR_OK;
 }
@@ -365,6 +580,24 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   const long nblk = (long)p.tiles_w * p.tiles_h * B;
   if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
   const dim3 grid((unsigned)nblk, p.cout_chunks);
+  if (g_conv_variant == 4) {
+    const bool aff = in_scale != nullptr, msk = mask != nullptr, rs = res != nullptr;
+    const size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (!(in_shift && !in_scale) && !(aff && !msk) && !(msk && rs)) {
+      if (aff)
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false>), grid, dim3(256), lb, st, p);
+      else if (msk)
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, true, false>), grid, dim3(256), lb, st, p);
+      else if (rs)
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, true>), grid, dim3(256), lb, st, p);
+      else
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false>), grid, dim3(256), lb, st, p);
+      return sisr_check_launch();
+    }
+    hipLaunchKernelGGL(conv3x3_c64_kernel<2>, grid, dim3(256), lb, st, p);
+    return sisr_check_launch();
+  }
   switch (g_conv_variant) {
     case 0:
       hipLaunchKernelGGL(conv3x3_c64_kernel<0>, grid, dim3(256), HALO_H * HALO_W * 68 * sizeof(float),
@@ -374,6 +607,14 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
       hipLaunchKernelGGL(conv3x3_c64_kernel<1>, grid, dim3(256), HALO_H * HALO_W * 68 * sizeof(float),
                          (hipStream_t)stream, p);
       break;
+    case 11: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 1>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
+    case 12: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 2>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
+    case 13: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 3>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
+    case 14: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 4>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
+    case 3: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 0, false>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
+    case 17: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 6, false>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
+    case 16: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 6>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
+    case 15: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 5>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
     default:
       hipLaunchKernelGGL(conv3x3_c64_kernel<2>, grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float),
                          (hipStream_t)stream, p);

@@ -79,52 +79,61 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) {
     const int th = tr / p.tiles_w, tw = tr - th * p.tiles_w;
     const int h0 = th * WT_H, w0 = tw * WT_W;
     __syncthreads();  // previous tile fully consumed
-    {  // branch-free staging: clamped address + select (all loads of a thread in flight together)
+    {  // Issue-lean staging (the fp32 MFMA owns the SIMD's issue port for its 64 cycles, so every staging
+       // instruction of this wave is paid on top of the co-resident waves' MFMAs): thread = (chunk c4, column
+       // pcol [+32]); rows are walked with a scalar row base, so an item is one global_load (scalar base + lane
+       // offset), one mask op and one ds_write.  Loads go in batches (144 accumulator VGPRs are live).
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
+      const int c4 = tl & 7, pcol = tl >> 3;
       const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(cc) + cih * 32;
-      const int c4 = tid & 7;  // constant per thread: both item strides (256) are multiples of 8
-      // 144 accumulator VGPRs are live here, so the loads go in batches of <= 6 float4 (24 VGPRs)
+      unsigned gx[2], lx[2];
+      bool okx[2];
 #pragma unroll
-      for (int base = 0; base < X_ITERS; base += 6) {
-        f32x4 v[6];
+      for (int k = 0; k < 2; ++k) {
+        const int col = pcol + 32 * k;
+        const int gw = w0 - 1 + col;
+        okx[k] = gw >= 0 && gw < W && col < WH_W;
+        gx[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c4 * 4);
+        lx[k] = col * WSTR + c4 * 4;
+      }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const int it = base + k;
-          if (it < X_ITERS) {
-            const int pix = (it * 256 + tid) >> 3;
-            const int pr = pix / WH_W, pc = pix - pr * WH_W;
-            const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
-            const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
-            const int ch_ = min(max(gh, 0), H - 1), cw_ = min(max(gw, 0), W - 1);
-            const f32x4 t = *reinterpret_cast<const f32x4*>(xb + (long)ch_ * p.xv.sH + (long)cw_ * p.xv.sW + c4 * 4);
-            v[k] = sisr_keep_if(t, ok);
-          }
+      for (int r0 = 0; r0 < WH_H; r0 += 5) {
+        f32x4 v[5][2];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const float* xrow = xb + (long)min(max(h0 - 1 + r0 + r, 0), H - 1) * p.xv.sH;  // scalar
+          v[r][0] = *reinterpret_cast<const f32x4*>(xrow + gx[0]);
+          if (pcol < 2) v[r][1] = *reinterpret_cast<const f32x4*>(xrow + gx[1]);
         }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const int idx = (base + k) * 256 + tid;
-          if (base + k < X_ITERS && idx < X_ITEMS) *reinterpret_cast<f32x4*>(ldx + (idx >> 3) * WSTR + c4 * 4) = v[k];
+        for (int r = 0; r < 5; ++r) {
+          const int gh = h0 - 1 + r0 + r;
+          const bool rok = gh >= 0 && gh < H;  // scalar
+          *reinterpret_cast<f32x4*>(ldx + (r0 + r) * (WH_W * WSTR) + lx[0]) = sisr_keep_if(v[r][0], rok && okx[0]);
+          if (pcol < 2)
+            *reinterpret_cast<f32x4*>(ldx + (r0 + r) * (WH_W * WSTR) + lx[1]) = sisr_keep_if(v[r][1], rok && okx[1]);
         }
       }
       const float* yb = p.dy + (long)b * p.yv.sB + p.yv.chunk(cq) + coh * 32;
       f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
       if (p.dy_scale) s4 = *reinterpret_cast<const f32x4*>(p.dy_scale + (long)b * Cout + cq * 64 + coh * 32 + c4 * 4);
       if (p.dy_shift) t4 = *reinterpret_cast<const f32x4*>(p.dy_shift + (long)b * Cout + cq * 64 + coh * 32 + c4 * 4);
+      const int gwy = w0 + pcol;
+      const bool oky = gwy < W;
+      const unsigned gy = (unsigned)(min(gwy, W - 1) * (int)p.yv.sW + c4 * 4);
+      const unsigned ly = pcol * WSTR + c4 * 4;
 #pragma unroll
-      for (int base = 0; base < Y_ITERS; base += 4) {
+      for (int r0 = 0; r0 < WT_H; r0 += 4) {
         f32x4 u[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int pix = ((base + k) * 256 + tid) >> 3;
-          const int gh = h0 + (pix >> 5), gw = w0 + (pix & 31);
-          const bool ok = gh < H && gw < W;
-          const int ch_ = min(gh, H - 1), cw_ = min(gw, W - 1);
-          const f32x4 t = *reinterpret_cast<const f32x4*>(yb + (long)ch_ * p.yv.sH + (long)cw_ * p.yv.sW + c4 * 4);
-          u[k] = sisr_keep_if(t * s4 + t4, ok);
-        }
+        for (int r = 0; r < 4; ++r)
+          u[r] = *reinterpret_cast<const f32x4*>(yb + (long)min(h0 + r0 + r, H - 1) * p.yv.sH + gy);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          *reinterpret_cast<f32x4*>(ldy + (((base + k) * 256 + tid) >> 3) * WSTR + c4 * 4) = u[k];
-          bsum += u[k];
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 t = sisr_keep_if(u[r] * s4 + t4, oky && (h0 + r0 + r < H));
+          *reinterpret_cast<f32x4*>(ldy + (r0 + r) * (WT_W * WSTR) + ly) = t;
+          bsum += t;
         }
       }
     }

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--variants", default="0,1,2")
     ap.add_argument("--stagger", default="")
+    ap.add_argument("--rounds", type=int, default=0, help="interleaved A/B rounds over --variants (conv only)")
     ap.add_argument("--wstagger", default="")
     a = ap.parse_args()
     only = set(a.only.split(",")) if a.only else None
@@ -70,12 +71,28 @@ def main():
         res[name] = {"us": t * 1e6, unit: work / t / (1e12 if unit == "TFLOP/s" else 1e9)}
         print(json.dumps({"kernel": name, "batch": B, **res[name]}), flush=True)
 
-    for var in [int(t) for t in a.variants.split(",")]:
-        hip.lib().sisr_conv3x3_c64_set_variant(var)
-        run(f"conv_v{var}", lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64), flop, "TFLOP/s")
-        run(f"conv_dgrad2_v{var}", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1,
-                                                        in_scale=sc, in_shift=sh), flop, "TFLOP/s")
-    hip.lib().sisr_conv3x3_c64_set_variant(int(a.variants.split(",")[-1]))
+    variants = [int(t) for t in a.variants.split(",")]
+    if a.rounds > 0 and (not only or "conv" in only):
+        # interleaved A/B (guide rule 24): rounds x variants in one process, median and min per variant
+        times = {var: [] for var in variants}
+        for _ in range(3):
+            ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64)
+        for r in range(a.rounds):
+            for var in variants:
+                hip.lib().sisr_conv3x3_c64_set_variant(var)
+                times[var].append(timeit(lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64), a.iters, warm=1))
+        for var in variants:
+            ts = sorted(times[var])
+            med, mn = ts[len(ts) // 2], ts[0]
+            print(json.dumps({"kernel": f"conv_v{var}", "batch": B, "median_us": med * 1e6, "min_us": mn * 1e6,
+                              "median_TFLOP/s": flop / med / 1e12, "best_TFLOP/s": flop / mn / 1e12}), flush=True)
+    else:
+        for var in variants:
+            hip.lib().sisr_conv3x3_c64_set_variant(var)
+            run(f"conv_v{var}", lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64), flop, "TFLOP/s")
+            run(f"conv_dgrad2_v{var}", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1,
+                                                            in_scale=sc, in_shift=sh), flop, "TFLOP/s")
+    hip.lib().sisr_conv3x3_c64_set_variant(4)
     for st in [int(t) for t in a.stagger.split(",") if t]:
         hip.lib().sisr_conv3x3_c64_set_stagger(st)
         run(f"conv_stagger{st}", lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64), flop, "TFLOP/s")
