@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void ca_gate_bwd_param_kernel(const float* __r
                                                                 float* __restrict__ dw1, float* __restrict__ db1,
                                                                 float* __restrict__ dw2, float* __restrict__ db2) {
   const int n = 64 * R;
-  for (int i = threadIdx.x; i < 2 * n + 64 + R; i += 256) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * n + 64 + R; i += gridDim.x * 256) {
     float acc = 0.f;
     if (i < n) {  // dw2[c][j] = sum_b dz2[b][c] * hid[b][j]
       const int c = i / R, j = i - c * R;
@@ -289,8 +289,9 @@ extern "C" int sisr_ca_gate_bwd(const float* dg_partial, int parts, int B, float
                      w2, hidden, hid, ca, mul, shift, dmul, dz2, dz1);
   int rc = sisr_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(ca_gate_bwd_param_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dz2, dz1, s, hid, B, hidden,
-                     dw1, db1, dw2, db2);
+  const int nout = 2 * 64 * hidden + 64 + hidden;
+  hipLaunchKernelGGL(ca_gate_bwd_param_kernel, dim3((nout + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz2, dz1, s,
+                     hid, B, hidden, dw1, db1, dw2, db2);
   return sisr_check_launch();
 }
 

@@ -266,34 +266,52 @@ struct Corr3Reduce {
   int blocks, chunks, flip, a_is_out;
 };
 
-// one thread per (chunk q, row k < 27, channel c) plus bias rows
-__global__ void corr3_reduce_kernel(Corr3Reduce p) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// blockDim (64, 4): x = output element within a 64-run, y = block-partial group (partials split 4 ways with 8
+// loads in flight, group sums added in group order).  Elements: chunks*27*64 weights, then the bias entries.
+__global__ __launch_bounds__(256) void corr3_reduce_kernel(Corr3Reduce p) {
+  __shared__ float red[4][64];
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int grp = threadIdx.y;
   const int per_chunk = 27 * 64;
   const int nw = p.chunks * per_chunk;
+  const long stride = (long)p.chunks * CORR_ROWS * 64;
+  long src = -1;
+  int j0 = i - nw;
+  if (i < nw) {
+    const int q = i / per_chunk, r = i - q * per_chunk;
+    src = (long)q * CORR_ROWS * 64 + r;  // r = k*64 + c
+  } else if (p.db) {
+    if (p.a_is_out) {
+      if (j0 < 3) src = (long)(28 + j0) * 64;  // sums of P: identical in every lane, take chunk 0 / c = 0
+    } else if (j0 < p.chunks * 64) {
+      src = (long)(j0 >> 6) * CORR_ROWS * 64 + 27 * 64 + (j0 & 63);
+    }
+  }
+  float s = 0.f;
+  if (src >= 0) {
+    int k = grp;
+    for (; k + 28 < p.blocks; k += 32) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = p.part[(long)(k + 4 * u) * stride + src];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; k < p.blocks; k += 4) s += p.part[(long)k * stride + src];
+  }
+  red[grp][threadIdx.x] = s;
+  __syncthreads();
+  if (grp != 0 || src < 0) return;
+  s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
   if (i < nw) {
     const int q = i / per_chunk, r = i - q * per_chunk;
     const int k = r >> 6, c = r & 63;
-    float s = 0.f;
-    for (int j = 0; j < p.blocks; ++j) s += p.part[((long)j * p.chunks + q) * CORR_ROWS * 64 + k * 64 + c];
     const int a = k / 9, t = k - a * 9;
-    const long ch = (long)q * 64 + c;
-    const long o = p.a_is_out ? a : ch, ii = p.a_is_out ? ch : a;
+    const long chn = (long)q * 64 + c;
+    const long o = p.a_is_out ? a : chn, ii = p.a_is_out ? chn : a;
     p.dw[o * p.so + ii * p.si + (p.flip ? 8 - t : t)] = s * p.alpha;
-  } else if (p.db) {
-    const int j0 = i - nw;
-    if (p.a_is_out) {  // bias over the 3-channel side: sums of P (identical in every lane; take chunk 0, c = 0)
-      if (j0 < 3) {
-        float s = 0.f;
-        for (int j = 0; j < p.blocks; ++j) s += p.part[((long)j * p.chunks) * CORR_ROWS * 64 + (28 + j0) * 64];
-        p.db[j0] = s * p.alpha;
-      }
-    } else if (j0 < p.chunks * 64) {
-      const int q = j0 >> 6, c = j0 & 63;
-      float s = 0.f;
-      for (int j = 0; j < p.blocks; ++j) s += p.part[((long)j * p.chunks + q) * CORR_ROWS * 64 + 27 * 64 + c];
-      p.db[j0] = s * p.alpha;
-    }
+  } else {
+    p.db[j0] = s * p.alpha;
   }
 }
 
@@ -397,6 +415,6 @@ extern "C" int sisr_corr3x3_c3(const float* P, const float* Q, const int64_t* qv
   r.flip = flip_taps;
   r.a_is_out = a_is_out;
   const int total = p.chunks * 27 * 64 + (dbias ? (a_is_out ? 3 : channels) : 0);
-  hipLaunchKernelGGL(corr3_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
+  hipLaunchKernelGGL(corr3_reduce_kernel, dim3((total + 63) / 64), dim3(64, 4), 0, (hipStream_t)stream, r);
   return sisr_check_launch();
 }

@@ -14,12 +14,54 @@ Operators
   ca_layer / gate_mul   stand-alone CALayer / x*gate (ref: advanced/architectures.py:13-32)
   l1_loss        nn.L1Loss(mean) (ref: SISR/models/__init__.py:268)
 """
+import os
+
 import torch
 from torch.autograd import Function
 
 from . import hip
 
 CL = torch.channels_last
+
+
+# ----------------------------------------------------------------------------- side stream for weight gradients
+# In a block's backward the weight-gradient kernels (wgrad2, wgrad1) do not feed the data-gradient chain
+# (dgrad2 -> dgrad1 -> previous block), so they are issued on a second HIP stream: the ramp-up and tail of
+# each ~170 us MFMA launch is then filled by workgroups of the other queue.  The main stream re-joins the side
+# stream once, at the end of the backward pass (autograd engine callback), before anything reads the grads.
+WGRAD_SIDE_STREAM = os.environ.get("SISR_WGRAD_SIDE_STREAM", "1") != "0"
+_side_streams = {}
+_join_pending = set()
+
+
+def side_stream(device, create=True):
+    s = _side_streams.get(device.index)
+    if s is None and create:
+        s = torch.cuda.Stream(device=device)
+        _side_streams[device.index] = s
+    return s
+
+
+def _join_side(device):
+    _join_pending.discard(device.index)
+    s = _side_streams.get(device.index)
+    if s is not None:
+        torch.cuda.current_stream(device).wait_stream(s)
+
+
+def _on_side(device, after_event, fn, tensors):
+    """Run fn() on the side stream once `after_event` (recorded on the main stream) has passed; keep the
+    caching allocator from recycling `tensors` before the side stream is done with them."""
+    side = side_stream(device)
+    with torch.cuda.stream(side):
+        side.wait_event(after_event)
+        fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
+    if device.index not in _join_pending:
+        _join_pending.add(device.index)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(device))
 
 
 def _cl(x):
@@ -335,18 +377,37 @@ class _ResBlock(Function):
                           "sisr_sum_partials")
                 scale = g
         # conv2 backward: dt2 = dy*scale + shift is rebuilt on load, never stored
+        dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
+        dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
+        side = WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False  # plain first-order backward only
+
+        def wgrad2():
+            wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, alpha=rs, dy_scale=scale, dy_shift=shift)
+
+        if side:
+            ev = torch.cuda.Event()
+            ev.record()
+            _on_side(dev, ev, wgrad2, (t1, dy, scale, shift, dw2, db2))
         dt1 = _empty_cl(B, 64, H, W, dev)
         conv_c64(dy, v, ctx.pd2, None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1, in_scale=scale, in_shift=shift,
                  alpha=rs)
-        dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
-        wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, alpha=rs, dy_scale=scale, dy_shift=shift)
+        if not side:
+            wgrad2()
+
+        def wgrad1():
+            wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64)
+
         # conv1 backward (+ skip connection gradient)
+        if side:
+            ev = torch.cuda.Event()
+            ev.record()
+            _on_side(dev, ev, wgrad1, (x, dt1, dw1, db1))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _empty_cl(B, 64, H, W, dev)
             conv_c64(dt1, v, ctx.pd1, None, (1, 64), dx, v, B, H, W, 64, 64, res=dy)
-        dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
-        wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64)
+        if not side:
+            wgrad1()
         return dx, dw1, db1, dw2, db2, dcaw1, dcab1, dcaw2, dcab2, (dm if has_m else None), None
 
 

@@ -116,6 +116,10 @@ class GradReducer:
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
+            from . import ops
+            wside = ops.side_stream(flat.device, create=False)  # weight gradients are produced on this stream
+            if wside is not None:
+                self.stream.wait_stream(wside)
             with torch.cuda.stream(self.stream):
                 torch._foreach_copy_(list(flat.split([p.numel() for p in bucket])), [g.reshape(-1) for g in grads])
                 self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
