@@ -30,6 +30,7 @@ CL = torch.channels_last
 # each ~170 us MFMA launch is then filled by workgroups of the other queue.  The main stream re-joins the side
 # stream once, at the end of the backward pass (autograd engine callback), before anything reads the grads.
 WGRAD_SIDE_STREAM = os.environ.get("SISR_WGRAD_SIDE_STREAM", "1") != "0"
+IN_BACKWARD = False  # set while a conv operator's backward runs (bench.py times forward launches only)
 _side_streams = {}
 _join_pending = set()
 
@@ -184,59 +185,64 @@ class _Conv3x3(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        B, H, W, cin, cout = ctx.geom
-        dev = x.device
-        L = hip.lib()
-        need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
-        dx = dw = db = dres = None
-        if ctx.kind == "c64":
-            dy = _cl(dy)
-            r = ctx.shuffle
-            dyview = hip.view_shuffle(H, W, r) if r > 1 else hip.view_plain(H, W, cout)
-            if need_x:
-                packed = ctx.packed_dgrad if ctx.packed_dgrad is not None else pack_weight(w, "dgrad", r)
-                dx = _empty_cl(B, cin, H, W, dev)
-                conv_c64(dy, dyview, packed, None, (1, 64), dx, hip.view_plain(H, W, cin), B, H, W, cout, cin,
-                         alpha=ctx.alpha)
-            if need_w or need_b:
-                dw = torch.empty_like(w)
-                db = torch.empty(cout, device=dev, dtype=torch.float32) if ctx.has_bias else None
-                wgrad_c64(x, hip.view_plain(H, W, cin), dy, dyview, dw, db, B, H, W, cin, cout, alpha=ctx.alpha,
-                          shuffle=r)
-            if ctx.has_res and need_r:
-                dres = dy
-        elif ctx.kind == "cin3":
-            dy = _cl(dy)
-            if need_x:
-                dx = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
-                rc = L.sisr_conv3x3_cout3(hip.ptr(dy), hip.view_plain(H, W, cout), hip.ptr(w), 9, 27, 1, None,
-                                          hip.ptr(dx), B, H, W, cout, hip.stream())
-                hip.check(rc, "sisr_conv3x3_cout3(dgrad)")
-            if need_w or need_b:
-                dw = torch.empty_like(w)
-                db = torch.empty(cout, device=dev, dtype=torch.float32) if ctx.has_bias else None
-                nbytes = L.sisr_corr3x3_c3_workspace_bytes(B, H, W, cout)
-                ws = hip.workspace(dev, nbytes)
-                rc = L.sisr_corr3x3_c3(hip.ptr(x), hip.ptr(dy), hip.view_plain(H, W, cout), 1.0, hip.ptr(dw), 27, 9, 0,
-                                       0, hip.ptr(db), hip.ptr(ws), nbytes, B, H, W, cout, hip.stream())
-                hip.check(rc, "sisr_corr3x3_c3(head)")
-        else:  # cout3
-            dy = dy.contiguous()
-            if need_x:
-                dx = _empty_cl(B, cin, H, W, dev)
-                rc = L.sisr_conv3x3_cin3(hip.ptr(dy), hip.ptr(w), 9, cin * 9, 1, None, hip.ptr(dx),
-                                         hip.view_plain(H, W, cin), B, H, W, cin, hip.stream())
-                hip.check(rc, "sisr_conv3x3_cin3(dgrad)")
-            if need_w or need_b:
-                dw = torch.empty_like(w)
-                db = torch.empty(3, device=dev, dtype=torch.float32) if ctx.has_bias else None
-                nbytes = L.sisr_corr3x3_c3_workspace_bytes(B, H, W, cin)
-                ws = hip.workspace(dev, nbytes)
-                rc = L.sisr_corr3x3_c3(hip.ptr(dy), hip.ptr(x), hip.view_plain(H, W, cin), 1.0, hip.ptr(dw), cin * 9, 9,
-                                       1, 1, hip.ptr(db), hip.ptr(ws), nbytes, B, H, W, cin, hip.stream())
-                hip.check(rc, "sisr_corr3x3_c3(tail)")
-        return dx, dw, db, dres, None, None
+        global IN_BACKWARD
+        IN_BACKWARD = True
+        try:
+            x, w = ctx.saved_tensors
+            B, H, W, cin, cout = ctx.geom
+            dev = x.device
+            L = hip.lib()
+            need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
+            dx = dw = db = dres = None
+            if ctx.kind == "c64":
+                dy = _cl(dy)
+                r = ctx.shuffle
+                dyview = hip.view_shuffle(H, W, r) if r > 1 else hip.view_plain(H, W, cout)
+                if need_x:
+                    packed = ctx.packed_dgrad if ctx.packed_dgrad is not None else pack_weight(w, "dgrad", r)
+                    dx = _empty_cl(B, cin, H, W, dev)
+                    conv_c64(dy, dyview, packed, None, (1, 64), dx, hip.view_plain(H, W, cin), B, H, W, cout, cin,
+                             alpha=ctx.alpha)
+                if need_w or need_b:
+                    dw = torch.empty_like(w)
+                    db = torch.empty(cout, device=dev, dtype=torch.float32) if ctx.has_bias else None
+                    wgrad_c64(x, hip.view_plain(H, W, cin), dy, dyview, dw, db, B, H, W, cin, cout, alpha=ctx.alpha,
+                              shuffle=r)
+                if ctx.has_res and need_r:
+                    dres = dy
+            elif ctx.kind == "cin3":
+                dy = _cl(dy)
+                if need_x:
+                    dx = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
+                    rc = L.sisr_conv3x3_cout3(hip.ptr(dy), hip.view_plain(H, W, cout), hip.ptr(w), 9, 27, 1, None,
+                                              hip.ptr(dx), B, H, W, cout, hip.stream())
+                    hip.check(rc, "sisr_conv3x3_cout3(dgrad)")
+                if need_w or need_b:
+                    dw = torch.empty_like(w)
+                    db = torch.empty(cout, device=dev, dtype=torch.float32) if ctx.has_bias else None
+                    nbytes = L.sisr_corr3x3_c3_workspace_bytes(B, H, W, cout)
+                    ws = hip.workspace(dev, nbytes)
+                    rc = L.sisr_corr3x3_c3(hip.ptr(x), hip.ptr(dy), hip.view_plain(H, W, cout), 1.0, hip.ptr(dw), 27, 9, 0,
+                                           0, hip.ptr(db), hip.ptr(ws), nbytes, B, H, W, cout, hip.stream())
+                    hip.check(rc, "sisr_corr3x3_c3(head)")
+            else:  # cout3
+                dy = dy.contiguous()
+                if need_x:
+                    dx = _empty_cl(B, cin, H, W, dev)
+                    rc = L.sisr_conv3x3_cin3(hip.ptr(dy), hip.ptr(w), 9, cin * 9, 1, None, hip.ptr(dx),
+                                             hip.view_plain(H, W, cin), B, H, W, cin, hip.stream())
+                    hip.check(rc, "sisr_conv3x3_cin3(dgrad)")
+                if need_w or need_b:
+                    dw = torch.empty_like(w)
+                    db = torch.empty(3, device=dev, dtype=torch.float32) if ctx.has_bias else None
+                    nbytes = L.sisr_corr3x3_c3_workspace_bytes(B, H, W, cin)
+                    ws = hip.workspace(dev, nbytes)
+                    rc = L.sisr_corr3x3_c3(hip.ptr(dy), hip.ptr(x), hip.view_plain(H, W, cin), 1.0, hip.ptr(dw), cin * 9, 9,
+                                           1, 1, hip.ptr(db), hip.ptr(ws), nbytes, B, H, W, cin, hip.stream())
+                    hip.check(rc, "sisr_corr3x3_c3(tail)")
+            return dx, dw, db, dres, None, None
+        finally:
+            IN_BACKWARD = False
 
 
 def conv3x3(x, weight, bias=None, residual=None, alpha=1.0, shuffle=1):
@@ -292,6 +298,7 @@ class _ResBlock(Function):
         B, C, H, W = x.shape
         if C != 64 or tuple(w1.shape) != (64, 64, 3, 3) or tuple(w2.shape) != (64, 64, 3, 3):
             raise NotImplementedError("fused residual block is specialised for n_feats = 64")
+        _join_pending.clear()  # a backward pass that died mid-way must not leave the join flag set
         dev = x.device
         x = _cl(x)
         w1, w2 = w1.contiguous(), w2.contiguous()
@@ -339,76 +346,81 @@ class _ResBlock(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        has_ca, has_m, rs, (B, H, W), s_caw1, s_caw2 = ctx.cfg
-        sv = list(ctx.saved_tensors)
-        x, w1, w2, t1 = sv[:4]
-        dev = x.device
-        L = hip.lib()
-        dy = _cl(dy)
-        v = hip.view_plain(H, W, 64)
-        hw = H * W
-        dcaw1 = dcab1 = dcaw2 = dcab2 = dm = None
-        scale = shift = None
-        if has_ca or has_m:
-            t2 = sv[4]
-            parts = L.sisr_gate_dg_parts(hw)
-            dgp = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
-            hip.check(L.sisr_gate_dg_partial(hip.ptr(dy), hip.ptr(t2), hip.ptr(dgp), B, hw, 64, hip.stream()),
-                      "sisr_gate_dg_partial")
-            if has_ca:
-                caw1c, caw2c, s, hid, ca, g = sv[5:11]
-                mm = sv[11] if has_m else None
-                R = caw1c.shape[0]
-                shift = _vec(B, 64, dev)
-                dmv = _vec(B, 64, dev) if has_m else None
-                dcaw1, dcab1 = torch.empty_like(caw1c), torch.empty(R, device=dev)
-                dcaw2, dcab2 = torch.empty_like(caw2c), torch.empty(64, device=dev)
-                rc = L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
-                                        hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
-                                        hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
-                                        hip.ptr(_vec(B, 80, dev)), hip.stream())
-                hip.check(rc, "sisr_ca_gate_bwd")
-                dcaw1, dcaw2 = dcaw1.reshape(s_caw1), dcaw2.reshape(s_caw2)
-                dm, scale = dmv, g
-            else:
-                g = sv[5]
-                dm = _vec(B, 64, dev)
-                hip.check(L.sisr_sum_partials(hip.ptr(dgp), parts, B, 64, 1.0, hip.ptr(dm), hip.stream()),
-                          "sisr_sum_partials")
-                scale = g
-        # conv2 backward: dt2 = dy*scale + shift is rebuilt on load, never stored
-        dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
-        dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
-        side = WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False  # plain first-order backward only
+        global IN_BACKWARD
+        IN_BACKWARD = True
+        try:
+            has_ca, has_m, rs, (B, H, W), s_caw1, s_caw2 = ctx.cfg
+            sv = list(ctx.saved_tensors)
+            x, w1, w2, t1 = sv[:4]
+            dev = x.device
+            L = hip.lib()
+            dy = _cl(dy)
+            v = hip.view_plain(H, W, 64)
+            hw = H * W
+            dcaw1 = dcab1 = dcaw2 = dcab2 = dm = None
+            scale = shift = None
+            if has_ca or has_m:
+                t2 = sv[4]
+                parts = L.sisr_gate_dg_parts(hw)
+                dgp = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
+                hip.check(L.sisr_gate_dg_partial(hip.ptr(dy), hip.ptr(t2), hip.ptr(dgp), B, hw, 64, hip.stream()),
+                          "sisr_gate_dg_partial")
+                if has_ca:
+                    caw1c, caw2c, s, hid, ca, g = sv[5:11]
+                    mm = sv[11] if has_m else None
+                    R = caw1c.shape[0]
+                    shift = _vec(B, 64, dev)
+                    dmv = _vec(B, 64, dev) if has_m else None
+                    dcaw1, dcab1 = torch.empty_like(caw1c), torch.empty(R, device=dev)
+                    dcaw2, dcab2 = torch.empty_like(caw2c), torch.empty(64, device=dev)
+                    rc = L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
+                                            hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
+                                            hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
+                                            hip.ptr(_vec(B, 80, dev)), hip.stream())
+                    hip.check(rc, "sisr_ca_gate_bwd")
+                    dcaw1, dcaw2 = dcaw1.reshape(s_caw1), dcaw2.reshape(s_caw2)
+                    dm, scale = dmv, g
+                else:
+                    g = sv[5]
+                    dm = _vec(B, 64, dev)
+                    hip.check(L.sisr_sum_partials(hip.ptr(dgp), parts, B, 64, 1.0, hip.ptr(dm), hip.stream()),
+                              "sisr_sum_partials")
+                    scale = g
+            # conv2 backward: dt2 = dy*scale + shift is rebuilt on load, never stored
+            dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
+            dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
+            side = WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False  # plain first-order backward only
 
-        def wgrad2():
-            wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, alpha=rs, dy_scale=scale, dy_shift=shift)
+            def wgrad2():
+                wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, alpha=rs, dy_scale=scale, dy_shift=shift)
 
-        if side:
-            ev = torch.cuda.Event()
-            ev.record()
-            _on_side(dev, ev, wgrad2, (t1, dy, scale, shift, dw2, db2))
-        dt1 = _empty_cl(B, 64, H, W, dev)
-        conv_c64(dy, v, ctx.pd2, None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1, in_scale=scale, in_shift=shift,
-                 alpha=rs)
-        if not side:
-            wgrad2()
+            if side:
+                ev = torch.cuda.Event()
+                ev.record()
+                _on_side(dev, ev, wgrad2, (t1, dy, scale, shift, dw2, db2))
+            dt1 = _empty_cl(B, 64, H, W, dev)
+            conv_c64(dy, v, ctx.pd2, None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1, in_scale=scale, in_shift=shift,
+                     alpha=rs)
+            if not side:
+                wgrad2()
 
-        def wgrad1():
-            wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64)
+            def wgrad1():
+                wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64)
 
-        # conv1 backward (+ skip connection gradient)
-        if side:
-            ev = torch.cuda.Event()
-            ev.record()
-            _on_side(dev, ev, wgrad1, (x, dt1, dw1, db1))
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = _empty_cl(B, 64, H, W, dev)
-            conv_c64(dt1, v, ctx.pd1, None, (1, 64), dx, v, B, H, W, 64, 64, res=dy)
-        if not side:
-            wgrad1()
-        return dx, dw1, db1, dw2, db2, dcaw1, dcab1, dcaw2, dcab2, (dm if has_m else None), None
+            # conv1 backward (+ skip connection gradient)
+            if side:
+                ev = torch.cuda.Event()
+                ev.record()
+                _on_side(dev, ev, wgrad1, (x, dt1, dw1, db1))
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = _empty_cl(B, 64, H, W, dev)
+                conv_c64(dt1, v, ctx.pd1, None, (1, 64), dx, v, B, H, W, 64, 64, res=dy)
+            if not side:
+                wgrad1()
+            return dx, dw1, db1, dw2, db2, dcaw1, dcab1, dcaw2, dcab2, (dm if has_m else None), None
+        finally:
+            IN_BACKWARD = False
 
 
 def res_block(x, w1, b1, w2, b2, ca=None, m=None, res_scale=1.0):
@@ -436,22 +448,27 @@ class _ConvReluConv(Function):
 
     @staticmethod
     def backward(ctx, dt2):
-        x, w1, w2, t1 = ctx.saved_tensors
-        B, C, H, W = x.shape
-        dev = x.device
-        dt2 = _cl(dt2)
-        v = hip.view_plain(H, W, 64)
-        dt1 = _empty_cl(B, 64, H, W, dev)
-        conv_c64(dt2, v, pack_weight(w2, "dgrad"), None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1)
-        dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
-        wgrad_c64(t1, v, dt2, v, dw2, db2, B, H, W, 64, 64)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = _empty_cl(B, 64, H, W, dev)
-            conv_c64(dt1, v, pack_weight(w1, "dgrad"), None, (1, 64), dx, v, B, H, W, 64, 64)
-        dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
-        wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64)
-        return dx, dw1, db1, dw2, db2
+        global IN_BACKWARD
+        IN_BACKWARD = True
+        try:
+            x, w1, w2, t1 = ctx.saved_tensors
+            B, C, H, W = x.shape
+            dev = x.device
+            dt2 = _cl(dt2)
+            v = hip.view_plain(H, W, 64)
+            dt1 = _empty_cl(B, 64, H, W, dev)
+            conv_c64(dt2, v, pack_weight(w2, "dgrad"), None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1)
+            dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
+            wgrad_c64(t1, v, dt2, v, dw2, db2, B, H, W, 64, 64)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = _empty_cl(B, 64, H, W, dev)
+                conv_c64(dt1, v, pack_weight(w1, "dgrad"), None, (1, 64), dx, v, B, H, W, 64, 64)
+            dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
+            wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64)
+            return dx, dw1, db1, dw2, db2
+        finally:
+            IN_BACKWARD = False
 
 
 def res_block_convs(x, w1, b1, w2, b2):
@@ -686,19 +703,24 @@ class _ConvStack(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        stack, w = ctx.saved_tensors
-        B, N, H, W, C = stack.shape
-        dev = stack.device
-        dy = _cl(dy)
-        dstack = None
-        if ctx.needs_input_grad[0]:
-            dstack = torch.empty_like(stack)
-            conv_c64(dy, hip.view_plain(H, W, 64), ctx.pd, None, (1, 64), dstack, hip.view_maps(H, W, N), B, H, W, 64,
-                     64 * N)
-        dw = torch.empty_like(w)
-        db = torch.empty(64, device=dev, dtype=torch.float32) if ctx.has_bias else None
-        wgrad_c64(stack, hip.view_maps(H, W, N), dy, hip.view_plain(H, W, 64), dw, db, B, H, W, 64 * N, 64)
-        return dstack, dw, db
+        global IN_BACKWARD
+        IN_BACKWARD = True
+        try:
+            stack, w = ctx.saved_tensors
+            B, N, H, W, C = stack.shape
+            dev = stack.device
+            dy = _cl(dy)
+            dstack = None
+            if ctx.needs_input_grad[0]:
+                dstack = torch.empty_like(stack)
+                conv_c64(dy, hip.view_plain(H, W, 64), ctx.pd, None, (1, 64), dstack, hip.view_maps(H, W, N), B, H, W, 64,
+                         64 * N)
+            dw = torch.empty_like(w)
+            db = torch.empty(64, device=dev, dtype=torch.float32) if ctx.has_bias else None
+            wgrad_c64(stack, hip.view_maps(H, W, N), dy, hip.view_plain(H, W, 64), dw, db, B, H, W, 64 * N, 64)
+            return dstack, dw, db
+        finally:
+            IN_BACKWARD = False
 
 
 def conv3x3_stack(stack, weight, bias):
