@@ -357,3 +357,41 @@ def test_two_ranks_share_one_gpu_grad_reducer(tmp_path):
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["value"] > 0
     assert np.isfinite(line["config"]["final_loss"])
+
+
+def test_set5_training_psnr_parity_at_equal_steps():
+    """north_star: 'PSNR on Set5 within 0.02 dB of the reference at equal steps'.  EDSR-baseline (16 blocks,
+    full depth) trained for 40 Adam steps on seeded Set5 crops, once on the HIP kernels and once by the CPU
+    oracle (itself pinned to the reference), same init / batches / schedule; then full-image Set5 Y-PSNR."""
+    import random
+    torch.manual_seed(8)
+    h = build_gpu("edsr", eval_mode=False, lr=1e-4, scheduler="cosine_annealing_warm_restarts",
+                  scheduler_params={"t_mult": 1, "restart_period": 25, "lr_min": 1e-7})
+    tr = O.Trainer("edsr", {k: v.detach().cpu() for k, v in h.net.state_dict().items()}, lr=1e-4,
+                   scheduler="cosine_annealing_warm_restarts",
+                   scheduler_params={"t_mult": 1, "restart_period": 25, "lr_min": 1e-7}, num_blocks=16, scale=4,
+                   res_scale=0.1)
+    images = [(x[0], y[0]) for _, x, y, _ in set5()]
+    rng = random.Random(3)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    for step in range(40):
+        xs, ys = [], []
+        for _ in range(4):
+            x, y = images[rng.randrange(5)]
+            i, j = rng.randrange(x.shape[1] - 31), rng.randrange(x.shape[2] - 31)
+            xs.append(x[:, i:i + 32, j:j + 32])
+            ys.append(y[:, 4 * i:4 * i + 128, 4 * j:4 * j + 128])
+        xb, yb = torch.stack(xs), torch.stack(ys)
+        loss_hip, _ = h.run_train(xb, yb)
+        loss_ref, _, _ = tr.step(xb, yb)
+        assert abs(float(loss_hip) - loss_ref) < 2e-3, (step, float(loss_hip), loss_ref)
+    diffs = []
+    with torch.no_grad():
+        for x, y in images:
+            out, _, _ = h.run_eval(x[None])
+            ref = O.edsr(tr.sd, x[None], num_blocks=16, scale=4, res_scale=0.1)
+            p_hip = sisr_amd.metrics.y_psnr(out[0].numpy(), y.numpy())
+            p_ref = O.y_psnr(ref[0].numpy(), y.numpy())
+            diffs.append(p_hip - p_ref)
+    print("Set5 Y-PSNR (HIP - oracle) after 40 steps:", diffs)
+    assert max(abs(d) for d in diffs) < 0.02, diffs
