@@ -96,9 +96,10 @@ int sisr_ca_gate_bwd(const float* dg_partial, int parts, int B, float inv_hw, co
  * ref: attention_manipulators/q_layer.py:4-43 ParaCALayer: m = sigmoid(V2 act(V1 md + c1) + c2) */
 int sisr_meta_gate_fwd(const float* md, int B, int M, int hidden, int channels, const float* v1, const float* c1,
                        const float* v2, const float* c2, int relu, float* hid, float* m, void* stream);
+size_t sisr_meta_gate_bwd_workspace_bytes(int B, int hidden, int channels);
 int sisr_meta_gate_bwd(const float* dm, const float* m, const float* hid, const float* md, int B, int M, int hidden,
                        int channels, const float* v1, const float* v2, int relu, float* dv1, float* dc1, float* dv2,
-                       float* dc2, float* dmd, void* stream);
+                       float* dc2, float* dmd, float* workspace, void* stream);
 
 /* ---- gated residual: y = t*g[b,c] + shift[b,c] + x  (g, shift, x nullable)
  * ref: the `x * y` / `res += x` tails of CALayer, RCAB, QRCAB, ParamResBlock; with shift it is also the
@@ -108,6 +109,15 @@ int sisr_gate_residual_fwd(const float* t, const float* g, const float* shift, c
 int sisr_gate_dg_parts(long hw);
 int sisr_gate_dg_partial(const float* dy, const float* t, float* part, int B, long hw, int channels, void* stream);
 int sisr_sum_partials(const float* part, int parts, int B, int channels, float scale, float* out, void* stream);
+
+/* ---- pixel attention, 64 channels, hidden 8 (ref: attention_manipulators/architectures.py:13-26 PALayer):
+ * y = x * sigmoid(w2 . relu(W1 x + b1) + b2) per pixel; x, y contiguous [npix][64]. */
+int sisr_pa_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, long npix,
+                int channels, int hidden, void* stream);
+size_t sisr_pa_bwd_workspace_bytes(long npix);
+int sisr_pa_bwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* dy,
+                float* dx, float* dw1, float* db1, float* dw2, float* db2, float* workspace, long npix, int channels,
+                int hidden, void* stream);
 
 /* ---- HAN attention modules ---------------------------------------------------------------------
  * ref: advanced/HAN_blocks.py:7-37 LAM_Module: x [B][N][chw] (N layer maps, any common layout);

@@ -216,8 +216,7 @@ class ParaCALayer(nn.Module):
 
 
 class PALayer(nn.Module):
-    """ref: attention_manipulators/architectures.py:13-26.  Parameter holder; the per-pixel 1x1 gate has no
-    HIP kernel yet ('next')."""
+    """ref: attention_manipulators/architectures.py:13-26 (per-pixel 64 -> 8 -> 1 sigmoid gate)."""
 
     def __init__(self, channel):
         super().__init__()
@@ -225,7 +224,7 @@ class PALayer(nn.Module):
                                 nn.Conv2d(channel // 8, 1, 1, padding=0, bias=True), nn.Sigmoid())
 
     def forward(self, x):
-        raise NotImplementedError("pixel attention (include_pixel_attention=True) is not implemented on the HIP path")
+        return ops.pa_layer(x, self.pa[0].weight, self.pa[0].bias, self.pa[2].weight, self.pa[2].bias)
 
 
 class QCALayer(nn.Module):
@@ -304,7 +303,12 @@ class QRCAB(nn.Module):
         feat, md = x
         b = self.body
         if self.pa:
-            return self.pa_node(feat), md  # raises: not implemented on the HIP path
+            # per-pixel gate between the channel and meta gates: the per-(b,c) fusion does not apply
+            t = ops.res_block_convs(feat, b[0].weight, b[0].bias, b[2].weight, b[2].bias)
+            t = self.pa_node(self.final_body(t, md))
+            if self.q_layer:
+                return ops.gate_mul(t, self.q_node.gate(md), feat), md
+            return ops.add_residual(t, feat), md
         if self.final_body.style == 'standard':
             m = self.q_node.gate(md) if self.q_layer else None
             y = ops.res_block(feat, b[0].weight, b[0].bias, b[2].weight, b[2].bias,

@@ -36,7 +36,11 @@ _SIGS = {
     "sisr_ca_gate_bwd_workspace_bytes": (c_size_t, [c_int]),
     "sisr_ca_gate_bwd": (c_int, [P, c_int, c_int, c_float, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
     "sisr_meta_gate_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P]),
-    "sisr_meta_gate_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P]),
+    "sisr_meta_gate_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sisr_meta_gate_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P]),
+    "sisr_pa_fwd": (c_int, [P, P, P, P, P, P, c_long, c_int, c_int, P]),
+    "sisr_pa_bwd_workspace_bytes": (c_size_t, [c_long]),
+    "sisr_pa_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_long, c_int, c_int, P]),
     "sisr_gate_residual_fwd": (c_int, [P, P, P, P, P, c_int, c_long, c_int, P]),
     "sisr_gate_dg_parts": (c_int, [c_long]),
     "sisr_gate_dg_partial": (c_int, [P, P, P, c_int, c_long, c_int, P]),

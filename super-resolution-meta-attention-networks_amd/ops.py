@@ -278,7 +278,8 @@ class _MetaGate(Function):
         dmd = torch.empty_like(md2) if ctx.needs_input_grad[0] else None
         rc = hip.lib().sisr_meta_gate_bwd(hip.ptr(dm.contiguous()), hip.ptr(m), hip.ptr(hid), hip.ptr(md2), B, M, Hd, C,
                                           hip.ptr(v1c), hip.ptr(v2c), int(ctx.relu), hip.ptr(dv1), hip.ptr(dc1),
-                                          hip.ptr(dv2), hip.ptr(dc2), hip.ptr(dmd), hip.stream())
+                                          hip.ptr(dv2), hip.ptr(dc2), hip.ptr(dmd), hip.ptr(_vec(B, Hd + C, dev)),
+                                          hip.stream())
         hip.check(rc, "sisr_meta_gate_bwd")
         s_md, s_v1, s_v2 = ctx.shapes
         return (dmd.reshape(s_md) if dmd is not None else None, dv1.reshape(s_v1), dc1, dv2.reshape(s_v2), dc2, None)
@@ -596,6 +597,63 @@ class _GlobalAvgPool(Function):
 
 def global_avg_pool(t):
     return _GlobalAvgPool.apply(t)
+
+
+class _PALayer(Function):
+    """Per-pixel attention gate (ref: attention_manipulators/architectures.py:13-26)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        B, C, H, W = x.shape
+        if C != 64 or w1.shape[0] != 8:
+            raise NotImplementedError("pixel attention kernel is specialised for 64 channels / 8 hidden units")
+        x = _cl(x)
+        w1c, w2c = w1.reshape(8, 64).contiguous(), w2.reshape(8).contiguous()
+        b1c, b2c = b1.contiguous(), b2.reshape(1).contiguous()
+        y = _empty_cl(B, C, H, W, x.device)
+        hip.check(hip.lib().sisr_pa_fwd(hip.ptr(x), hip.ptr(w1c), hip.ptr(b1c), hip.ptr(w2c), hip.ptr(b2c), hip.ptr(y),
+                                        B * H * W, 64, 8, hip.stream()), "sisr_pa_fwd")
+        ctx.save_for_backward(x, w1c, b1c, w2c, b2c)
+        ctx.shapes = (w1.shape, w2.shape, b2.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1c, b1c, w2c, b2c = ctx.saved_tensors
+        B, C, H, W = x.shape
+        L = hip.lib()
+        dy = _cl(dy)
+        npix = B * H * W
+        ws = hip.workspace(x.device, L.sisr_pa_bwd_workspace_bytes(npix))
+        dx = _empty_cl(B, C, H, W, x.device)
+        dw1, db1 = torch.empty_like(w1c), torch.empty_like(b1c)
+        dw2, db2 = torch.empty_like(w2c), torch.empty_like(b2c)
+        hip.check(L.sisr_pa_bwd(hip.ptr(x), hip.ptr(w1c), hip.ptr(b1c), hip.ptr(w2c), hip.ptr(b2c), hip.ptr(dy),
+                                hip.ptr(dx), hip.ptr(dw1), hip.ptr(db1), hip.ptr(dw2), hip.ptr(db2), hip.ptr(ws), npix,
+                                64, 8, hip.stream()), "sisr_pa_bwd")
+        s1, s2, sb2 = ctx.shapes
+        return dx, dw1.reshape(s1), db1, dw2.reshape(s2), db2.reshape(sb2)
+
+
+def pa_layer(x, w1, b1, w2, b2):
+    return _PALayer.apply(x, w1, b1, w2, b2)
+
+
+class _AddResidual(Function):
+    """y = t + x on channels-last maps."""
+
+    @staticmethod
+    def forward(ctx, t, x):
+        B, C, H, W = t.shape
+        return _affine(_cl(t), None, None, _cl(x), B, H, W, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add_residual(t, x):
+    return _AddResidual.apply(t, x)
 
 
 # ----------------------------------------------------------------------------- HAN attention modules

@@ -171,9 +171,14 @@ def test_g1_qca(style):
 
 
 @pytest.mark.parametrize("q", [0, 1])
-def test_g1_qrcab(q):
-    m = A.QRCAB(A.default_conv, 64, 3, 16, style="standard", pa=False, q_layer=bool(q), num_metadata=10)
-    run_block(f"g1_qrcab_q{q}_pa0", m, 2, call=lambda mod, i: mod((i[0], i[1]))[0])
+@pytest.mark.parametrize("pa", [0, 1])
+def test_g1_qrcab(q, pa):
+    m = A.QRCAB(A.default_conv, 64, 3, 16, style="standard", pa=bool(pa), q_layer=bool(q), num_metadata=10)
+    run_block(f"g1_qrcab_q{q}_pa{pa}", m, 2, call=lambda mod, i: mod((i[0], i[1]))[0])
+
+
+def test_g1_palayer():
+    run_block("g1_palayer", A.PALayer(64), 1)
 
 
 @pytest.mark.parametrize("nl", [0, 1])
@@ -267,6 +272,19 @@ def test_qhan_reduced_vs_oracle():
     _live_gammas(net)
     net_vs_oracle(net, "qhan", dict(n_resgroups=10, n_resblocks=1, scale=4), rnd(2, 3, 12, 20, seed=38, scale=0.5),
                   rnd(2, 10, 1, 1, seed=39, scale=0.3))
+
+
+def test_qrcan_pixel_attention_and_modulate_vs_oracle():
+    torch.manual_seed(8)
+    net = A.QRCAN(n_resblocks=2, n_resgroups=2, n_feats=64, scale=2, style="standard", num_metadata=10,
+                  include_q_layer=True, include_pixel_attention=True)
+    cfg = dict(n_resgroups=2, n_resblocks=2, scale=2, style="standard", include_q_layer=True,
+               include_pixel_attention=True)
+    net_vs_oracle(net, "qrcan", cfg, rnd(2, 3, 9, 21, seed=43, scale=0.5), rnd(2, 10, 1, 1, seed=44, scale=0.3))
+    torch.manual_seed(8)
+    net = A.QRCAN(n_resblocks=2, n_resgroups=1, n_feats=64, scale=2, style="modulate", num_metadata=1)
+    cfg = dict(n_resgroups=1, n_resblocks=2, scale=2, style="modulate")
+    net_vs_oracle(net, "qrcan", cfg, rnd(2, 3, 9, 21, seed=45, scale=0.5), rnd(2, 64, 1, 1, seed=46, scale=0.3).abs())
 
 
 def test_qedsr_reduced_vs_oracle():
