@@ -413,3 +413,68 @@ def test_set5_training_psnr_parity_at_equal_steps():
             diffs.append(p_hip - p_ref)
     print("Set5 Y-PSNR (HIP - oracle) after 40 steps:", diffs)
     assert max(abs(d) for d in diffs) < 0.02, diffs
+
+
+# ----------------------------------------------------------------------------- size-independent properties, edge cases
+def test_adjoint_identities_at_bench_size():
+    """<conv(x), dy> = <x, dgrad(dy)> = <w, wgrad(x, dy)> + <b, sum dy> on a full 8x64x128x128 map: the three
+    kernels are mutually consistent at production size (fp64 accumulation of the inner products)."""
+    g = torch.Generator(device="cpu").manual_seed(50)
+    x = torch.randn(8, 64, 128, 128, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    b = torch.randn(64, generator=g).to(DEV).requires_grad_(True)
+    dy = torch.randn(8, 64, 128, 128, generator=g).to(DEV)
+    y = ops.conv3x3(x, w, b)
+    y.backward(dy)
+    lhs = (y.double() * dy.double()).sum().item()
+    via_x = (x.detach().double() * x.grad.double()).sum().item() + (b.detach().double() * b.grad.double()).sum().item()
+    via_w = (w.detach().double() * w.grad.double()).sum().item() + (b.detach().double() * b.grad.double()).sum().item()
+    assert abs(lhs - via_x) < 1e-6 * abs(lhs) + 1e-2 and abs(lhs - via_w) < 1e-6 * abs(lhs) + 1e-2, (lhs, via_x, via_w)
+    # linearity in the input
+    x2 = torch.randn(8, 64, 128, 128, generator=g).to(DEV)
+    with torch.no_grad():
+        close(ops.conv3x3(x.detach() + 2 * x2, w, None), ops.conv3x3(x.detach(), w, None) + 2 * ops.conv3x3(x2, w, None),
+              1e-4, 2e-5)
+
+
+def test_backward_is_bitwise_reproducible():
+    """No atomics anywhere: two identical training steps give bit-identical gradients (side stream included)."""
+    grads = []
+    for _ in range(2):
+        torch.manual_seed(8)
+        net = A.RCAN(n_resblocks=2, n_resgroups=2, n_feats=64, scale=4).to(DEV)
+        x = rnd(2, 3, 40, 72, seed=60).to(DEV)
+        y = rnd(2, 3, 160, 288, seed=61).to(DEV)
+        ops.l1_loss(net(x), y).backward()
+        torch.cuda.synchronize()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu())
+    assert torch.equal(grads[0], grads[1])
+
+
+def test_large_odd_image_eval_vs_oracle():
+    torch.manual_seed(8)
+    net = A.RCAN(n_resblocks=1, n_resgroups=1, n_feats=64, scale=2)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = rnd(1, 3, 203, 311, seed=62, scale=0.5)
+    with torch.no_grad():
+        ref = O.rcan(sd, x, n_resgroups=1, n_resblocks=1, scale=2)
+        out = net.to(DEV)(x.to(DEV))
+    assert out.shape == (1, 3, 406, 622)
+    close(out, ref, 2e-4, 2e-5)
+
+
+def test_invalid_inputs_fail_loudly():
+    w = torch.zeros(64, 64, 3, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        ops.conv3x3(torch.zeros(0, 64, 8, 8, device=DEV), w)          # empty batch
+    with pytest.raises(NotImplementedError, match="multiples of 64"):
+        ops.conv3x3(torch.zeros(1, 48, 8, 8, device=DEV), torch.zeros(48, 48, 3, 3, device=DEV))
+    with pytest.raises(RuntimeError, match="fp32"):
+        ops.conv3x3(torch.zeros(1, 64, 8, 8, device=DEV, dtype=torch.bfloat16), w)
+    with pytest.raises(RuntimeError, match="shape mismatch"):
+        ops.l1_loss(torch.zeros(1, 3, 8, 8, device=DEV), torch.zeros(1, 3, 8, 9, device=DEV))
+    # 1x1 spatial extent and a single pixel column are legal
+    x = rnd(1, 64, 1, 1, seed=63)
+    close(ops.conv3x3(x.to(DEV), w + 0.01), F.conv2d(x, w.cpu() + 0.01, padding=1), 1e-5, 1e-6)
+    x = rnd(2, 64, 37, 1, seed=64)
+    close(ops.conv3x3(x.to(DEV), w + 0.01), F.conv2d(x, w.cpu() + 0.01, padding=1), 1e-5, 1e-6)
