@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--workload", default="rcan", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay forward+backward as a hipGraph (small batches)")
     args = ap.parse_args()
 
     import importlib
@@ -134,6 +135,12 @@ def main():
                                     scheduler_params={"t_mult": 1, "restart_period": 125000, "lr_min": 1e-7}, **params)
     if world > 1:
         h.set_multi_gpu()
+    if args.graph:
+        h.use_graph = True
+        args.no_kernel_timing = True
+        if h.reducer is not None:
+            h.reducer.remove()
+            h.reducer.overlap = False
     B = args.batch
     g = torch.Generator().manual_seed(8 + rank)
     x = torch.rand(B, 3, 128, 128, generator=g).to(dev)
@@ -176,7 +183,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{name.upper()} x4 full depth, 128x128 LR -> 512x512 tiles, train step = "
                                    f"fwd + L1 + bwd + Adam + scheduler", "per_gpu_batch": B, "global_batch": B * world,
-                       "parallelism": f"dp{world}", "final_loss": loss_val,
+                       "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "final_loss": loss_val,
                        "algorithmic_tflops": value * tflop_per_patch},
         }
         ks = timer.summary()

@@ -390,7 +390,9 @@ class _ResBlock(Function):
             # conv2 backward: dt2 = dy*scale + shift is rebuilt on load, never stored
             dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
             dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
-            side = WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False  # plain first-order backward only
+                # plain first-order backward only; not under hipGraph capture (record_stream + private pools)
+            side = (WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False
+                    and not torch.cuda.is_current_stream_capturing())
 
             def wgrad2():
                 wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, alpha=rs, dy_scale=scale, dy_shift=shift)

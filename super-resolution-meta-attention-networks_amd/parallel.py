@@ -95,7 +95,7 @@ class GradReducer:
         self.works = [None] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
-        self.overlap = overlap
+        self.overlap = overlap  # False: no hooks, everything is reduced at the join (needed under hipGraph replay)
         self.handles = []
         if overlap:
             for p in self.params:

@@ -478,3 +478,21 @@ def test_invalid_inputs_fail_loudly():
     close(ops.conv3x3(x.to(DEV), w + 0.01), F.conv2d(x, w.cpu() + 0.01, padding=1), 1e-5, 1e-6)
     x = rnd(2, 64, 37, 1, seed=64)
     close(ops.conv3x3(x.to(DEV), w + 0.01), F.conv2d(x, w.cpu() + 0.01, padding=1), 1e-5, 1e-6)
+
+
+def test_hip_graph_replay_matches_eager():
+    """BaseModel.use_graph: forward+loss+backward replayed from a hipGraph gives the eager trajectory."""
+    losses = {}
+    for mode in (False, True):
+        torch.manual_seed(8)
+        h = sisr_amd.handlers.EDSRHandler(device=0, model_save_dir="/tmp", eval_mode=False, num_blocks=3, lr=1e-4)
+        h.use_graph = mode
+        g = torch.Generator().manual_seed(5)
+        ls = []
+        for _ in range(4):
+            x, y = torch.rand(2, 3, 24, 40, generator=g), torch.rand(2, 3, 96, 160, generator=g)
+            loss, out = h.train_step(x, y)
+            ls.append(float(loss))
+        losses[mode] = (ls, float(sum(p.double().sum() for p in h.net.parameters())))
+    assert np.allclose(losses[True][0], losses[False][0], rtol=0, atol=1e-6), losses
+    assert abs(losses[True][1] - losses[False][1]) < 1e-5
