@@ -160,10 +160,15 @@ __global__ __launch_bounds__(256) void meta_gate_bwd_sample_kernel(const float* 
                                                                    const float* __restrict__ v2, int relu,
                                                                    float* __restrict__ dz2_out, float* __restrict__ dz1_out,
                                                                    float* __restrict__ dmd) {
-  extern __shared__ float sm[];
+  extern __shared__ float sm[];  // dz2 [C] | dz1 [Hd] | v2 [C*Hd] | v1 [Hd*M]   (weights staged coalesced)
   float* dz2 = sm;
   float* dz1 = sm + C;
+  float* v2s = dz1 + Hd;
+  float* v1s = v2s + C * Hd;
   const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < C * Hd; i += 256) v2s[i] = v2[i];
+  if (dmd)
+    for (int i = tid; i < Hd * M; i += 256) v1s[i] = v1[i];
   for (int c = tid; c < C; c += 256) {
     const float mv = m[(long)b * C + c];
     const float d = dm[(long)b * C + c] * mv * (1.f - mv);
@@ -173,16 +178,16 @@ __global__ __launch_bounds__(256) void meta_gate_bwd_sample_kernel(const float* 
   __syncthreads();
   for (int j = tid; j < Hd; j += 256) {
     float dh = 0.f;
-    for (int c = 0; c < C; ++c) dh += v2[(long)c * Hd + j] * dz2[c];
+    for (int c = 0; c < C; ++c) dh += v2s[c * Hd + j] * dz2[c];
     if (relu && !(hid[(long)b * Hd + j] > 0.f)) dh = 0.f;
     dz1[j] = dh;
     dz1_out[(long)b * Hd + j] = dh;
   }
-  __syncthreads();
   if (dmd) {
+    __syncthreads();
     for (int k = tid; k < M; k += 256) {
       float d = 0.f;
-      for (int j = 0; j < Hd; ++j) d += v1[(long)j * M + k] * dz1[j];
+      for (int j = 0; j < Hd; ++j) d += v1s[j * M + k] * dz1[j];
       dmd[(long)b * M + k] = d;
     }
   }
@@ -447,11 +452,12 @@ extern "C" int sisr_meta_gate_bwd(const float* dm, const float* m, const float* 
                                   int hidden, int channels, const float* v1, const float* v2, int relu, float* dv1,
                                   float* dc1, float* dv2, float* dc2, float* dmd, float* workspace, void* stream) {
   if (!dm || !m || !hid || !md || !v1 || !v2 || !dv1 || !dc1 || !dv2 || !dc2 || !workspace || B <= 0) return SISR_ERR_ARG;
-  if (hidden + channels > 8192) return SISR_ERR_UNSUPPORTED;
+  const size_t lds = ((size_t)hidden + channels + (size_t)channels * hidden + (size_t)hidden * M) * sizeof(float);
+  if (lds > 60000) return SISR_ERR_UNSUPPORTED;
   float* dz2 = workspace;
   float* dz1 = workspace + (size_t)B * channels;
-  hipLaunchKernelGGL(meta_gate_bwd_sample_kernel, dim3(B), dim3(256), (hidden + channels) * sizeof(float),
-                     (hipStream_t)stream, dm, m, hid, M, hidden, channels, v1, v2, relu, dz2, dz1, dmd);
+  hipLaunchKernelGGL(meta_gate_bwd_sample_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dm, m, hid, M, hidden,
+                     channels, v1, v2, relu, dz2, dz1, dmd);
   int rc = sisr_check_launch();
   if (rc) return rc;
   const long total = (long)channels * hidden + (long)hidden * M + channels + hidden;

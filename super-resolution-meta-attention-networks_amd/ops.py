@@ -273,16 +273,17 @@ class _MetaGate(Function):
         B, M = md2.shape
         Hd, C = v1c.shape[0], v2c.shape[0]
         dev = md2.device
-        dv1, dc1 = torch.empty_like(v1c), torch.empty(Hd, device=dev)
-        dv2, dc2 = torch.empty_like(v2c), torch.empty(C, device=dev)
+        s_md, s_v1, s_v2 = ctx.shapes
+        # allocated in the parameters' own shapes: a reshaped (view) gradient would be cloned by AccumulateGrad
+        dv1, dc1 = torch.empty(s_v1, device=dev), torch.empty(Hd, device=dev)
+        dv2, dc2 = torch.empty(s_v2, device=dev), torch.empty(C, device=dev)
         dmd = torch.empty_like(md2) if ctx.needs_input_grad[0] else None
         rc = hip.lib().sisr_meta_gate_bwd(hip.ptr(dm.contiguous()), hip.ptr(m), hip.ptr(hid), hip.ptr(md2), B, M, Hd, C,
                                           hip.ptr(v1c), hip.ptr(v2c), int(ctx.relu), hip.ptr(dv1), hip.ptr(dc1),
                                           hip.ptr(dv2), hip.ptr(dc2), hip.ptr(dmd), hip.ptr(_vec(B, Hd + C, dev)),
                                           hip.stream())
         hip.check(rc, "sisr_meta_gate_bwd")
-        s_md, s_v1, s_v2 = ctx.shapes
-        return (dmd.reshape(s_md) if dmd is not None else None, dv1.reshape(s_v1), dc1, dv2.reshape(s_v2), dc2, None)
+        return (dmd.reshape(s_md) if dmd is not None else None, dv1, dc1, dv2, dc2, None)
 
 
 def meta_gate(md, v1, c1, v2, c2, relu):
@@ -372,14 +373,13 @@ class _ResBlock(Function):
                     R = caw1c.shape[0]
                     shift = _vec(B, 64, dev)
                     dmv = _vec(B, 64, dev) if has_m else None
-                    dcaw1, dcab1 = torch.empty_like(caw1c), torch.empty(R, device=dev)
-                    dcaw2, dcab2 = torch.empty_like(caw2c), torch.empty(64, device=dev)
+                    dcaw1, dcab1 = torch.empty(s_caw1, device=dev), torch.empty(R, device=dev)
+                    dcaw2, dcab2 = torch.empty(s_caw2, device=dev), torch.empty(64, device=dev)
                     rc = L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
                                             hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
                                             hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
                                             hip.ptr(_vec(B, 80, dev)), hip.stream())
                     hip.check(rc, "sisr_ca_gate_bwd")
-                    dcaw1, dcaw2 = dcaw1.reshape(s_caw1), dcaw2.reshape(s_caw2)
                     dm, scale = dmv, g
                 else:
                     g = sv[5]
