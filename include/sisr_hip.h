@@ -49,8 +49,8 @@ int sisr_pack_conv3x3(const float* w, float* packed, int cout, int cin, int64_t 
 int sisr_pack_conv3x3_both(const float* w, float* packed_fwd, float* packed_dgrad, int cout, int cin, int shuffle_r,
                            void* stream);
 int sisr_conv3x3_c64_gap_parts(int H, int W);
-int sisr_conv3x3_c64_set_stagger(int units); /* tuning knob: first-round start offset between co-resident workgroups */
-int sisr_conv3x3_c64_set_variant(int v); /* tuning knob: 0 padded LDS, 1 + deeper A prefetch, 2 swizzled LDS, 3 WG/CU */
+int sisr_conv3x3_c64_set_variant(int v); /* 4 issue-lean kernel + general fallback (default), 2 general kernel only,
+                                             13 / 16 diagnostic builds (no operand loads / phase stamps) */
 int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked, const float* bias, int bias_n,
                      int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,
                      const float* in_scale, const float* in_shift, const float* out_scale, float alpha, int relu,
@@ -59,7 +59,6 @@ int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked,
 /* ---- 3x3 convolution weight + bias gradient (fp32 MFMA), deterministic two-stage reduction ------
  * ref: autograd's convolution_backward for default_conv (loss.backward(), SISR/models/__init__.py:483).
  *   dW = alpha * sum X (x) dY',  db = alpha * sum dY',  dY' = dY*dy_scale[b][co] + dy_shift[b][co] */
-int sisr_wgrad3x3_c64_set_stagger(int units); /* tuning knob, see sisr_conv3x3_c64_set_stagger */
 size_t sisr_wgrad3x3_c64_workspace_bytes(int B, int H, int W, int cin, int cout);
 int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
                       const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so, int64_t si,

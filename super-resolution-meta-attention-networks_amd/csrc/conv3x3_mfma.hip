@@ -44,23 +44,21 @@ struct ConvParams {
   float alpha;
   int bias_n, bias_q;
   int B, H, W, cin_chunks, cout_chunks, relu, tiles_w, tiles_h;
-  int stagger;  // first-round workgroups sharing a CU start (slot * stagger) * ~3.5 us apart (0 = off)
 };
 
-// Variants (A/B-able in one process through sisr_conv3x3_c64_set_variant; the default is the fastest measured):
-//   0  padded LDS (68-float pixel stride), A fragments one step ahead, 2 workgroups per CU
-//   1  as 0 with A fragments two steps ahead
-//   2  XOR-swizzled LDS (64-float stride: 16-B chunk k of halo pixel p lives at slot k ^ (p & 15)),
-//      52 KB per workgroup so THREE workgroups fit a CU (register budget 168), A two steps ahead
-// ABL (diagnostic builds only, selected with variant ids 10+): 1 no B loads, 2 no A reads, 3 neither,
-// 4 no halo staging loads, 5 no epilogue stores, 6 phase stamps (s_memtime at start / after staging / after
-// the K loop / at the end, written per workgroup into the gap buffer as uint32 cycles).  Outputs of ablated
-// builds are meaningless.
-template <int V, int ABL = 0, bool PRIO = true>
-__global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(ConvParams p) {
-  constexpr int PSTR = (V == 2) ? 64 : 68;
-  constexpr int AD = (V == 0) ? 1 : 2;  // A prefetch distance in K-steps
-  constexpr int BD = (V == 2) ? 6 : 4;  // B prefetch distance in K-steps (8-slot ring)
+// General kernel: every prologue / epilogue combination, XOR-swizzled LDS (16-B chunk k of halo pixel p lives
+// at slot k ^ (p & 15)), 52 KB per workgroup so three fit a CU (register budget 168), rolled tap loop with A two
+// and B six K-steps ahead.  The hot combinations run on the leaner conv3x3_c64_v4_kernel below; this one stays
+// as the fallback and as the carrier of the diagnostic builds that led to it:
+// ABL (selected with sisr_conv3x3_c64_set_variant 13 / 16): 3 = no A and no B loads (pure MFMA + staging + stores),
+// 6 = phase stamps (s_memtime at start / after staging / after the K loop / at the end, written per wave into the
+// gap buffer as uint32 cycles).  Outputs of ABL builds are meaningless.
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
+  constexpr int V = 2;
+  constexpr int PSTR = 64;
+  constexpr int AD = 2;  // A prefetch distance in K-steps
+  constexpr int BD = 6;  // B prefetch distance in K-steps (8-slot ring)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -87,26 +85,8 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
   unsigned long long st0 = 0, st1 = 0, st2 = 0;
   if (ABL == 6) st0 = __builtin_amdgcn_s_memtime();
 
-  // All workgroups do identical work, so the three that share a CU would otherwise run in lockstep and
-  // their halo-load / store phases would coincide instead of hiding under each other's MFMA phase.
-  // First-round waves start (hardware wave slot on their SIMD) x stagger apart; the slot id comes from
-  // HW_REG_HW_ID[3:0], so co-resident waves always differ whatever the block -> CU placement is.  Speed only.
-  if (p.stagger > 0 && blockIdx.y == 0 && blockIdx.x < 768) {
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3;  // size 4, offset 0, HW_ID
-    for (unsigned k = 0; k < slot * p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
-  }
-
-  // Issue priority.  Measured with in-kernel stamps (tools/conv_phases.py): while the other two waves of a
-  // SIMD stream fp32 MFMAs, a wave in its staging or store phase got roughly one VALU/VMEM issue slot per
-  // MFMA and those phases took 49k + 28k cycles of a 130k-cycle workgroup lifetime (K loop: 53k), leaving
-  // the matrix pipe idle ~20 % of the time.  Raising the priority of the short non-MFMA phases lets them
-  // take the issue slots between the older waves' MFMAs (separate pipes) and get out of the way.
-  if (V == 2 && PRIO) __builtin_amdgcn_s_setprio(3);
   for (int c = 0; c < p.cin_chunks; ++c) {
-    if (c) {
-      __syncthreads();  // previous chunk's A reads are done before the halo is overwritten
-      if (V == 2 && PRIO) __builtin_amdgcn_s_setprio(3);
-    }
+    if (c) __syncthreads();  // previous chunk's A reads are done before the halo is overwritten
     // ---- stage the halo of input chunk c: global -> VGPR -> LDS (16 lanes x 16 B per pixel)
     {
       // Branch-free: out-of-image taps load a clamped (valid) address and are zeroed by a select, so
@@ -128,8 +108,8 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
         const int gh = h0 - 1 + pr, gw = w0 - 1 + pc;
         const bool ok = gh >= 0 && gh < H && gw >= 0 && gw < W;
         const int ch_ = min(max(gh, 0), H - 1), cw_ = min(max(gw, 0), W - 1);
-        f32x4 t = {1.f, 2.f, 3.f, 4.f};
-        if (ABL != 4) t = *reinterpret_cast<const f32x4*>(xb + (long)ch_ * p.xv.sH + (long)cw_ * p.xv.sW + c4 * 4);
+        f32x4 t;
+        t = *reinterpret_cast<const f32x4*>(xb + (long)ch_ * p.xv.sH + (long)cw_ * p.xv.sW + c4 * 4);
         v[it] = sisr_keep_if(t * s4 + t4, ok);  // zero padding stays zero: the affine is for in-image pixels only
       }
 #pragma unroll
@@ -141,7 +121,6 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
       }
     }
     __syncthreads();
-    if (V == 2 && PRIO) __builtin_amdgcn_s_setprio(0);
     if (ABL == 6) st1 = __builtin_amdgcn_s_memtime();
 
     // ---- 72 K-steps (9 taps x 8 octets of input channels), 8 MFMAs each
@@ -151,11 +130,11 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
     auto load_a = [&](int m, int t, int j) -> f32x4 {
       const int pix = pix0 + (t / 3 + m) * HALO_W + (t % 3);
       const int slot = (V == 2) ? ((2 * j + hh) ^ (pix & 15)) : (2 * j + hh);
-      if (ABL == 2 || ABL == 3) return (f32x4){(float)pix, 1.f, (float)slot, 2.f};
+      if (ABL == 3) return (f32x4){(float)pix, 1.f, (float)slot, 2.f};
       return *reinterpret_cast<const f32x4*>(lds + pix * PSTR + slot * 4);
     };
     auto load_b = [&](int s) -> f32x4 {  // K-step s = tap*8 + j; clamped so the run-ahead never leaves the buffer
-      if (ABL == 1 || ABL == 3) return (f32x4){(float)s, 1.f, (float)hh, 3.f};
+      if (ABL == 3) return (f32x4){(float)s, 1.f, (float)hh, 3.f};
       return *reinterpret_cast<const f32x4*>(wq + min(s, 71) * 512);
     };
     // Software pipeline over K-steps s = tap*8 + j (8 MFMAs each): B (global/L2) BD steps ahead in an
@@ -198,7 +177,6 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
   }
 
   if (ABL == 6) st2 = __builtin_amdgcn_s_memtime();
-  if (V == 2 && PRIO) __builtin_amdgcn_s_setprio(3);
   // ---- epilogue.  C/D map of the 32x32 tile: column (= output channel) on the lane, pixel
   // (r&3) + 8*(r>>2) + 4*(lane>>5) in register r.
   const int co = ch * 32 + n;
@@ -222,7 +200,7 @@ __global__ __launch_bounds__(256, (V == 2 ? 3 : 2)) void conv3x3_c64_kernel(Conv
         const long off = ybase + (long)row * p.yv.sH + (long)col * p.yv.sW;
         if (p.mask) v = p.mask[off] > 0.f ? v : 0.f;
         if (p.res) v += p.res[off];
-        if (ABL != 5) p.y[off] = v;
+        p.y[off] = v;
         gsum += v;
       }
     }
@@ -526,16 +504,11 @@ extern "C" int sisr_pack_conv3x3_both(const float* w, float* packed_fwd, float* 
   return sisr_check_launch();
 }
 
-// Tuning knob (process-wide, read-only during launches): which conv3x3_c64 variant to run.
+// Kernel selection (process-wide, read-only during launches): 4 = issue-lean kernel with the general kernel as
+// fallback (default), 2 = general kernel only, 13 / 16 = diagnostic builds of the general kernel (see above).
 static int g_conv_variant = 4;
-static int g_conv_stagger = 0;  // measured: no gain once clocks are warm (profiles/r01 notes)
-extern "C" int sisr_conv3x3_c64_set_stagger(int units) {
-  if (units < 0 || units > 64) return SISR_ERR_ARG;
-  g_conv_stagger = units;
-  return SISR_OK;
-}
 extern "C" int sisr_conv3x3_c64_set_variant(int v) {
-  if (!((v >= 0 && v <= 4) || (v >= 11 && v <= 17))) return SISR_ERR_ARG;
+  if (v != 4 && v != 2 && v != 13 && v != 16) return SISR_ERR_ARG;
   g_conv_variant = v;
   return SISR_OK;
 }
@@ -576,7 +549,6 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   p.relu = relu;
   p.tiles_w = (W + TW - 1) / TW;
   p.tiles_h = (H + TH - 1) / TH;
-  p.stagger = g_conv_stagger;
   const long nblk = (long)p.tiles_w * p.tiles_h * B;
   if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
   const dim3 grid((unsigned)nblk, p.cout_chunks);
@@ -595,30 +567,15 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
         hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false>), grid, dim3(256), lb, st, p);
       return sisr_check_launch();
     }
-    hipLaunchKernelGGL(conv3x3_c64_kernel<2>, grid, dim3(256), lb, st, p);
+    hipLaunchKernelGGL(conv3x3_c64_kernel<0>, grid, dim3(256), lb, st, p);
     return sisr_check_launch();
   }
-  switch (g_conv_variant) {
-    case 0:
-      hipLaunchKernelGGL(conv3x3_c64_kernel<0>, grid, dim3(256), HALO_H * HALO_W * 68 * sizeof(float),
-                         (hipStream_t)stream, p);
-      break;
-    case 1:
-      hipLaunchKernelGGL(conv3x3_c64_kernel<1>, grid, dim3(256), HALO_H * HALO_W * 68 * sizeof(float),
-                         (hipStream_t)stream, p);
-      break;
-    case 11: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 1>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
-    case 12: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 2>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
-    case 13: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 3>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
-    case 14: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 4>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
-    case 3: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 0, false>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
-    case 17: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 6, false>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
-    case 16: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 6>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
-    case 15: hipLaunchKernelGGL((conv3x3_c64_kernel<2, 5>), grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float), (hipStream_t)stream, p); break;
-    default:
-      hipLaunchKernelGGL(conv3x3_c64_kernel<2>, grid, dim3(256), HALO_H * HALO_W * 64 * sizeof(float),
-                         (hipStream_t)stream, p);
-      break;
-  }
+  const size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
+  if (g_conv_variant == 13)
+    hipLaunchKernelGGL(conv3x3_c64_kernel<3>, grid, dim3(256), lb, (hipStream_t)stream, p);
+  else if (g_conv_variant == 16)
+    hipLaunchKernelGGL(conv3x3_c64_kernel<6>, grid, dim3(256), lb, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(conv3x3_c64_kernel<0>, grid, dim3(256), lb, (hipStream_t)stream, p);
   return sisr_check_launch();
 }

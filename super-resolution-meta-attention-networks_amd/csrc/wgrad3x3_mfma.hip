@@ -41,7 +41,6 @@ struct WgradParams {
   float* slabs;      // [S][gridDim.y][SLAB]
   float* bias_slabs; // [S][cout_chunks*2][32] (written by ci-quadrant 0 of cin chunk 0) or null
   int B, H, W, cin_chunks, cout_chunks, tiles_w, tiles_h, S;
-  int stagger;  // the second workgroup of each CU starts `stagger` * ~3.5 us later (0 = off)
 };
 
 __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) {
@@ -63,14 +62,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) {
   for (int t = 0; t < 9; ++t) acc[t] = (f32x16){0};
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};  // this thread's 4 channels (tid&7) of the dY column sums
 
-  // The two workgroups that share a CU do identical work; offset the second one so that its staging phases
-  // fall under the first one's MFMA phases instead of coinciding with them (speed-only assumption about
-  // placement: linear block ids b and b+256 share a CU).
-  if (p.stagger > 0) {
-    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-    if ((lin >> 8) & 1)
-      for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
-  }
   const int tiles_per_img = p.tiles_w * p.tiles_h;
   const int total = tiles_per_img * p.B;
   for (int tile = blockIdx.x; tile < total; tile += p.S) {
@@ -272,13 +263,6 @@ static int wgrad_split(int B, int H, int W, int units) {
   return (int)S;
 }
 
-static int g_wgrad_stagger = 0;
-extern "C" int sisr_wgrad3x3_c64_set_stagger(int units) {
-  if (units < 0 || units > 64) return SISR_ERR_ARG;
-  g_wgrad_stagger = units;
-  return SISR_OK;
-}
-
 extern "C" size_t sisr_wgrad3x3_c64_workspace_bytes(int B, int H, int W, int cin, int cout) {
   if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
   const int units = (cin / 64) * (cout / 64) * 4;
@@ -315,7 +299,6 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   p.tiles_h = (H + WT_H - 1) / WT_H;
   const int units = p.cin_chunks * p.cout_chunks * 4;
   p.S = wgrad_split(B, H, W, units);
-  p.stagger = g_wgrad_stagger;
   p.slabs = workspace;
   p.bias_slabs = dbias ? workspace + (size_t)p.S * units * SLAB : nullptr;
   const size_t lds_bytes = (size_t)(LDS_X + LDS_Y) * sizeof(float);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-workgroup phase durations of conv3x3_c64 (stamped build, variant 16)."""
+"""Diagnostic: per-workgroup phase durations of the general conv3x3_c64 kernel (stamped build, variant 16)."""
 import json
 import os
 import sys

@@ -37,10 +37,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--hw", type=int, default=128)
     ap.add_argument("--only", default="")
-    ap.add_argument("--variants", default="0,1,2")
-    ap.add_argument("--stagger", default="")
+    ap.add_argument("--variants", default="4,2")
     ap.add_argument("--rounds", type=int, default=0, help="interleaved A/B rounds over --variants (conv only)")
-    ap.add_argument("--wstagger", default="")
     a = ap.parse_args()
     only = set(a.only.split(",")) if a.only else None
     B, H, W = a.batch, a.hw, a.hw
@@ -64,8 +62,7 @@ def main():
     res = {}
 
     def run(name, fn, work, unit):
-        if only and name not in only and name.split("_v")[0] not in only and name.split("_stagger")[0] not in only \
-                and name.split("_stagger")[0] + "_stagger" not in only:
+        if only and name not in only and name.split("_v")[0] not in only:
             return
         t = timeit(fn, a.iters)
         res[name] = {"us": t * 1e6, unit: work / t / (1e12 if unit == "TFLOP/s" else 1e9)}
@@ -93,19 +90,11 @@ def main():
             run(f"conv_dgrad2_v{var}", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1,
                                                             in_scale=sc, in_shift=sh), flop, "TFLOP/s")
     hip.lib().sisr_conv3x3_c64_set_variant(4)
-    for st in [int(t) for t in a.stagger.split(",") if t]:
-        hip.lib().sisr_conv3x3_c64_set_stagger(st)
-        run(f"conv_stagger{st}", lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64), flop, "TFLOP/s")
-    hip.lib().sisr_conv3x3_c64_set_stagger(0)
     run("conv_relu_gap", lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64, relu=True, gap=gap), flop,
         "TFLOP/s")
     run("conv_dgrad2", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1, in_scale=sc,
                                             in_shift=sh), flop, "TFLOP/s")
     run("conv_res", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, res=x), flop, "TFLOP/s")
-    for st in [int(t) for t in a.wstagger.split(",") if t]:
-        hip.lib().sisr_wgrad3x3_c64_set_stagger(st)
-        run(f"wgrad_stagger{st}", lambda: ops.wgrad_c64(x, v, dy, v, dw, db, B, H, W, 64, 64), flop, "TFLOP/s")
-    hip.lib().sisr_wgrad3x3_c64_set_stagger(0)
     run("wgrad", lambda: ops.wgrad_c64(x, v, dy, v, dw, db, B, H, W, 64, 64), flop, "TFLOP/s")
     run("wgrad_affine", lambda: ops.wgrad_c64(x, v, dy, v, dw, db, B, H, W, 64, 64, dy_scale=sc, dy_shift=sh), flop,
         "TFLOP/s")
