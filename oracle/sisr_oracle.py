@@ -280,8 +280,201 @@ def qhan(sd, x, md, n_resgroups=10, n_resblocks=20, scale=4, num_q_layers_inner_
     return _han_tail(sd, h, layers, scale)
 
 
-NETS = {"rcan": rcan, "edsr": edsr, "han": han, "qrcan": qrcan, "qedsr": qedsr, "qhan": qhan}
-META_NETS = ("qrcan", "qedsr", "qhan")
+# ----------------------------------------------------------------------------- SAN: second-order + non-local attention
+class _CovPool(torch.autograd.Function):
+    """Covariance pooling  X I^ X^T  with I^ = I/M - 11^T/M^2  (ref: advanced/mpncov.py:12-47).
+    The reference materialises the M x M matrix I^; X I^ is simply (X - rowmean(X)) / M, which is what is
+    computed here (identical algebra, no M^2 memory).  Backward is the reference's: (G + G^T) X I^."""
+
+    @staticmethod
+    def forward(ctx, x):
+        b, c, h, w = x.shape
+        rows = x.reshape(b, c, h * w)
+        centred = (rows - rows.mean(dim=2, keepdim=True)) / (h * w)
+        ctx.save_for_backward(centred)
+        ctx.shape = x.shape
+        return centred.bmm(rows.transpose(1, 2))
+
+    @staticmethod
+    def backward(ctx, g):
+        (centred,) = ctx.saved_tensors
+        return (g + g.transpose(1, 2)).bmm(centred).reshape(ctx.shape)
+
+
+class _SqrtmNS(torch.autograd.Function):
+    """Matrix square root by coupled Newton-Schulz iteration with trace pre-normalisation and sqrt(trace)
+    post-compensation; hand-derived backward (ref: advanced/mpncov.py:49-112).  iterN >= 2 only (SOCA uses 5)."""
+
+    @staticmethod
+    def forward(ctx, a, n_iter):
+        b, d, _ = a.shape
+        eye3 = 3.0 * torch.eye(d, dtype=a.dtype).expand(b, d, d)
+        tr = a.diagonal(dim1=1, dim2=2).sum(dim=1)
+        an = a / tr.view(b, 1, 1)
+        zy = 0.5 * (eye3 - an)
+        ys, zs = [an.bmm(zy)], [zy]
+        for _ in range(1, n_iter - 1):
+            zy = 0.5 * (eye3 - zs[-1].bmm(ys[-1]))
+            ys.append(ys[-1].bmm(zy))
+            zs.append(zy.bmm(zs[-1]))
+        last = 0.5 * ys[-1].bmm(eye3 - zs[-1].bmm(ys[-1]))
+        ctx.save_for_backward(a, an, last, tr, torch.stack(ys, 1), torch.stack(zs, 1))
+        return last * tr.sqrt().view(b, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, an, last, tr, ys, zs = ctx.saved_tensors
+        b, d, _ = a.shape
+        eye3 = 3.0 * torch.eye(d, dtype=a.dtype).expand(b, d, d)
+        rt = tr.sqrt()
+        gp = g * rt.view(b, 1, 1)                                   # through the post-compensation
+        aux = (g * last).sum(dim=(1, 2)) / (2.0 * rt)               # d/d(trace) of sqrt(trace)
+        k = ys.shape[1] - 1
+        yk, zk = ys[:, k], zs[:, k]
+        dy = 0.5 * (gp.bmm(eye3 - yk.bmm(zk)) - zk.bmm(yk).bmm(gp))
+        dz = -0.5 * yk.bmm(gp).bmm(yk)
+        for i in range(k - 1, -1, -1):
+            yi, zi = ys[:, i], zs[:, i]
+            yz = eye3 - yi.bmm(zi)
+            zyi = zi.bmm(yi)
+            dy, dz = (0.5 * (dy.bmm(yz) - zi.bmm(dz).bmm(zi) - zyi.bmm(dy)),
+                      0.5 * (yz.bmm(dz) - yi.bmm(dy).bmm(yi) - dz.bmm(zyi)))
+        dn = 0.5 * (dy.bmm(eye3 - an) - dz - an.bmm(dy))
+        ga = dn / tr.view(b, 1, 1)
+        diag = aux - (dn * a).sum(dim=(1, 2)) / (tr * tr)           # trace normalisation + post-compensation
+        return ga + diag.view(b, 1, 1) * torch.eye(d, dtype=a.dtype), None
+
+
+def cov_sqrt(x, n_iter=5):
+    """(B,C,H,W) -> (B,C,C): sqrtm(covpool(x)).  ref: advanced/SAN_blocks.py:290-291."""
+    return _SqrtmNS.apply(_CovPool.apply(x), n_iter)
+
+
+def _soca_window(x, limit=1000):
+    """Centre crop applied before pooling when a side exceeds 1000 (ref: advanced/SAN_blocks.py:264-280); the
+    branch structure (strict comparisons, Python slice semantics for a negative start) is kept as is."""
+    h, w = x.shape[2:]
+    if h < limit and w < limit:
+        return x
+    if h < limit and w > limit:
+        w0 = (w - limit) // 2
+        return x[:, :, :, w0:w0 + limit]
+    if w < limit and h > limit:
+        h0 = (h - limit) // 2
+        return x[:, :, h0:h0 + limit, :]
+    h0, w0 = (h - limit) // 2, (w - limit) // 2
+    return x[:, :, h0:h0 + limit, w0:w0 + limit]
+
+
+def soca(sd, key, x):
+    """Second-order channel attention.  ref: advanced/SAN_blocks.py:244-302: gate = conv_du(mean over rows of
+    sqrtm(cov(x))), output gate * x."""
+    b, c = x.shape[:2]
+    pooled = cov_sqrt(_soca_window(x)).mean(dim=1).view(b, c, 1, 1)
+    gate = torch.sigmoid(_fc(sd, key + ".conv_du.2", F.relu(_fc(sd, key + ".conv_du.0", pooled))))
+    return gate * x
+
+
+def nonlocal_block(sd, key, x):
+    """Embedded-Gaussian non-local block (ref: advanced/SAN_blocks.py:104-148):
+    z = W(softmax(theta(x)^T phi(x)) g(x)) + x with 1x1 projections to C/8 channels.
+    In the 2-D block the constructor's local `sub_sample` is rebound to the nn.Upsample class (:40), which is
+    truthy, so phi and g are ALWAYS followed by MaxPool2d(2) (:88-93, state_dict keys `phi.0`, `g.0`) although
+    Nonlocal_CA passes sub_sample=False: queries are all positions, keys/values the 2x2-max-pooled ones."""
+    b, _, h, w = x.shape
+    ci = sd[key + ".g.0.weight"].shape[0]
+    g = F.max_pool2d(F.conv2d(x, sd[key + ".g.0.weight"], sd[key + ".g.0.bias"]), 2).reshape(b, ci, -1).transpose(1, 2)
+    th = F.conv2d(x, sd[key + ".theta.weight"], sd[key + ".theta.bias"]).reshape(b, ci, h * w).transpose(1, 2)
+    ph = F.max_pool2d(F.conv2d(x, sd[key + ".phi.0.weight"], sd[key + ".phi.0.bias"]), 2).reshape(b, ci, -1)
+    att = torch.softmax(th.bmm(ph), dim=-1)
+    y = att.bmm(g).transpose(1, 2).reshape(b, ci, h, w)
+    return F.conv2d(y, sd[key + ".W.weight"], sd[key + ".W.bias"]) + x
+
+
+def nonlocal_ca(sd, key, x):
+    """Non-local attention applied independently to the four quadrants split at (H//2, W//2).
+    ref: advanced/SAN_blocks.py:314-336.  The module's `soca` child is never called."""
+    h1, w1 = x.shape[2] // 2, x.shape[3] // 2
+    rows = []
+    for hs in (slice(0, h1), slice(h1, None)):
+        rows.append(torch.cat([nonlocal_block(sd, key + ".non_local", x[:, :, hs, ws])
+                               for ws in (slice(0, w1), slice(w1, None))], dim=3))
+    return torch.cat(rows, dim=2)
+
+
+def rb(sd, key, x):
+    """ref: advanced/SAN_blocks.py:359-363: conv(relu(conv(x))) + x."""
+    return conv(sd, key + ".conv_first.2", F.relu(conv(sd, key + ".conv_first.0", x))) + x
+
+
+def lsrag(sd, key, x, n_resblocks):
+    """ref: advanced/SAN_blocks.py:394-412: RB^n -> SOCA -> conv_last, + x (the group's gamma is unused)."""
+    r = x
+    for i in range(n_resblocks):
+        r = rb(sd, f"{key}.rcab.{i}", r)
+    return conv(sd, key + ".conv_last", soca(sd, key + ".soca", r)) + x
+
+
+def qrb(sd, key, x, md):
+    """ref: attention_manipulators/qsan_blocks.py:29-34: meta gate (ReLU variant) between conv pair and skip."""
+    r = conv(sd, key + ".conv_first.2", F.relu(conv(sd, key + ".conv_first.0", x)))
+    return para_ca_layer(sd, key + ".q_layer", r, md, True) + x
+
+
+def qlsrag(sd, key, x, md, n_resblocks):
+    """ref: attention_manipulators/qsan_blocks.py:66-85."""
+    r = x
+    for i in range(n_resblocks):
+        r = qrb(sd, f"{key}.rcab.{i}", r, md)
+    return conv(sd, key + ".conv_last", soca(sd, key + ".soca", r)) + x
+
+
+def san(sd, x, n_resgroups=20, n_resblocks=10, scale=4):
+    """ref: advanced/architectures.py:291-312.  One Nonlocal_CA is applied twice (shared weights); every group
+    adds gamma * (the first non-local output); SAN.conv_last is never used."""
+    h = conv(sd, "head.0", x)
+    shared = nonlocal_ca(sd, "non_local", h)
+    r = shared
+    for g in range(n_resgroups):
+        r = lsrag(sd, f"RG.{g}", r, n_resblocks) + sd["gamma"] * shared
+    r = nonlocal_ca(sd, "non_local", r) + h
+    return conv(sd, "tail.1", upsampler(sd, "tail.0", r, scale))
+
+
+def qsan(sd, x, md, n_resgroups=20, n_resblocks=10, scale=4):
+    """ref: attention_manipulators/architectures.py:449-467."""
+    h = conv(sd, "head.0", x)
+    shared = nonlocal_ca(sd, "non_local", h)
+    r = shared
+    for g in range(n_resgroups):
+        r = qlsrag(sd, f"RG.{g}", r, md, n_resblocks) + sd["gamma"] * shared
+    r = nonlocal_ca(sd, "non_local", r) + h
+    return conv(sd, "tail.1", upsampler(sd, "tail.0", r, scale))
+
+
+def chop_forward(run, x, scale, max_pixels=160000, shave=10):
+    """Overlapping 4-way tiling used by the SAN / QSAN handlers at evaluation time
+    (ref: advanced/handlers.py:80-118, attention_manipulators/handlers.py:99-137): corners of size
+    (h//2 + shave, w//2 + shave), recursion while a corner holds >= max_pixels, seams cut at the half points."""
+    b, c, h, w = x.shape
+    hh, wh = h // 2, w // 2
+    hs, ws = hh + shave, wh + shave
+    corners = [x[:, :, :hs, :ws], x[:, :, :hs, w - ws:], x[:, :, h - hs:, :ws], x[:, :, h - hs:, w - ws:]]
+    if hs * ws < max_pixels:
+        sr = [run(t) for t in corners]
+    else:
+        sr = [chop_forward(run, t, scale, max_pixels, shave) for t in corners]
+    H, W, hh, wh, hs, ws = scale * h, scale * w, scale * hh, scale * wh, scale * hs, scale * ws
+    out = x.new_empty(b, sr[0].shape[1], H, W)
+    out[:, :, :hh, :wh] = sr[0][:, :, :hh, :wh]
+    out[:, :, :hh, wh:] = sr[1][:, :, :hh, ws - W + wh:ws]
+    out[:, :, hh:, :wh] = sr[2][:, :, hs - H + hh:hs, :wh]
+    out[:, :, hh:, wh:] = sr[3][:, :, hs - H + hh:hs, ws - W + wh:ws]
+    return out
+
+
+NETS = {"rcan": rcan, "edsr": edsr, "han": han, "san": san, "qrcan": qrcan, "qedsr": qedsr, "qhan": qhan, "qsan": qsan}
+META_NETS = ("qrcan", "qedsr", "qhan", "qsan")
 
 
 def forward(name, sd, x, metadata=None, **cfg):
@@ -392,7 +585,8 @@ class Trainer:
         loss.backward()
         if self.grad_clip is not None:
             torch.nn.utils.clip_grad_norm_(list(self.sd.values()), self.grad_clip)
-        gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in self.sd.values())).item()  # post-clip
+        gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in self.sd.values()
+                               if p.grad is not None)).item()  # post-clip; SAN holds parameters its forward never uses
         self.opt.step()
         if self.sched is not None:
             self.sched.step()
