@@ -134,6 +134,32 @@ size_t sisr_csam_bwd_workspace_bytes(int B, int H, int W, int C);
 int sisr_csam_bwd(const float* x, const float* w27, const float* bias, const float* gamma, const float* dy, float* dx,
                   float* dw27, float* dbias, float* dgamma, float* workspace, int B, int H, int W, int C, void* stream);
 
+/* ---- SAN attention modules ---------------------------------------------------------------------
+ * Second-order channel attention, ref: advanced/SAN_blocks.py:244-302 SOCA + advanced/mpncov.py:12-112.
+ *   covpool_fwd : cov[b] = (1/M) sum_p (x_p - mean[b]) x_p^T      x [B][M][64] channels-last, mean [B][64]
+ *                 (= Covpool.forward's X I^ X^T without the M x M matrix)
+ *   sqrtm_fwd   : Newton-Schulz square root (trace pre-normalised, `iters` iterations, post-compensated) and the
+ *                 column means SOCA feeds to its gate: pooled [B][64]; `saved` keeps the iterates for backward
+ *   sqrtm_bwd   : Sqrtm.backward from dL/dpooled; returns G + G^T (the form Covpool.backward consumes)
+ *   soca_bwd_apply : dx = dy * gate[b,c] + (1/M) (G + G^T)(x - mean)   -- `y_cov * x` plus Covpool.backward
+ * Non-local attention, ref: advanced/SAN_blocks.py:126-141 (_embedded_gaussian: f = theta^T phi, softmax over
+ * keys, y = f g): theta [nb][nq][8], phi / g [nb][nk][8]; streaming softmax, lse [nb][nq] kept for backward,
+ * dsum [nb][nq] is scratch. */
+size_t sisr_covpool_workspace_bytes(int B, long hw);
+int sisr_covpool_fwd(const float* x, const float* mean, float* cov, float* workspace, int B, long hw, int channels,
+                     void* stream);
+size_t sisr_sqrtm_saved_bytes(int B, int dim, int iters);
+int sisr_sqrtm_fwd(const float* cov, float* saved, float* pooled, int B, int dim, int iters, void* stream);
+int sisr_sqrtm_bwd(const float* cov, const float* saved, const float* dpooled, float* dcov_sym, int B, int dim,
+                   int iters, void* stream);
+int sisr_soca_bwd_apply(const float* dy, const float* gate, const float* x, const float* mean, const float* dcov_sym,
+                        float* dx, int B, long hw, int channels, void* stream);
+int sisr_nl_attn_fwd(const float* theta, const float* phi, const float* g, float* y, float* lse, int nb, int nq, int nk,
+                     int dim, void* stream);
+int sisr_nl_attn_bwd(const float* theta, const float* phi, const float* g, const float* y, const float* lse,
+                     const float* dy, float* dtheta, float* dphi, float* dg, float* dsum, int nb, int nq, int nk,
+                     int dim, void* stream);
+
 /* ---- loss and optimiser ---------------------------------------------------------------------------
  * ref: SISR/models/__init__.py:268 nn.L1Loss, :299-308 optim.Adam, :481-489 standard_update */
 size_t sisr_l1_loss_workspace_bytes(void);

@@ -420,6 +420,11 @@ try:  # HAN / QHAN are registered once their attention kernels are built (han.py
     HANDLERS += [HANHandler, QHANHandler]
 except ImportError:
     pass
+try:  # SAN / QSAN (san.py)
+    from .san import SANHandler, QSANHandler
+    HANDLERS += [SANHandler, QSANHandler]
+except ImportError:
+    pass
 # registry key = class name minus 'Handler', lower-cased (ref: models/__init__.py:26-30)
 available_models = {h.__name__.split('Handler')[0].lower(): h for h in HANDLERS}
 

@@ -57,6 +57,16 @@ _SIGS.update({
     "sisr_csam_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "sisr_csam_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
 })
+_SIGS.update({  # SAN attention (csrc/san.hip)
+    "sisr_covpool_workspace_bytes": (c_size_t, [c_int, c_long]),
+    "sisr_covpool_fwd": (c_int, [P, P, P, P, c_int, c_long, c_int, P]),
+    "sisr_sqrtm_saved_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sisr_sqrtm_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "sisr_sqrtm_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "sisr_soca_bwd_apply": (c_int, [P, P, P, P, P, P, c_int, c_long, c_int, P]),
+    "sisr_nl_attn_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "sisr_nl_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+})
 
 
 class HipLibraryMissing(ImportError):

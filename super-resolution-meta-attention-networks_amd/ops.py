@@ -787,6 +787,165 @@ def conv3x3_stack(stack, weight, bias):
     return _ConvStack.apply(stack, weight, bias)
 
 
+# ----------------------------------------------------------------------------- SAN attention modules
+SOCA_LIMIT = 1000  # ref: advanced/SAN_blocks.py:265-266 (h1 = w1 = 1000)
+SOCA_ITERS = 5     # ref: advanced/SAN_blocks.py:291 SqrtmLayer(cov_mat, 5)
+
+
+def soca_window(H, W):
+    """Slices of the centre crop SOCA pools over when a side exceeds 1000 (ref: advanced/SAN_blocks.py:267-280,
+    strict comparisons and Python slice semantics kept); None when the whole map is used."""
+    lim = SOCA_LIMIT
+    if H < lim and W < lim:
+        return None
+    if H < lim and W > lim:
+        w0 = (W - lim) // 2
+        return slice(None), slice(w0, w0 + lim)
+    if W < lim and H > lim:
+        h0 = (H - lim) // 2
+        return slice(h0, h0 + lim), slice(None)
+    h0, w0 = (H - lim) // 2, (W - lim) // 2
+    return slice(h0, h0 + lim), slice(w0, w0 + lim)
+
+
+class _SOCA(Function):
+    """Second-order channel attention  y = x * sigmoid(W2 relu(W1 v + b1) + b2),  v = column means of
+    sqrtm(cov(x))  (ref: advanced/SAN_blocks.py:261-302; advanced/mpncov.py for cov / sqrtm and their
+    hand-written backward, which is what the kernels implement)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        B, C, H, W = x.shape
+        if C != 64:
+            raise NotImplementedError("SOCA kernels are specialised for 64 channels")
+        x = _cl(x)
+        dev = x.device
+        L = hip.lib()
+        win = soca_window(H, W)
+        xs = x if win is None else x[:, :, win[0], win[1]].contiguous(memory_format=CL)
+        hs, ws = xs.shape[2:]
+        M = hs * ws
+        part, parts = _pixel_sums(xs, None, B, hs, ws)
+        mean = _vec(B, 64, dev)
+        hip.check(L.sisr_sum_partials(hip.ptr(part), parts, B, 64, 1.0 / M, hip.ptr(mean), hip.stream()),
+                  "sisr_sum_partials")
+        cov = torch.empty((B, 64, 64), device=dev, dtype=torch.float32)
+        wsp = hip.workspace(dev, L.sisr_covpool_workspace_bytes(B, M))
+        hip.check(L.sisr_covpool_fwd(hip.ptr(xs), hip.ptr(mean), hip.ptr(cov), hip.ptr(wsp), B, M, 64, hip.stream()),
+                  "sisr_covpool_fwd")
+        saved = torch.empty(L.sisr_sqrtm_saved_bytes(B, 64, SOCA_ITERS) // 4, device=dev, dtype=torch.float32)
+        pooled = _vec(B, 64, dev)
+        hip.check(L.sisr_sqrtm_fwd(hip.ptr(cov), hip.ptr(saved), hip.ptr(pooled), B, 64, SOCA_ITERS, hip.stream()),
+                  "sisr_sqrtm_fwd")
+        R = w1.shape[0]
+        w1c, w2c = w1.reshape(R, 64).contiguous(), w2.reshape(64, R).contiguous()
+        s, hid, ca, g = _vec(B, 64, dev), _vec(B, R, dev), _vec(B, 64, dev), _vec(B, 64, dev)
+        hip.check(L.sisr_ca_gate_fwd(hip.ptr(pooled), 1, B, 1.0, hip.ptr(w1c), hip.ptr(b1.contiguous()), hip.ptr(w2c),
+                                     hip.ptr(b2.contiguous()), 64, R, None, hip.ptr(s), hip.ptr(hid), hip.ptr(ca),
+                                     hip.ptr(g), hip.stream()), "sisr_ca_gate_fwd")
+        ctx.save_for_backward(x, w1c, w2c, s, hid, ca, mean, cov, saved)
+        ctx.shapes, ctx.win = (w1.shape, w2.shape), win
+        return _affine(x, g, None, None, B, H, W, 64)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1c, w2c, s, hid, ca, mean, cov, saved = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dev = x.device
+        L = hip.lib()
+        R = w1c.shape[0]
+        dy = _cl(dy)
+        dgp, parts = _pixel_sums(dy, x, B, H, W)
+        dpooled = _vec(B, 64, dev)
+        dw1, db1 = torch.empty_like(w1c), torch.empty(R, device=dev)
+        dw2, db2 = torch.empty_like(w2c), torch.empty(64, device=dev)
+        hip.check(L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0, hip.ptr(w1c), hip.ptr(w2c), 64, R, hip.ptr(s),
+                                     hip.ptr(hid), hip.ptr(ca), None, hip.ptr(dpooled), None, hip.ptr(dw1),
+                                     hip.ptr(db1), hip.ptr(dw2), hip.ptr(db2), hip.ptr(_vec(B, 80, dev)), hip.stream()),
+                  "sisr_ca_gate_bwd")
+        dsym = torch.empty_like(cov)
+        hip.check(L.sisr_sqrtm_bwd(hip.ptr(cov), hip.ptr(saved), hip.ptr(dpooled), hip.ptr(dsym), B, 64, SOCA_ITERS,
+                                   hip.stream()), "sisr_sqrtm_bwd")
+        win = ctx.win
+        if win is None:
+            dx = _empty_cl(B, 64, H, W, dev)
+            hip.check(L.sisr_soca_bwd_apply(hip.ptr(dy), hip.ptr(ca), hip.ptr(x), hip.ptr(mean), hip.ptr(dsym),
+                                            hip.ptr(dx), B, H * W, 64, hip.stream()), "sisr_soca_bwd_apply")
+        else:  # covariance term only inside the pooled window (maps with a side > 1000: evaluation-size inputs)
+            dx = _affine(dy, ca, None, None, B, H, W, 64)
+            xs = x[:, :, win[0], win[1]].contiguous(memory_format=CL)
+            hs, ws = xs.shape[2:]
+            zero = torch.zeros_like(xs)
+            dwin = torch.empty_like(xs)
+            hip.check(L.sisr_soca_bwd_apply(hip.ptr(zero), hip.ptr(ca), hip.ptr(xs), hip.ptr(mean), hip.ptr(dsym),
+                                            hip.ptr(dwin), B, hs * ws, 64, hip.stream()), "sisr_soca_bwd_apply")
+            dx[:, :, win[0], win[1]] += dwin
+        return dx, dw1.reshape(ctx.shapes[0]), db1, dw2.reshape(ctx.shapes[1]), db2
+
+
+def soca(x, w1, b1, w2, b2):
+    return _SOCA.apply(x, w1, b1, w2, b2)
+
+
+class _NonLocalAttention(Function):
+    """y_i = sum_j softmax_j(theta_i . phi_j) g_j on [nb][n][8] rows (ref: advanced/SAN_blocks.py:126-141)."""
+
+    @staticmethod
+    def forward(ctx, theta, phi, g):
+        nb, nq, d = theta.shape
+        nk = phi.shape[1]
+        theta, phi, g = theta.contiguous(), phi.contiguous(), g.contiguous()
+        y = torch.empty_like(theta)
+        lse = torch.empty((nb, nq), device=theta.device, dtype=torch.float32)
+        hip.check(hip.lib().sisr_nl_attn_fwd(hip.ptr(theta), hip.ptr(phi), hip.ptr(g), hip.ptr(y), hip.ptr(lse), nb, nq,
+                                             nk, d, hip.stream()), "sisr_nl_attn_fwd")
+        ctx.save_for_backward(theta, phi, g, y, lse)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        theta, phi, g, y, lse = ctx.saved_tensors
+        nb, nq, d = theta.shape
+        nk = phi.shape[1]
+        dy = dy.contiguous()
+        dtheta, dphi, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
+        dsum = torch.empty_like(lse)
+        hip.check(hip.lib().sisr_nl_attn_bwd(hip.ptr(theta), hip.ptr(phi), hip.ptr(g), hip.ptr(y), hip.ptr(lse),
+                                             hip.ptr(dy), hip.ptr(dtheta), hip.ptr(dphi), hip.ptr(dg), hip.ptr(dsum), nb,
+                                             nq, nk, d, hip.stream()), "sisr_nl_attn_bwd")
+        return dtheta, dphi, dg
+
+
+def nonlocal_attention(theta, phi, g):
+    return _NonLocalAttention.apply(theta, phi, g)
+
+
+class _ScaleAdd(Function):
+    """y = a + gamma * r with a learnable scalar gamma (SAN's share-source skip, ref: advanced/architectures.py:301-302)."""
+
+    @staticmethod
+    def forward(ctx, a, r, gamma):
+        B, C, H, W = a.shape
+        a, r = _cl(a), _cl(r)
+        gv = gamma.reshape(1, 1).expand(B, C).contiguous()
+        ctx.save_for_backward(r, gv)
+        ctx.gshape = gamma.shape
+        return _affine(r, gv, None, a, B, H, W, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        r, gv = ctx.saved_tensors
+        B, C, H, W = r.shape
+        dy = _cl(dy)
+        dr = _affine(dy, gv, None, None, B, H, W, C)
+        dgp, _ = _pixel_sums(dy, r, B, H, W)
+        return dy, dr, dgp.sum().reshape(ctx.gshape)
+
+
+def scale_add(a, r, gamma):
+    return _ScaleAdd.apply(a, r, gamma)
+
+
 # ----------------------------------------------------------------------------- L1 loss
 class _L1Loss(Function):
     @staticmethod

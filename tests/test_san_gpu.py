@@ -1,0 +1,219 @@
+"""SAN / QSAN on the HIP kernels vs the reference's vectors and the oracle (pytest -m gpu).
+
+Tolerances, fp32: the covariance / Newton-Schulz chain amplifies summation-order noise a little more than a conv
+(five coupled 64x64 iterations), so the second-order gate is compared at 1e-4 relative; the whole-net and Set5 checks
+use the same bars as the other models (1e-3 dB Y-PSNR).
+"""
+import numpy as np
+import pytest
+import torch
+
+import sisr_amd
+from conftest import golden_json, load_golden
+from oracle import sisr_oracle as O
+from test_hip_gpu import DEV, close, net_vs_oracle, rnd, run_block
+from test_init_parity import set5
+
+pytestmark = pytest.mark.gpu
+A = sisr_amd.architectures
+S = sisr_amd.san
+ops = sisr_amd.ops
+hip = sisr_amd.hip
+
+NET_ZERO = ("non_local.non_local.W.weight", "non_local.non_local.W.bias", "gamma")
+
+
+def perturb(net, keys=NET_ZERO, seed=777, scale=0.05):
+    """tools/make_fixtures_san.py:randomize -- wake the zero-initialised attention branches deterministically."""
+    g = torch.Generator().manual_seed(seed)
+    named = dict(net.named_parameters())
+    with torch.no_grad():
+        for k in keys:
+            named[k].copy_((torch.randn(named[k].shape, generator=g) * scale).to(named[k].device))
+
+
+# ----------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("B,H,W", [(2, 10, 12), (1, 13, 9), (3, 64, 64), (1, 128, 128)])
+def test_covpool_kernel(B, H, W):
+    x = rnd(B, 64, H, W, seed=60) + 0.7
+    want = O._CovPool.apply(x.double())
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    L = hip.lib()
+    M = H * W
+    mean = xd.mean(dim=(2, 3)).contiguous()
+    cov = torch.empty(B, 64, 64, device=DEV)
+    ws = hip.workspace(xd.device, L.sisr_covpool_workspace_bytes(B, M))
+    hip.check(L.sisr_covpool_fwd(hip.ptr(xd), hip.ptr(mean), hip.ptr(cov), hip.ptr(ws), B, M, 64, hip.stream()), "cov")
+    close(cov, want, 2e-5, 2e-6, "covpool")
+
+
+def test_sqrtm_kernels_follow_the_reference_formulas():
+    """Forward column means and the hand-derived backward (mpncov.py:78-112) vs the oracle's restatement."""
+    B = 3
+    x = rnd(B, 64, 20, 20, seed=61)
+    cov = O._CovPool.apply(x).detach()
+    covo = cov.clone().requires_grad_(True)
+    pooled_ref = O._SqrtmNS.apply(covo, 5).mean(dim=1)
+    cot = rnd(B, 64, seed=62)
+    pooled_ref.backward(cot)
+    L = hip.lib()
+    cd = cov.to(DEV).contiguous()
+    saved = torch.empty(L.sisr_sqrtm_saved_bytes(B, 64, 5) // 4, device=DEV)
+    pooled = torch.empty(B, 64, device=DEV)
+    hip.check(L.sisr_sqrtm_fwd(hip.ptr(cd), hip.ptr(saved), hip.ptr(pooled), B, 64, 5, hip.stream()), "sqrtm_fwd")
+    close(pooled, pooled_ref, 5e-5, 5e-6, "sqrtm pooled")
+    dsym = torch.empty_like(cd)
+    hip.check(L.sisr_sqrtm_bwd(hip.ptr(cd), hip.ptr(saved), hip.ptr(cot.to(DEV)), hip.ptr(dsym), B, 64, 5,
+                               hip.stream()), "sqrtm_bwd")
+    g = covo.grad
+    close(dsym, g + g.transpose(1, 2), 2e-4, 2e-5, "sqrtm dcov (symmetrised)")
+
+
+@pytest.mark.parametrize("nb,nq,nk", [(2, 30, 6), (3, 300, 77), (4, 4096, 1024), (1, 1000, 513)])
+def test_nonlocal_attention_kernel(nb, nq, nk):
+    th, ph, g = rnd(nb, nq, 8, seed=63), rnd(nb, nk, 8, seed=64), rnd(nb, nk, 8, seed=65)
+    cot = rnd(nb, nq, 8, seed=66)
+    ref_in = [t.double().requires_grad_(True) for t in (th, ph, g)]
+    ref = torch.softmax(ref_in[0] @ ref_in[1].transpose(1, 2), dim=-1) @ ref_in[2]
+    ref.backward(cot.double())
+    ins = [t.to(DEV).requires_grad_(True) for t in (th, ph, g)]
+    out = ops.nonlocal_attention(*ins)
+    close(out, ref, 2e-5, 2e-6, "attention out")
+    out.backward(cot.to(DEV))
+    for name, a, b in zip(("dtheta", "dphi", "dg"), ins, ref_in):
+        close(a.grad, b.grad, 1e-4, 1e-5, name)
+
+
+# ----------------------------------------------------------------------------- blocks vs the reference's own vectors
+@pytest.mark.parametrize("name", ["s1_soca", "s1_soca_odd"])
+def test_s1_soca(name):
+    run_block(name, S.SOCA(64, reduction=16), 1, rtol=3e-4, atol=3e-5)
+
+
+@pytest.mark.parametrize("name", ["s1_nonlocal", "s1_nonlocal_odd"])
+def test_s1_nonlocal_ca(name):
+    run_block(name, S.Nonlocal_CA(in_feat=64, inter_feat=8, reduction=8, sub_sample=False, bn_layer=False), 1)
+
+
+def test_soca_window_crop_matches_oracle():
+    """Maps with a side > 1000 are pooled over a centre crop (SAN_blocks.py:267-280)."""
+    torch.manual_seed(8)
+    m = S.SOCA(64, reduction=16)
+    sd = {"b." + k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x = rnd(1, 64, 3, 1100, seed=67)
+    xo = x.clone().requires_grad_(True)
+    ref = O.soca(sd, "b", xo)
+    cot = rnd(*ref.shape, seed=68)
+    ref.backward(cot)
+    m.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    out = m(xd)
+    close(out, ref, 3e-4, 3e-5, "soca crop out")
+    out.backward(cot.to(DEV))
+    close(xd.grad, xo.grad, 5e-4, 5e-5, "soca crop dx")
+    for k, p in m.named_parameters():
+        close(p.grad, sd["b." + k].grad, 1e-3, 1e-4, k)
+
+
+# ----------------------------------------------------------------------------- reduced nets (n_feats = 64) vs the oracle
+def test_san_reduced_vs_oracle():
+    torch.manual_seed(8)
+    net = S.SAN(n_resgroups=2, n_resblocks=2, n_feats=64, reduction=16, scale=4)
+    perturb(net, scale=0.2)
+    unused = {k for k, _ in net.named_parameters() if k.startswith(("conv_last", "non_local.soca")) or
+              (k.endswith(".gamma") and k != "gamma")}
+    _net_vs_oracle_with_unused(net, "san", dict(n_resgroups=2, n_resblocks=2, scale=4),
+                               rnd(2, 3, 20, 28, seed=70, scale=0.5), None, unused)
+
+
+def test_qsan_reduced_vs_oracle_odd_size():
+    torch.manual_seed(8)
+    net = S.QSAN(n_resgroups=2, n_resblocks=2, n_feats=64, reduction=16, scale=2, input_para=10)
+    perturb(net, scale=0.2)
+    unused = {k for k, _ in net.named_parameters() if k.startswith(("conv_last", "non_local.soca")) or
+              (k.endswith(".gamma") and k != "gamma")}
+    _net_vs_oracle_with_unused(net, "qsan", dict(n_resgroups=2, n_resblocks=2, scale=2),
+                               rnd(2, 3, 13, 19, seed=71, scale=0.5), rnd(2, 10, 1, 1, seed=72, scale=0.3), unused)
+
+
+def _net_vs_oracle_with_unused(net, name, cfg, x, md, unused):
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    ref = O.forward(name, sd, x.clone(), md, **cfg)
+    cot = rnd(*ref.shape, seed=31)
+    ref.backward(cot)
+    net.to(DEV)
+    out = net(x.to(DEV), md.to(DEV)) if md is not None else net(x.to(DEV))
+    assert out.shape == ref.shape and out.is_contiguous()
+    close(out, ref, 5e-4, 5e-5, name + " out")
+    out.backward(cot.to(DEV))
+    for k, p in net.named_parameters():
+        if k in unused:
+            assert p.grad is None and sd[k].grad is None, k
+        else:
+            close(p.grad, sd[k].grad, 2e-3, 2e-4, f"{name} grad {k}")
+
+
+# ----------------------------------------------------------------------------- full depth vs the reference (S3 / S4)
+PARAMS = {"san": {}, "qsan": {"metadata": ["blur_kernel"]}}
+
+
+def build_gpu(name, eval_mode=True, **extra):
+    torch.manual_seed(8)
+    return sisr_amd.handlers.available_models[name](device=0, model_save_dir="/tmp", eval_mode=eval_mode, scale=4,
+                                                    **PARAMS[name], **extra)
+
+
+@pytest.mark.parametrize("name", ["san", "qsan"])
+def test_set5_chopped_eval_psnr_parity_with_reference(name):
+    """Full-depth net (attention branches perturbed as in the fixture) through handler.run_eval -> forward_chop on
+    every Set5 LR image: Y-PSNR within 1e-3 dB of the reference's CPU output."""
+    ref = golden_json("s3_full_depth")[name]
+    crops = np.load(f"{sisr_amd.__path__[0]}/../tests/golden/s3_{name}_crops.npz")
+    h = build_gpu(name)
+    perturb(h.net, keys=ref["perturbed"]["keys"], seed=ref["perturbed"]["seed"], scale=ref["perturbed"]["scale"])
+    for im, x, y, md in set5():
+        kw = dict(metadata=md, metadata_keys=[("blur_kernel",)] * 10) if "metadata" in PARAMS[name] else {}
+        out, loss, _ = h.run_eval(x, y, request_loss=True, **kw)
+        o = out[0].numpy()
+        assert abs(sisr_amd.metrics.y_psnr(o, y[0].numpy()) - ref["images"][im]["y_psnr"]) < 1e-3, im
+        assert abs(float(loss) - ref["images"][im]["l1"]) < 1e-5
+        hh, ww = o.shape[1:]
+        close(o[:, hh // 2 - 16:hh // 2 + 16, ww // 2 - 16:ww // 2 + 16], crops[im], 1e-3, 1e-4, im)
+
+
+@pytest.mark.parametrize("name", ["san", "qsan"])
+def test_run_train_trajectory_matches_reference(name):
+    ref = golden_json("s4_train_steps")[name]
+    h = build_gpu(name, eval_mode=False, lr=1e-4, scheduler=ref["scheduler"], scheduler_params=ref["scheduler_params"])
+    g = torch.Generator().manual_seed(77)
+    rows = []
+    for i, step in enumerate(ref["steps"]):
+        x = torch.rand(2, 3, 16, 16, generator=g)
+        y = torch.rand(2, 3, 64, 64, generator=g)
+        md = torch.rand(2, 10, generator=g, dtype=torch.float64) * 0.4
+        kw = dict(metadata=md, metadata_keys=[("blur_kernel", "blur_kernel")] * 10) if "metadata" in PARAMS[name] else {}
+        assert abs(h.get_learning_rate() - step["lr_before"]) < 1e-12
+        loss, out = h.run_train(x, y, **kw)
+        gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in h.net.parameters() if p.grad is not None)))
+        rows.append((i, float(loss) - step["loss"], gn / step["grad_norm"] - 1, float(out.mean()) - step["out_mean"]))
+    print(name, "trajectory (step, dloss, rel dgradnorm, dmean):", rows)
+    for i, dl, dg, dm in rows:
+        k = 1 + 4 * i
+        assert abs(dl) < 2e-5 * k, rows
+        assert abs(dg) < 1e-3 * k, rows
+        assert abs(dm) < 1e-4 * k, rows
+
+
+def test_san_train_step_at_bench_tile_is_finite_and_reproducible():
+    """One 128x128 training step (4096-query x 1024-key attention per quadrant, M = 16384 covariance pooling)."""
+    losses = []
+    for _ in range(2):
+        h = build_gpu("san", eval_mode=False, lr=1e-4)
+        perturb(h.net)
+        g = torch.Generator().manual_seed(5)
+        x, y = torch.rand(2, 3, 128, 128, generator=g), torch.rand(2, 3, 512, 512, generator=g)
+        loss, _ = h.run_train(x, y)
+        gsum = float(sum(p.grad.double().abs().sum() for p in h.net.parameters() if p.grad is not None))
+        assert np.isfinite(float(loss)) and np.isfinite(gsum)
+        losses.append((float(loss), gsum))
+    assert losses[0] == losses[1], losses
