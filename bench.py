@@ -40,6 +40,9 @@ WORKLOADS = {
     "qedsr": ("qedsr", {"metadata": ["blur_kernel"]}, 0.195),
     "han": ("han", {}, 1.614),
     "qhan": ("qhan", {"metadata": ["blur_kernel"]}, 1.614),
+    # SAN: 20 groups x (10 RB x 2 convs + 1) = 420 body convs + head + upsampler/tail; attention FLOPs not counted
+    "san": ("san", {}, 1.598),
+    "qsan": ("qsan", {"metadata": ["blur_kernel"]}, 1.598),
 }
 
 
@@ -84,7 +87,8 @@ def cpu_baseline(workload, seconds_budget=30.0):
     cfg = {"rcan": dict(n_resgroups=10, n_resblocks=20, scale=4), "edsr": dict(num_blocks=16, scale=4, res_scale=0.1),
            "qrcan": dict(n_resgroups=10, n_resblocks=20, scale=4, style="standard", include_q_layer=True),
            "qedsr": dict(num_blocks=16, scale=4, res_scale=0.1, q_layer_nonlinearity=False),
-           "han": dict(n_resgroups=10, n_resblocks=20, scale=4), "qhan": dict(n_resgroups=10, n_resblocks=20, scale=4)}[name]
+           "han": dict(n_resgroups=10, n_resblocks=20, scale=4), "qhan": dict(n_resgroups=10, n_resblocks=20, scale=4),
+           "san": dict(n_resgroups=20, n_resblocks=10, scale=4), "qsan": dict(n_resgroups=20, n_resblocks=10, scale=4)}[name]
     tr = O.Trainer(name, h.net.state_dict(), lr=1e-4, **cfg)
     g = torch.Generator().manual_seed(8)
     x, y = torch.rand(1, 3, 128, 128, generator=g), torch.rand(1, 3, 512, 512, generator=g)
