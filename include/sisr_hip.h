@@ -134,6 +134,26 @@ size_t sisr_csam_bwd_workspace_bytes(int B, int H, int W, int C);
 int sisr_csam_bwd(const float* x, const float* w27, const float* bias, const float* gamma, const float* dy, float* dx,
                   float* dw27, float* dbias, float* dgamma, float* workspace, int B, int H, int W, int C, void* stream);
 
+/* ---- bf16 matrix-core variants of the 64-channel-chunk conv and its weight gradient ----------------
+ * Same arguments, views, prologue / epilogue options and results layout as sisr_conv3x3_c64 / sisr_wgrad3x3_c64
+ * (ref: advanced/common.py:5-8 default_conv and its autograd backward).  Feature maps, biases and gradients stay
+ * fp32 in HBM; the two MFMA operands are rounded to bf16 (round-to-nearest-even) on their way into LDS --
+ * activations after the optional affine prologue, weights once at pack time -- products are exact and
+ * accumulation is fp32 (the semantics of a bf16 autocast convolution).  The bias gradient is summed from the
+ * unrounded fp32 values.  pack_conv3x3_bf16_both writes cout*cin*9 bf16 elements per packing. */
+int sisr_pack_conv3x3_bf16_both(const float* w, void* packed_fwd, void* packed_dgrad, int cout, int cin, int shuffle_r,
+                                void* stream);
+int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const void* wpacked_bf16, const float* bias, int bias_n,
+                          int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,
+                          const float* in_scale, const float* in_shift, const float* out_scale, float alpha, int relu,
+                          float* gap_partial, int B, int H, int W, int cin, int cout, void* stream);
+size_t sisr_wgrad3x3_c64_bf16_workspace_bytes(int B, int H, int W, int cin, int cout);
+int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
+                           const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so, int64_t si,
+                           int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n, int in_perm_q, float* dbias,
+                           int bias_n, int bias_q, float* workspace, size_t workspace_bytes, int B, int H, int W,
+                           int cin, int cout, void* stream);
+
 /* ---- SAN attention modules ---------------------------------------------------------------------
  * Second-order channel attention, ref: advanced/SAN_blocks.py:244-302 SOCA + advanced/mpncov.py:12-112.
  *   covpool_fwd : cov[b] = (1/M) sum_p (x_p - mean[b]) x_p^T      x [B][M][64] channels-last, mean [B][64]

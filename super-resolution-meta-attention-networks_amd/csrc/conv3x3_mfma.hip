@@ -408,6 +408,233 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
   }
 }
 
+// ------------------------------------------------------------------ bf16 matrix-core kernel (fp32 in HBM)
+// Same tile / wave geometry, View addressing and epilogue as the fp32 kernels, but the contraction runs on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate): activations are rounded to bf16 (RNE, v_cvt_pk_bf16_f32)
+// when the halo is staged into LDS -- after the optional per-(b, c) affine prologue -- weights are rounded once
+// at pack time, products are exact and accumulation stays fp32.  Feature maps remain fp32 in HBM, so every other
+// kernel of the step is unchanged; the conv itself becomes HBM-bound (268 MB per 64->64 launch at B = 32 against
+// 15 us of MFMA time).
+//   LDS image: halo pixel = 64 bf16 = 128 B; its 16-B chunk k (channels 8k..8k+7) sits at slot
+//   k ^ ((col >> 1) & 7): the A fragment of lane (pixel column n, half h) for K-step (tap, 16-channel block kb)
+//   is the single ds_read_b128 of chunk 2kb+h, and 16 consecutive columns then cover all 64 banks once.
+//   B fragments ([q][c][36 K-steps][h][co][8] bf16, 2 KB per K-step) stream from L2 one global_load_dwordx4 per
+//   K-step, prefetched four steps ahead.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ u32x4 sisr_pack_bf16x8(f32x4 a, f32x4 b) {
+  bf16x8 r;
+  r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+  r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+  return __builtin_bit_cast(u32x4, r);
+}
+
+#define BH_PIX 128  // bytes per halo pixel
+
+template <bool AFFINE, bool MASK, bool RES>
+__global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = blockIdx.y;
+  int bid;
+  {
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const unsigned qn = nb >> 3, rn = nb & 7;
+    bid = (int)((xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx);
+  }
+  const int tw = bid % p.tiles_w;
+  bid /= p.tiles_w;
+  const int th = bid % p.tiles_h;
+  const int b = bid / p.tiles_h;
+  const int h0 = th * TH, w0 = tw * TW;
+  const int ph = __builtin_amdgcn_readfirstlane(wave >> 1), ch = __builtin_amdgcn_readfirstlane(wave & 1);
+  const int n = lane & 31, hh = lane >> 5;
+  const int H = p.H, W = p.W;
+  const int co = ch * 32 + n;
+  const int Cout = p.cout_chunks * 64;
+
+  const float bv = p.bias ? p.bias[co * p.bias_n + q * p.bias_q] : 0.f;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = bv;
+
+  // lane constants of the A reads: byte offset of (halo row 2ph, column n+kw, chunk 2kb+hh)
+  unsigned aoff[3][4];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+      aoff[kw][kb] = ((2 * ph) * HALO_W + n + kw) * BH_PIX + (((2 * kb + hh) ^ (((n + kw) >> 1) & 7)) << 4);
+  const unsigned boff = (hh * 64 + co) * 16;  // bytes
+
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w);
+  for (int c = 0; c < p.cin_chunks; ++c) {
+    if (c) __syncthreads();
+    {  // ---- halo staging: thread = (8-channel chunk c8, column pcol [+32]); rows in two batches of three
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
+      const int c8 = tl & 7, pcol = tl >> 3;
+      const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(c);
+      f32x4 s4a = {1.f, 1.f, 1.f, 1.f}, s4b = s4a, t4a = {0.f, 0.f, 0.f, 0.f}, t4b = t4a;
+      if (AFFINE) {
+        const float* sp = p.in_scale + ((long)b * p.cin_chunks + c) * 64 + c8 * 8;
+        s4a = *reinterpret_cast<const f32x4*>(sp);
+        s4b = *reinterpret_cast<const f32x4*>(sp + 4);
+        if (p.in_shift) {
+          const float* tp = p.in_shift + ((long)b * p.cin_chunks + c) * 64 + c8 * 8;
+          t4a = *reinterpret_cast<const f32x4*>(tp);
+          t4b = *reinterpret_cast<const f32x4*>(tp + 4);
+        }
+      }
+      unsigned goff[2], loff[2];
+      bool cok[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int col = pcol + 32 * k;
+        const int gw = w0 - 1 + col;
+        cok[k] = gw >= 0 && gw < W && col < HALO_W;
+        goff[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c8 * 8);
+        loff[k] = col * BH_PIX + ((c8 ^ ((col >> 1) & 7)) << 4);
+      }
+#pragma unroll
+      for (int r0 = 0; r0 < HALO_H; r0 += 3) {
+        f32x4 v[3][2][2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int gh = h0 - 1 + r0 + r;
+          const float* xrow = xb + (long)min(max(gh, 0), H - 1) * p.xv.sH;  // scalar
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (k == 0 || pcol < 2) {
+              v[r][k][0] = *reinterpret_cast<const f32x4*>(xrow + goff[k]);
+              v[r][k][1] = *reinterpret_cast<const f32x4*>(xrow + goff[k] + 4);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int gh = h0 - 1 + r0 + r;
+          const bool rok = gh >= 0 && gh < H;  // scalar
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (k == 0 || pcol < 2) {
+              f32x4 ta = v[r][k][0], tb = v[r][k][1];
+              if (AFFINE) {
+                ta = ta * s4a + t4a;
+                tb = tb * s4b + t4b;
+              }
+              u32x4 pk = sisr_pack_bf16x8(ta, tb);
+              const unsigned m = (rok && cok[k]) ? 0xffffffffu : 0u;
+              pk &= (u32x4){m, m, m, m};
+              *reinterpret_cast<u32x4*>(ldsb + (r0 + r) * (HALO_W * BH_PIX) + loff[k]) = pk;
+            }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- K loop: 36 steps (tap t = s >> 2, 16-channel block kb = s & 3) x 2 MFMAs
+    const unsigned char* wq = wbase + ((long)q * p.cin_chunks + c) * (36 * 2048);  // scalar
+#define BF_LOAD_B(s) (*reinterpret_cast<const bf16x8*>(wq + (s) * 2048 + boff))
+#define BF_LOAD_A(m, s) \
+  (*reinterpret_cast<const bf16x8*>(ldsb + ((((s) >> 2) / 3 + (m)) * (HALO_W * BH_PIX)) + aoff[((s) >> 2) % 3][(s) & 3]))
+    bf16x8 bq[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bq[s] = BF_LOAD_B(s);
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+      const bf16x8 bb = bq[s & 3];
+      if (s + 4 < 36) bq[s & 3] = BF_LOAD_B(s + 4);
+      const bf16x8 a0 = BF_LOAD_A(0, s);
+      const bf16x8 a1 = BF_LOAD_A(1, s);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc1, 0, 0, 0);
+    }
+#undef BF_LOAD_A
+#undef BF_LOAD_B
+  }
+
+  // ---- epilogue (identical to the fp32 kernel: the C/D layout of the 32x32 MFMA does not depend on dtype)
+  float os = p.alpha;
+  if (p.out_scale) os *= p.out_scale[(long)b * Cout + q * 64 + co];
+  const float lo = p.relu ? 0.f : -3.402823466e38f;
+  const unsigned loff_y = (unsigned)(co + 4 * hh * (int)p.yv.sW);
+  const long tile_base = (long)b * p.yv.sB + p.yv.chunk(q) + (long)w0 * p.yv.sW;
+  const bool full = (h0 + TH <= H) && (w0 + TW <= W);
+  float gsum = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int row = h0 + 2 * ph + m;
+    const f32x16 acc = m ? acc1 : acc0;
+    const long row_base = tile_base + (long)row * p.yv.sH;
+    if (full) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long off = row_base + (long)((r & 3) + 8 * (r >> 2)) * p.yv.sW;
+        float v = fmaxf(acc[r], lo) * os;
+        if (MASK) v = (p.mask + off)[loff_y] > 0.f ? v : 0.f;
+        if (RES) v += (p.res + off)[loff_y];
+        (p.y + off)[loff_y] = v;
+        gsum += v;
+      }
+    } else if (row < H) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cr = (r & 3) + 8 * (r >> 2);
+        if (w0 + cr + 4 * hh < W) {
+          const long off = row_base + (long)cr * p.yv.sW;
+          float v = fmaxf(acc[r], lo) * os;
+          if (MASK) v = (p.mask + off)[loff_y] > 0.f ? v : 0.f;
+          if (RES) v += (p.res + off)[loff_y];
+          (p.y + off)[loff_y] = v;
+          gsum += v;
+        }
+      }
+    }
+  }
+  if (p.gap) {
+    gsum += __shfl_xor(gsum, 32);
+    if (hh == 0) {
+      const int tile = th * p.tiles_w + tw;
+      const long parts = (long)p.tiles_w * p.tiles_h * 2;
+      p.gap[(((long)b * parts) + tile * 2 + ph) * Cout + q * 64 + co] = gsum;
+    }
+  }
+}
+
+// bf16 packings of one OIHW weight (forward and input-gradient orders) in one launch:
+// packed[q][c][s][h][n][j] = bf16(w[o][i][t]),  t = s >> 2,  i_local = 16*(s & 3) + 8h + j,  o_local = n.
+__global__ void pack_conv3x3_bf16_both_kernel(const float* __restrict__ w, __bf16* __restrict__ pf,
+                                              __bf16* __restrict__ pd, int cout, int cin, int r) {
+  const long total = (long)cout * cin * 9;
+  const int rr = r * r;
+  const int oc = cout >> 6, ic = cin >> 6;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t_ = idx;
+    const int j = t_ & 7;
+    t_ >>= 3;
+    const int n = t_ & 63;
+    t_ >>= 6;
+    const int h = t_ & 1;
+    t_ >>= 1;
+    const int s = t_ % 36;
+    t_ /= 36;
+    const int t = s >> 2;
+    const int k = 16 * (s & 3) + 8 * h + j;
+    {
+      const int c = t_ % ic, q = t_ / ic;
+      const long o = r > 1 ? (long)n * rr + q : (long)q * 64 + n;
+      const long i = (long)c * 64 + k;
+      pf[idx] = (__bf16)w[(o * cin + i) * 9 + t];
+    }
+    {
+      const int c = t_ % oc, q = t_ / oc;
+      const long i = (long)q * 64 + n;
+      const long o = r > 1 ? (long)k * rr + c : (long)c * 64 + k;
+      pd[idx] = (__bf16)w[(o * cin + i) * 9 + (8 - t)];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ weight packing
 // packed[q][c][t][j][h][co][e] = w[o*so + i*si + t'],  o = co*on + q*oq,  i = (8j+4h+e)*in_ + c*iq,
 // t' = flip ? 8-t : t.  One thread per packed element.
@@ -577,5 +804,74 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
     hipLaunchKernelGGL(conv3x3_c64_kernel<6>, grid, dim3(256), lb, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL(conv3x3_c64_kernel<0>, grid, dim3(256), lb, (hipStream_t)stream, p);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_pack_conv3x3_bf16_both(const float* w, void* packed_fwd, void* packed_dgrad, int cout, int cin,
+                                           int shuffle_r, void* stream) {
+  if (!w || !packed_fwd || !packed_dgrad || cout <= 0 || cin <= 0 || shuffle_r < 1) return SISR_ERR_ARG;
+  if ((cin & 63) || (cout & 63)) return SISR_ERR_UNSUPPORTED;
+  if (shuffle_r > 1 && cout != 64 * shuffle_r * shuffle_r) return SISR_ERR_UNSUPPORTED;
+  const long total = (long)cout * cin * 9;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_conv3x3_bf16_both_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                     (__bf16*)packed_fwd, (__bf16*)packed_dgrad, cout, cin, shuffle_r);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const void* wpacked_bf16, const float* bias,
+                                     int bias_n, int bias_q, float* y, const int64_t* yview, const float* res,
+                                     const float* mask, const float* in_scale, const float* in_shift,
+                                     const float* out_scale, float alpha, int relu, float* gap_partial, int B, int H,
+                                     int W, int cin, int cout, void* stream) {
+  if (!x || !wpacked_bf16 || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
+  if (in_shift && !in_scale) return SISR_ERR_UNSUPPORTED;
+  if (!sisr_aligned16(x) || !sisr_aligned16(wpacked_bf16) || !sisr_aligned16(in_scale) || !sisr_aligned16(in_shift))
+    return SISR_ERR_ALIGN;
+  ConvParams p;
+  p.x = x;
+  p.xv = view_from(xview);
+  p.y = y;
+  p.yv = view_from(yview);
+  if ((p.xv.sB | p.xv.sH | p.xv.sW | p.xv.chi | p.xv.clo) & 3) return SISR_ERR_ALIGN;
+  p.res = res;
+  p.mask = mask;
+  p.w = reinterpret_cast<const float*>(wpacked_bf16);
+  p.bias = bias;
+  p.in_scale = in_scale;
+  p.in_shift = in_shift;
+  p.out_scale = out_scale;
+  p.gap = gap_partial;
+  p.alpha = alpha;
+  p.bias_n = bias_n;
+  p.bias_q = bias_q;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.cin_chunks = cin / 64;
+  p.cout_chunks = cout / 64;
+  p.relu = relu;
+  p.tiles_w = (W + TW - 1) / TW;
+  p.tiles_h = (H + TH - 1) / TH;
+  const long nblk = (long)p.tiles_w * p.tiles_h * B;
+  if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
+  const dim3 grid((unsigned)nblk, p.cout_chunks);
+  const size_t lb = HALO_H * HALO_W * BH_PIX;
+  hipStream_t st = (hipStream_t)stream;
+  const int sel = (in_scale ? 4 : 0) | (mask ? 2 : 0) | (res ? 1 : 0);
+  switch (sel) {
+#define BF_CASE(i, a, m, r) \
+  case i: hipLaunchKernelGGL((conv3x3_c64_bf16_kernel<a, m, r>), grid, dim3(256), lb, st, p); break;
+    BF_CASE(0, false, false, false)
+    BF_CASE(1, false, false, true)
+    BF_CASE(2, false, true, false)
+    BF_CASE(3, false, true, true)
+    BF_CASE(4, true, false, false)
+    BF_CASE(5, true, false, true)
+    BF_CASE(6, true, true, false)
+    BF_CASE(7, true, true, true)
+#undef BF_CASE
+  }
   return sisr_check_launch();
 }

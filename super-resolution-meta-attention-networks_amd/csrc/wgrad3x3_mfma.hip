@@ -187,6 +187,198 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) {
   }
 }
 
+// ------------------------------------------------------------------ bf16 matrix-core weight gradient
+// Operands rounded to bf16 (RNE) as they are staged into LDS, products exact, fp32 accumulation; the bias
+// gradient is summed from the unrounded fp32 dY'.  A workgroup owns all 64 ci x 64 co of one (cin chunk, cout
+// chunk) pair: wave w accumulates quadrant (ci half w>>1, co half w&1) for the nine taps in nine persistent
+// accumulators, all four waves walking the same staged tile, so the inputs are read from HBM once and no
+// cross-wave reduction is needed.  The contraction index is the pixel, which is the SLOW index of the
+// channels-last image, so both MFMA operands are fetched with the transposing LDS read ds_read_b64_tr_b16
+// (4 pixels x 16 channels per 16-lane group, delivered channel-major): the LDS image stays the natural
+// [pixel][64 ch] bf16 rows (128 B), a tap shift is a whole-pixel offset, and the 16-B chunk k of a pixel sits at
+// slot k ^ 4*((col >> 1) & 1) so that the four pixels of a transposed block fall into four disjoint bank
+// quarters.  Slab layout and second-stage reduction are shared with the fp32 kernel.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+#define BW_PIX 128
+#define BW_X_BYTES (WH_H * WH_W * BW_PIX)
+#define BW_Y_BYTES (WT_H * WT_W * BW_PIX)
+
+__device__ __forceinline__ u32x4 wg_pack_bf16x8(f32x4 a, f32x4 b) {
+  bf16x8 r;
+  r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+  r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+  return __builtin_bit_cast(u32x4, r);
+}
+
+__device__ __forceinline__ bf16x8 wg_tr_frag(const unsigned char* base, unsigned off0, unsigned off1) {
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(base + off0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(base + off1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_c64_bf16_kernel(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  unsigned char* ldx = ldsb;
+  unsigned char* ldy = ldsb + BW_X_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pair = blockIdx.y;
+  const int cq = pair % p.cout_chunks, cc = pair / p.cout_chunks;
+  const int cih = __builtin_amdgcn_readfirstlane(wave >> 1), coh = __builtin_amdgcn_readfirstlane(wave & 1);
+  const int H = p.H, W = p.W;
+  const bool do_bias = p.bias_slabs && cc == 0;
+  const int Cout = p.cout_chunks * 64;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x16){0};
+  f32x4 bsa = {0.f, 0.f, 0.f, 0.f}, bsb = bsa;
+
+  // transposed-read lane constants: lane = 16g + 4qq + pp supplies the address of block row (pixel) qq,
+  // channels 4pp..4pp+3 of the 16-channel block (g & 1); K half (g >> 1) covers pixels 8(g>>1) .. +7
+  unsigned aoff[3][2], yoff[2];
+  {
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int chunk = (g & 1) * 2 + (pp >> 1), sub = (pp & 1) * 8;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int pix = 8 * (g >> 1) + 4 * rd + qq;
+      yoff[rd] = pix * BW_PIX + (((coh * 4 + chunk) ^ (((pix >> 1) & 1) << 2)) << 4) + sub;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+        aoff[kw][rd] = (pix + kw) * BW_PIX + (((cih * 4 + chunk) ^ ((((pix + kw) >> 1) & 1) << 2)) << 4) + sub;
+    }
+  }
+
+  const int tiles_per_img = p.tiles_w * p.tiles_h;
+  const int total = tiles_per_img * p.B;
+  for (int tile = blockIdx.x; tile < total; tile += p.S) {
+    const int b = tile / tiles_per_img;
+    const int tr = tile - b * tiles_per_img;
+    const int th = tr / p.tiles_w, tw = tr - th * p.tiles_w;
+    const int h0 = th * WT_H, w0 = tw * WT_W;
+    __syncthreads();
+    {  // staging: thread = (8-channel chunk c8, column pcol [+32])
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
+      const int c8 = tl & 7, pcol = tl >> 3;
+      const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(cc);
+      unsigned gx[2], lx[2];
+      bool okx[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int col = pcol + 32 * k;
+        const int gw = w0 - 1 + col;
+        okx[k] = gw >= 0 && gw < W && col < WH_W;
+        gx[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c8 * 8);
+        lx[k] = col * BW_PIX + ((c8 ^ (((col >> 1) & 1) << 2)) << 4);
+      }
+#pragma unroll
+      for (int r0 = 0; r0 < WH_H; r0 += 2) {
+        f32x4 v[2][2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const float* xrow = xb + (long)min(max(h0 - 1 + r0 + r, 0), H - 1) * p.xv.sH;  // scalar
+          v[r][0][0] = *reinterpret_cast<const f32x4*>(xrow + gx[0]);
+          v[r][0][1] = *reinterpret_cast<const f32x4*>(xrow + gx[0] + 4);
+          if (pcol < 2) {
+            v[r][1][0] = *reinterpret_cast<const f32x4*>(xrow + gx[1]);
+            v[r][1][1] = *reinterpret_cast<const f32x4*>(xrow + gx[1] + 4);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int gh = h0 - 1 + r0 + r;
+          const bool rok = gh >= 0 && gh < H;  // scalar
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (k == 0 || pcol < 2) {
+              u32x4 pk = wg_pack_bf16x8(v[r][k][0], v[r][k][1]);
+              const unsigned m = (rok && okx[k]) ? 0xffffffffu : 0u;
+              pk &= (u32x4){m, m, m, m};
+              *reinterpret_cast<u32x4*>(ldx + (r0 + r) * (WH_W * BW_PIX) + lx[k]) = pk;
+            }
+        }
+      }
+      const float* yb = p.dy + (long)b * p.yv.sB + p.yv.chunk(cq);
+      f32x4 s4a = {1.f, 1.f, 1.f, 1.f}, s4b = s4a, t4a = {0.f, 0.f, 0.f, 0.f}, t4b = t4a;
+      if (p.dy_scale) {
+        const float* sp = p.dy_scale + (long)b * Cout + cq * 64 + c8 * 8;
+        s4a = *reinterpret_cast<const f32x4*>(sp);
+        s4b = *reinterpret_cast<const f32x4*>(sp + 4);
+      }
+      if (p.dy_shift) {
+        const float* tp = p.dy_shift + (long)b * Cout + cq * 64 + c8 * 8;
+        t4a = *reinterpret_cast<const f32x4*>(tp);
+        t4b = *reinterpret_cast<const f32x4*>(tp + 4);
+      }
+      const int gwy = w0 + pcol;
+      const bool oky = gwy < W;
+      const unsigned gy = (unsigned)(min(gwy, W - 1) * (int)p.yv.sW + c8 * 8);
+      const unsigned ly = pcol * BW_PIX + ((c8 ^ (((pcol >> 1) & 1) << 2)) << 4);
+#pragma unroll
+      for (int r0 = 0; r0 < WT_H; r0 += 2) {
+        f32x4 u[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const float* yrow = yb + (long)min(h0 + r0 + r, H - 1) * p.yv.sH;
+          u[r][0] = *reinterpret_cast<const f32x4*>(yrow + gy);
+          u[r][1] = *reinterpret_cast<const f32x4*>(yrow + gy + 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const bool ok = oky && (h0 + r0 + r < H);
+          const f32x4 ta = sisr_keep_if(u[r][0] * s4a + t4a, ok), tb = sisr_keep_if(u[r][1] * s4b + t4b, ok);
+          bsa += ta;
+          bsb += tb;
+          *reinterpret_cast<u32x4*>(ldy + (r0 + r) * (WT_W * BW_PIX) + ly) = wg_pack_bf16x8(ta, tb);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- 16 K-steps of 16 pixels (tile row r, half hf), nine taps each
+#pragma unroll 1
+    for (int r = 0; r < WT_H; ++r) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const unsigned char* yb = ldy + (r * WT_W + 16 * hf) * BW_PIX;
+        const bf16x8 bfrag = wg_tr_frag(yb, yoff[0], yoff[1]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const unsigned char* xa = ldx + ((r + t / 3) * WH_W + 16 * hf) * BW_PIX;
+          const bf16x8 afrag = wg_tr_frag(xa, aoff[t % 3][0], aoff[t % 3][1]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
+          if (t % 3 == 2) __builtin_amdgcn_sched_barrier(0);  // keep at most three taps' fragments in flight
+        }
+      }
+    }
+  }
+
+  // ---- slabs: unit = pair*4 + (ci half, co half), the fp32 kernel's layout
+  {
+    float* out = p.slabs + ((long)blockIdx.x * ((long)gridDim.y * 4) + pair * 4 + cih * 2 + coh) * SLAB;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64 + lane] = acc[t][r];
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(ldsb);
+    *reinterpret_cast<f32x4*>(red + tid * 8) = bsa;
+    *reinterpret_cast<f32x4*>(red + tid * 8 + 4) = bsb;
+    __syncthreads();
+    if (tid < 64) {  // channel tid = c8*8 + e lives in threads with (tid & 7) == c8
+      const int c8 = tid >> 3, e = tid & 7;
+      float s = 0.f;
+      for (int k = 0; k < 32; ++k) s += red[(k * 8 + c8) * 8 + e];
+      p.bias_slabs[((long)blockIdx.x * p.cout_chunks + cq) * 64 + tid] = s;
+    }
+  }
+}
+
 // Sum S slabs per output element in slab order and scatter to dW (generic strides / channel maps):
 // element (unit, tap t, reg r, lane l): ci_local = (r&3) + 8*(r>>2) + 4*(l>>5), co_local = l&31.
 struct ReduceParams {
@@ -304,6 +496,82 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   const size_t lds_bytes = (size_t)(LDS_X + LDS_Y) * sizeof(float);
   SISR_ALLOW_LDS(wgrad3x3_c64_kernel, lds_bytes);
   hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(p.S, units), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  int rc = sisr_check_launch();
+  if (rc) return rc;
+  ReduceParams r;
+  r.slabs = p.slabs;
+  r.bias_slabs = p.bias_slabs;
+  r.dw = dw;
+  r.db = dbias;
+  r.so = so;
+  r.si = si;
+  r.alpha = alpha;
+  r.S = p.S;
+  r.units = units;
+  r.cin_chunks = p.cin_chunks;
+  r.cout_chunks = p.cout_chunks;
+  r.flip = flip_taps;
+  r.on = out_perm_n;
+  r.oq = out_perm_q;
+  r.in_ = in_perm_n;
+  r.iq = in_perm_q;
+  r.bias_n = bias_n;
+  r.bias_q = bias_q;
+  const long total = (long)units * SLAB + (dbias ? cout : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, 4), 0, (hipStream_t)stream, r);
+  return sisr_check_launch();
+}
+
+static int wgrad_bf16_split(int B, int H, int W, int pairs) {
+  const long tiles = (long)B * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+  long S = 512 / pairs;  // two workgroups per CU resident across the whole grid
+  if (S < 1) S = 1;
+  if (S > tiles) S = tiles;
+  return (int)S;
+}
+
+extern "C" size_t sisr_wgrad3x3_c64_bf16_workspace_bytes(int B, int H, int W, int cin, int cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
+  const int pairs = (cin / 64) * (cout / 64);
+  const int S = wgrad_bf16_split(B, H, W, pairs);
+  return ((size_t)S * pairs * 4 * SLAB + (size_t)S * cout) * sizeof(float);
+}
+
+extern "C" int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
+                                      const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so,
+                                      int64_t si, int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n,
+                                      int in_perm_q, float* dbias, int bias_n, int bias_q, float* workspace,
+                                      size_t workspace_bytes, int B, int H, int W, int cin, int cout, void* stream) {
+  if (!x || !dy || !dw || !xview || !dyview || !workspace || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
+  if (workspace_bytes < sisr_wgrad3x3_c64_bf16_workspace_bytes(B, H, W, cin, cout)) return SISR_ERR_ARG;
+  if (!sisr_aligned16(x) || !sisr_aligned16(dy) || !sisr_aligned16(workspace) || !sisr_aligned16(dy_scale) ||
+      !sisr_aligned16(dy_shift))
+    return SISR_ERR_ALIGN;
+  WgradParams p;
+  p.x = x;
+  p.xv = view_from(xview);
+  p.dy = dy;
+  p.yv = view_from(dyview);
+  if ((p.xv.sB | p.xv.sH | p.xv.sW | p.xv.chi | p.xv.clo | p.yv.sB | p.yv.sH | p.yv.sW | p.yv.chi | p.yv.clo) & 3)
+    return SISR_ERR_ALIGN;
+  p.dy_scale = dy_scale;
+  p.dy_shift = dy_shift;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.cin_chunks = cin / 64;
+  p.cout_chunks = cout / 64;
+  p.tiles_w = (W + WT_W - 1) / WT_W;
+  p.tiles_h = (H + WT_H - 1) / WT_H;
+  const int pairs = p.cin_chunks * p.cout_chunks;
+  const int units = pairs * 4;
+  p.S = wgrad_bf16_split(B, H, W, pairs);
+  p.slabs = workspace;
+  p.bias_slabs = dbias ? workspace + (size_t)p.S * units * SLAB : nullptr;
+  const size_t lds_bytes = BW_X_BYTES + BW_Y_BYTES;
+  SISR_ALLOW_LDS(wgrad3x3_c64_bf16_kernel, lds_bytes);
+  hipLaunchKernelGGL(wgrad3x3_c64_bf16_kernel, dim3(p.S, pairs), dim3(256), lds_bytes, (hipStream_t)stream, p);
   int rc = sisr_check_launch();
   if (rc) return rc;
   ReduceParams r;

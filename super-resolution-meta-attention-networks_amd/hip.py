@@ -57,6 +57,14 @@ _SIGS.update({
     "sisr_csam_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "sisr_csam_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
 })
+_SIGS.update({  # bf16 matrix-core variants (csrc/conv3x3_mfma.hip, csrc/wgrad3x3_mfma.hip)
+    "sisr_pack_conv3x3_bf16_both": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "sisr_conv3x3_c64_bf16": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, c_float, c_int, P, c_int, c_int, c_int,
+                                 c_int, c_int, P]),
+    "sisr_wgrad3x3_c64_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "sisr_wgrad3x3_c64_bf16": (c_int, [P, P, P, P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
+                                  c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+})
 _SIGS.update({  # SAN attention (csrc/san.hip)
     "sisr_covpool_workspace_bytes": (c_size_t, [c_int, c_long]),
     "sisr_covpool_fwd": (c_int, [P, P, P, P, c_int, c_long, c_int, P]),
@@ -114,6 +122,13 @@ def ptr(t):
                            "There is no CPU fallback in this package.")
     if t.dtype != torch.float32:
         raise RuntimeError(f"sisr HIP kernels are fp32; got {t.dtype}")
+    return t.data_ptr()
+
+
+def ptr_bf16(t):
+    """Device pointer of a packed bf16 weight buffer."""
+    if not t.is_cuda or t.dtype != torch.bfloat16:
+        raise RuntimeError(f"expected a bf16 tensor on a HIP device; got {t.dtype} on {t.device}")
     return t.data_ptr()
 
 

@@ -78,8 +78,30 @@ def _vec(B, C, device):
 
 
 # ----------------------------------------------------------------------------- raw launches (no autograd)
+# Arithmetic of the 64-channel-chunk convolutions (forward, input gradient, weight gradient):
+#   "fp32"  v_mfma_f32_32x32x2_f32, exact fp32 -- the reference's arithmetic, the default
+#   "bf16"  v_mfma_f32_32x32x16_bf16: both operands rounded to bf16 (RNE) on their way into LDS, fp32 accumulate,
+#           fp32 feature maps / gradients / optimiser state in HBM (BASELINE config "HAN x4 bf16 ... MFMA")
+# Process-wide; packed weights are rebuilt every step, so switching between steps is safe.
+PRECISION = os.environ.get("SISR_PRECISION", "fp32")
+
+
+def set_precision(name):
+    global PRECISION
+    if name not in ("fp32", "bf16"):
+        raise ValueError(f"precision must be 'fp32' or 'bf16', got {name!r}")
+    PRECISION = name
+
+
+def _wptr(packed):
+    return hip.ptr_bf16(packed) if packed.dtype == torch.bfloat16 else hip.ptr(packed)
+
+
 def pack_weight(w, mode, shuffle=1):
     """OIHW fp32 weight -> B-fragment order of the MFMA conv ('fwd') or of its input gradient ('dgrad')."""
+    if PRECISION == "bf16":
+        pf, pd = pack_pair(w, shuffle)
+        return pf if mode == "fwd" else pd
     cout, cin = w.shape[0], w.shape[1]
     packed = torch.empty(cout * cin * 9, device=w.device, dtype=torch.float32)
     rr = shuffle * shuffle
@@ -98,6 +120,11 @@ def pack_weight(w, mode, shuffle=1):
 def pack_pair(w, shuffle=1):
     """(forward packing, input-gradient packing) of one weight, one launch."""
     cout, cin = w.shape[0], w.shape[1]
+    if PRECISION == "bf16":
+        buf = torch.empty(2, cout * cin * 9, device=w.device, dtype=torch.bfloat16)
+        hip.check(hip.lib().sisr_pack_conv3x3_bf16_both(hip.ptr(w), hip.ptr_bf16(buf[0]), hip.ptr_bf16(buf[1]), cout,
+                                                        cin, shuffle, hip.stream()), "sisr_pack_conv3x3_bf16_both")
+        return buf[0], buf[1]
     buf = torch.empty(2, cout * cin * 9, device=w.device, dtype=torch.float32)
     hip.check(hip.lib().sisr_pack_conv3x3_both(hip.ptr(w), hip.ptr(buf[0]), hip.ptr(buf[1]), cout, cin, shuffle,
                                                hip.stream()), "sisr_pack_conv3x3_both")
@@ -106,23 +133,28 @@ def pack_pair(w, shuffle=1):
 
 def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=None, mask=None, in_scale=None,
              in_shift=None, out_scale=None, alpha=1.0, relu=False, gap=None):
-    rc = hip.lib().sisr_conv3x3_c64(hip.ptr(x), xview, hip.ptr(packed), hip.ptr(bias), bias_nq[0], bias_nq[1],
-                                    hip.ptr(y), yview, hip.ptr(res), hip.ptr(mask), hip.ptr(in_scale),
-                                    hip.ptr(in_shift), hip.ptr(out_scale), float(alpha), int(relu), hip.ptr(gap), B, H,
-                                    W, cin, cout, hip.stream())
-    hip.check(rc, "sisr_conv3x3_c64")
+    L = hip.lib()
+    bf16 = packed.dtype == torch.bfloat16  # the packing decides: a weight packed under one mode runs under it
+    fn, name = (L.sisr_conv3x3_c64_bf16, "sisr_conv3x3_c64_bf16") if bf16 else (L.sisr_conv3x3_c64, "sisr_conv3x3_c64")
+    rc = fn(hip.ptr(x), xview, _wptr(packed), hip.ptr(bias), bias_nq[0], bias_nq[1], hip.ptr(y), yview, hip.ptr(res),
+            hip.ptr(mask), hip.ptr(in_scale), hip.ptr(in_shift), hip.ptr(out_scale), float(alpha), int(relu),
+            hip.ptr(gap), B, H, W, cin, cout, hip.stream())
+    hip.check(rc, name)
 
 
 def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_scale=None, dy_shift=None, shuffle=1):
     L = hip.lib()
-    nbytes = L.sisr_wgrad3x3_c64_workspace_bytes(B, H, W, cin, cout)
+    if PRECISION == "bf16":
+        size_fn, fn, name = L.sisr_wgrad3x3_c64_bf16_workspace_bytes, L.sisr_wgrad3x3_c64_bf16, "sisr_wgrad3x3_c64_bf16"
+    else:
+        size_fn, fn, name = L.sisr_wgrad3x3_c64_workspace_bytes, L.sisr_wgrad3x3_c64, "sisr_wgrad3x3_c64"
+    nbytes = size_fn(B, H, W, cin, cout)
     ws = hip.workspace(x.device, nbytes)
     rr = shuffle * shuffle
     on, oq = (rr, 1) if shuffle > 1 else (1, 64)
-    rc = L.sisr_wgrad3x3_c64(hip.ptr(x), xview, hip.ptr(dy), dyview, hip.ptr(dy_scale), hip.ptr(dy_shift),
-                             float(alpha), hip.ptr(dw), cin * 9, 9, 0, on, oq, 1, 64, hip.ptr(db), on, oq, hip.ptr(ws),
-                             nbytes, B, H, W, cin, cout, hip.stream())
-    hip.check(rc, "sisr_wgrad3x3_c64")
+    rc = fn(hip.ptr(x), xview, hip.ptr(dy), dyview, hip.ptr(dy_scale), hip.ptr(dy_shift), float(alpha), hip.ptr(dw),
+            cin * 9, 9, 0, on, oq, 1, 64, hip.ptr(db), on, oq, hip.ptr(ws), nbytes, B, H, W, cin, cout, hip.stream())
+    hip.check(rc, name)
 
 
 def gap_parts(H, W):
