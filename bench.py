@@ -32,6 +32,7 @@ import torch.distributed as dist  # noqa: E402
 
 CONV_BODY_FLOP_PER_PIXEL = 2 * 64 * 64 * 9
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
+HBM_PEAK_GBS = 8000.0          # same guide: HBM3E ~8 TB/s
 WORKLOADS = {
     # name: (registry name, handler kwargs, fwd+bwd algorithmic TFLOP per LR patch)
     "rcan": ("rcan", {}, 1.565),
@@ -117,10 +118,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward as a hipGraph (small batches)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="arithmetic of the 64-channel convs: fp32 MFMA (reference arithmetic, the headline) or bf16 "
+                         "MFMA operands with fp32 accumulate / storage (BASELINE config 'HAN x4 bf16')")
     args = ap.parse_args()
 
     import importlib
     sisr = importlib.import_module("sisr_amd")
+    sisr.ops.set_precision(args.precision)
     rank, world, local = sisr.parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
@@ -184,14 +189,24 @@ def main():
         line = {
             "metric": "LR-patches/sec (128x128x3, x4) fwd+bwd", "value": value, "unit": "patches/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands, f32 accumulate and storage",
+            "data": "synthetic",
             "config": {"workload": f"{name.upper()} x4 full depth, 128x128 LR -> 512x512 tiles, train step = "
                                    f"fwd + L1 + bwd + Adam + scheduler", "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "final_loss": loss_val,
                        "algorithmic_tflops": value * tflop_per_patch},
         }
         ks = timer.summary()
-        if ks:
+        if ks and args.precision == "bf16":
+            # the bf16 conv is HBM-bound: one fp32 map in, one out (weights / bias are L2-resident)
+            nbytes = 2 * (ks["flop_per_launch"] / CONV_BODY_FLOP_PER_PIXEL) * 64 * 4
+            gbs = nbytes / (ks["avg_us"] * 1e-6) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": "conv3x3_c64_bf16_kernel (64->64 body conv, forward launches)",
+                                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                "traffic": None, "avg_launch_us": ks["avg_us"], "launches_timed": ks["launches"],
+                                "bytes_per_launch": nbytes, "mfma_tflops": ks["tflops"]}
+        elif ks:
             traffic = None
             tj = os.path.join(ROOT, "profiles", "traffic_conv3x3_c64.json")
             if os.path.exists(tj):
@@ -202,7 +217,7 @@ def main():
                                 "frac": ks["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                 "avg_launch_us": ks["avg_us"], "launches_timed": ks["launches"],
                                 "flop_per_launch": ks["flop_per_launch"]}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.precision == "fp32":
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -39,29 +39,35 @@ def _r16(t):
 
 
 class _Bf16Conv(torch.autograd.Function):
+    """alpha * (conv(r16(x), r16(w)) + b).  A residual scale (EDSR's res_scale) is part of the operator because the
+    product applies it to the fp32 accumulator, i.e. AFTER the bf16 rounding of the incoming gradient in backward;
+    scaling outside would round alpha * dy instead of dy."""
+
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, alpha):
         xr, wr = _r16(x), _r16(w)
         ctx.save_for_backward(xr, wr)
-        ctx.has_bias = b is not None
-        return F.conv2d(xr, wr, b, padding=w.shape[-1] // 2)
+        ctx.has_bias, ctx.alpha = b is not None, alpha
+        return F.conv2d(xr, wr, b, padding=w.shape[-1] // 2) * alpha
 
     @staticmethod
     def backward(ctx, dy):
         xr, wr = ctx.saved_tensors
         dyr = _r16(dy)
         pad = wr.shape[-1] // 2
-        dx = torch.nn.grad.conv2d_input(xr.shape, wr, dyr, padding=pad)
-        dw = torch.nn.grad.conv2d_weight(xr, wr.shape, dyr, padding=pad)
-        return dx, dw, (dy.sum(dim=(0, 2, 3)) if ctx.has_bias else None)
+        dx = torch.nn.grad.conv2d_input(xr.shape, wr, dyr, padding=pad) * ctx.alpha
+        dw = torch.nn.grad.conv2d_weight(xr, wr.shape, dyr, padding=pad) * ctx.alpha
+        return dx, dw, (dy.sum(dim=(0, 2, 3)) * ctx.alpha if ctx.has_bias else None), None
 
 
-def conv(sd, key, x):
-    """ref: SISR/models/advanced/common.py:5-8 (default_conv): k x k, pad k//2, bias."""
+def conv(sd, key, x, alpha=1.0):
+    """ref: SISR/models/advanced/common.py:5-8 (default_conv): k x k, pad k//2, bias.  alpha: output scale the
+    caller applies right after (ResBlock's res_scale); in fp32 it is just that multiplication."""
     w = sd[key + ".weight"]
     if CONV_PRECISION == "bf16" and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
-        return _Bf16Conv.apply(x, w, sd.get(key + ".bias"))
-    return F.conv2d(x, w, sd.get(key + ".bias"), padding=w.shape[-1] // 2)
+        return _Bf16Conv.apply(x, w, sd.get(key + ".bias"), alpha)
+    y = F.conv2d(x, w, sd.get(key + ".bias"), padding=w.shape[-1] // 2)
+    return y if alpha == 1.0 else y * alpha
 
 
 def _fc(sd, key, v):
@@ -168,8 +174,7 @@ def pa_layer(sd, key, x):
 # ----------------------------------------------------------------------------- blocks
 def res_block(sd, key, x, res_scale):
     """ref: advanced/common.py:68-72: x + res_scale * conv(relu(conv(x)))."""
-    r = conv(sd, key + ".body.2", F.relu(conv(sd, key + ".body.0", x)))
-    return r * res_scale + x
+    return conv(sd, key + ".body.2", F.relu(conv(sd, key + ".body.0", x)), alpha=res_scale) + x
 
 
 def rcab(sd, key, x):
@@ -208,7 +213,7 @@ def q_residual_group(sd, key, x, md, n_resblocks, style, pa, q_layer, num_q_laye
 
 def param_res_block(sd, key, x, md, res_scale, q_layer_nonlinearity):
     """ref: attention_manipulators/architectures.py:348-356."""
-    r = conv(sd, key + ".body.2", F.relu(conv(sd, key + ".body.0", x))) * res_scale
+    r = conv(sd, key + ".body.2", F.relu(conv(sd, key + ".body.0", x)), alpha=res_scale)
     return para_ca_layer(sd, key + ".attention_layer", r, md, q_layer_nonlinearity) + x
 
 

@@ -79,32 +79,119 @@ def test_multichunk_and_shuffle_bf16():
         close(m.bias.grad, sd["c.bias"].grad, 1e-4, 1e-5, f"{cin}->{cout} db")
 
 
+def rms(t):
+    return float(t.double().pow(2).mean().sqrt())
+
+
+def test_conv_options_bf16():
+    """Every prologue / epilogue option of the bf16 conv kernel against the rounding restatement."""
+    B, H, W = 2, 11, 37
+    x, w, b = rnd(B, 64, H, W, seed=5), rnd(64, 64, 3, 3, seed=6, scale=0.05), rnd(64, seed=7)
+    res, mask = rnd(B, 64, H, W, seed=8), rnd(B, 64, H, W, seed=9)
+    sc, sh, osc = rnd(B, 64, seed=10).abs() + 0.5, rnd(B, 64, seed=11), rnd(B, 64, seed=12)
+    cl = torch.channels_last
+    d = lambda t: t.to(DEV).contiguous(memory_format=cl) if t.dim() == 4 else t.to(DEV).contiguous()  # noqa: E731
+    xd, bd, resd, maskd, scd, shd, oscd = map(d, (x, b, res, mask, sc, sh, osc))
+    wd = w.to(DEV).contiguous()  # OIHW
+    v = hip.view_plain(H, W, 64)
+    pk = ops.pack_weight(wd, "fwd")
+    assert pk.dtype == torch.bfloat16
+
+    def run(**kw):
+        y = torch.empty(B, 64, H, W, device=DEV).contiguous(memory_format=cl)
+        ops.conv_c64(xd, v, pk, kw.pop("bias", None), (1, 64), y, v, B, H, W, 64, 64, **kw)
+        return y
+
+    base = lambda xin: F.conv2d(r16(xin), r16(w), None, padding=1)  # noqa: E731
+    gap = torch.empty(B, ops.gap_parts(H, W), 64, device=DEV)
+    y = run(bias=bd, relu=True, gap=gap)
+    want = F.relu(base(x) + b.view(1, 64, 1, 1))
+    close(y, want, 2e-5, 2e-6, "relu + bias")
+    close(gap.sum(dim=1), want.sum(dim=(2, 3)), 1e-4, 1e-5, "gap partials")
+    close(run(res=resd, alpha=0.3), 0.3 * base(x) + res, 2e-5, 2e-6, "residual + alpha")
+    close(run(mask=maskd), base(x) * (mask > 0), 2e-5, 2e-6, "mask")
+    xa = x * sc.view(B, 64, 1, 1) + sh.view(B, 64, 1, 1)
+    close(run(mask=maskd, in_scale=scd, in_shift=shd), base(xa) * (mask > 0), 2e-5, 2e-6, "affine + mask")
+    close(run(in_scale=scd, res=resd), base(x * sc.view(B, 64, 1, 1)) + res, 2e-5, 2e-6, "scale + residual")
+    close(run(out_scale=oscd), base(x) * osc.view(B, 64, 1, 1), 2e-5, 2e-6, "out scale")
+
+
+@pytest.mark.parametrize("kind", ["rcab", "resblock", "paramresblock"])
+def test_fused_block_bf16_vs_oracle_restatement(kind):
+    """Two chained convs per direction: still comparable element-wise (one rounding layer of amplification)."""
+    torch.manual_seed(8)
+    relu = torch.nn.ReLU(True)
+    x, md = rnd(2, 64, 12, 40, seed=13), rnd(2, 10, 1, 1, seed=14, scale=0.3)
+    if kind == "rcab":
+        m = A.RCAB(A.default_conv, 64, 3, 16, act=relu)
+        fn = lambda sd, xx: O.rcab(sd, "b", xx)  # noqa: E731
+    elif kind == "resblock":
+        m = A.ResBlock(A.default_conv, 64, 3, act=relu, res_scale=0.1)
+        fn = lambda sd, xx: O.res_block(sd, "b", xx, 0.1)  # noqa: E731
+    else:
+        m = A.ParamResBlock(A.default_conv, 64, 10, 3, act=relu, res_scale=0.1)
+        fn = lambda sd, xx: O.param_res_block(sd, "b", xx, md, 0.1, False)  # noqa: E731
+    sd = {"b." + k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    xo = x.clone().requires_grad_(True)
+    ref = fn(sd, xo)
+    cot = rnd(*ref.shape, seed=15)
+    ref.backward(cot)
+    m.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    out = m((xd, md.to(DEV)))[0] if kind == "paramresblock" else m(xd)
+    out.backward(cot.to(DEV))
+
+    def near(got, want, what):
+        e, n = rms(got.detach().cpu() - want.detach()), rms(want.detach())
+        assert e < 2e-4 * n + 1e-7, (kind, what, e, n)
+
+    near(out, ref, "out")
+    near(xd.grad, xo.grad, "dx")
+    for k, p in m.named_parameters():
+        near(p.grad, sd["b." + k].grad, k)
+
+
 def _net_vs_oracle(net, name, cfg, x, md=None):
+    """Deep nets cannot be compared tightly in this mode.  An activation that differs by one fp32 ulp between the
+    GPU's and the CPU's summation order can round to the neighbouring bf16 value at the next conv's input (a 2^-8
+    relative step); a perturbation d << ulp therefore leaves a rounding layer with rms sqrt(d * ulp) >> d, and after
+    four or five convs two fp32-noise-apart evaluations have decorrelated to the bf16 noise floor itself.  What a
+    whole net can show is that the HIP result is no further from the bf16 restatement than the restatement is from
+    fp32 (same noise floor, no systematic error); exactness is established per kernel and per block above."""
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
     ref = O.forward(name, sd, x.clone(), md, **cfg)
     cot = rnd(*ref.shape, seed=31)
     ref.backward(cot)
+    O.CONV_PRECISION = "fp32"
+    sd32 = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    ref32 = O.forward(name, sd32, x.clone(), md, **cfg)
+    ref32.backward(cot)
+    O.CONV_PRECISION = "bf16"
     net.to(DEV)
     out = net(x.to(DEV), md.to(DEV)) if md is not None else net(x.to(DEV))
-    close(out, ref, 5e-4, 5e-5, name + " out")
     out.backward(cot.to(DEV))
+    o = out.detach().cpu()
+    gap, err = rms(ref.detach() - ref32.detach()), rms(o - ref.detach())
+    print(f"{name}: rms(bf16 oracle - fp32 oracle) = {gap:.3e}, rms(HIP bf16 - bf16 oracle) = {err:.3e}")
+    assert gap > 0 and err < 1.5 * gap, (gap, err)
+    worst, tot_g, tot_e = 0.0, 0.0, 0.0
     for k, p in net.named_parameters():
-        close(p.grad, sd[k].grad, 3e-3, 3e-4, f"{name} grad {k}")
-    return out.detach().cpu()
+        g16, g32 = sd[k].grad, sd32[k].grad
+        gg, ee = rms(g16 - g32), rms(p.grad.cpu() - g16)
+        tot_g += gg * gg * g16.numel()
+        tot_e += ee * ee * g16.numel()
+        if g16.numel() >= 64:  # single scalars (gammas, biases of 3) are one random draw each: judged in aggregate
+            assert ee <= 2.5 * gg + 1e-5 * (1 + rms(g16)), (k, gg, ee)
+            worst = max(worst, ee / (gg + 1e-30))
+    print(f"{name}: grads: total err / total gap = {(tot_e / tot_g) ** 0.5:.3f}, worst tensor {worst:.3f}")
+    assert tot_e < 2.25 * tot_g
+    return o
 
 
 def test_rcan_reduced_bf16_vs_oracle_restatement():
     torch.manual_seed(8)
     net = A.RCAN(n_resblocks=2, n_resgroups=2, n_feats=64, scale=4)
-    x = rnd(2, 3, 20, 36, seed=30, scale=0.5)
-    out = _net_vs_oracle(net, "rcan", dict(n_resgroups=2, n_resblocks=2, scale=4), x)
-    O.CONV_PRECISION = "fp32"
-    with torch.no_grad():
-        exact = O.forward("rcan", {k: v.cpu() for k, v in net.state_dict().items()}, x, None, n_resgroups=2,
-                          n_resblocks=2, scale=4)
-    rel = float((out - exact).abs().max() / exact.abs().max())
-    print("reduced RCAN bf16 vs fp32: max rel diff", rel)
-    assert 1e-5 < rel < 2e-2
+    _net_vs_oracle(net, "rcan", dict(n_resgroups=2, n_resblocks=2, scale=4), rnd(2, 3, 20, 36, seed=30, scale=0.5))
 
 
 def test_qrcan_and_han_reduced_bf16_vs_oracle_restatement():

@@ -39,7 +39,11 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--variants", default="4,2")
     ap.add_argument("--rounds", type=int, default=0, help="interleaved A/B rounds over --variants (conv only)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     a = ap.parse_args()
+    ops.set_precision(a.precision)
+    if a.precision == "bf16":
+        a.variants = "4"  # one bf16 conv kernel; report GB/s of the two fp32 maps beside TFLOP/s
     only = set(a.only.split(",")) if a.only else None
     B, H, W = a.batch, a.hw, a.hw
     dev = torch.device("cuda:0")
@@ -66,6 +70,8 @@ def main():
             return
         t = timeit(fn, a.iters)
         res[name] = {"us": t * 1e6, unit: work / t / (1e12 if unit == "TFLOP/s" else 1e9)}
+        if a.precision == "bf16" and unit == "TFLOP/s":
+            res[name]["GB/s (2 fp32 maps)"] = 2 * fm / t / 1e9
         print(json.dumps({"kernel": name, "batch": B, **res[name]}), flush=True)
 
     variants = [int(t) for t in a.variants.split(",")]
