@@ -430,6 +430,7 @@ __device__ __forceinline__ u32x4 sisr_pack_bf16x8(f32x4 a, f32x4 b) {
 }
 
 #define BH_PIX 128  // bytes per halo pixel
+#define BE_LD 68    // floats per pixel row of the epilogue transpose buffer (64 + 4: rows 272 B apart)
 
 template <bool AFFINE, bool MASK, bool RES>
 __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) {
@@ -553,50 +554,61 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) 
 #undef BF_LOAD_B
   }
 
-  // ---- epilogue (identical to the fp32 kernel: the C/D layout of the 32x32 MFMA does not depend on dtype)
+  // ---- epilogue.  The kernel is HBM-bound, so output / mask / residual traffic must move as whole 256-B pixel
+  // rows: the accumulators (column = cout on the lane, 16 pixel columns in registers) are transposed through LDS
+  // and every thread then handles float4 pieces of eight pixels, all of its loads in flight at once.
   float os = p.alpha;
   if (p.out_scale) os *= p.out_scale[(long)b * Cout + q * 64 + co];
   const float lo = p.relu ? 0.f : -3.402823466e38f;
-  const unsigned loff_y = (unsigned)(co + 4 * hh * (int)p.yv.sW);
-  const long tile_base = (long)b * p.yv.sB + p.yv.chunk(q) + (long)w0 * p.yv.sW;
-  const bool full = (h0 + TH <= H) && (w0 + TW <= W);
+  float* ot = reinterpret_cast<float*>(ldsb);  // [TH*TW pixels][64] fp32, row stride BE_LD
+  __syncthreads();                              // every wave is done reading the halo
   float gsum = 0.f;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    const int row = h0 + 2 * ph + m;
     const f32x16 acc = m ? acc1 : acc0;
-    const long row_base = tile_base + (long)row * p.yv.sH;
-    if (full) {
+    const int prow = (2 * ph + m) * TW;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long off = row_base + (long)((r & 3) + 8 * (r >> 2)) * p.yv.sW;
-        float v = fmaxf(acc[r], lo) * os;
-        if (MASK) v = (p.mask + off)[loff_y] > 0.f ? v : 0.f;
-        if (RES) v += (p.res + off)[loff_y];
-        (p.y + off)[loff_y] = v;
-        gsum += v;
-      }
-    } else if (row < H) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cr = (r & 3) + 8 * (r >> 2);
-        if (w0 + cr + 4 * hh < W) {
-          const long off = row_base + (long)cr * p.yv.sW;
-          float v = fmaxf(acc[r], lo) * os;
-          if (MASK) v = (p.mask + off)[loff_y] > 0.f ? v : 0.f;
-          if (RES) v += (p.res + off)[loff_y];
-          (p.y + off)[loff_y] = v;
-          gsum += v;
-        }
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int pc = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float v = fmaxf(acc[r], lo) * os;
+      ot[(prow + pc) * BE_LD + co] = v;
+      if (h0 + 2 * ph + m < H && w0 + pc < W) gsum += v;
     }
   }
-  if (p.gap) {
+  if (p.gap) {  // only offered without mask / residual (host checks): v above is the final value
     gsum += __shfl_xor(gsum, 32);
     if (hh == 0) {
       const int tile = th * p.tiles_w + tw;
       const long parts = (long)p.tiles_w * p.tiles_h * 2;
       p.gap[(((long)b * parts) + tile * 2 + ph) * Cout + q * 64 + co] = gsum;
+    }
+  }
+  __syncthreads();
+  {
+    const int c4 = tid & 15, pr = tid >> 4;  // pixel pr + 16 i  ->  tile row i >> 1, column pr + 16 (i & 1)
+    const long tile_base = (long)b * p.yv.sB + p.yv.chunk(q) + (long)w0 * p.yv.sW + c4 * 4;
+    f32x4 rv[8], mv[8];
+    bool ok[8];
+    long off[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = h0 + (i >> 1), col = pr + 16 * (i & 1);
+      ok[i] = row < H && w0 + col < W;
+      off[i] = tile_base + (long)min(row, H - 1) * p.yv.sH + (long)min(col, W - 1 - w0) * p.yv.sW;
+      if (RES) rv[i] = *reinterpret_cast<const f32x4*>(p.res + off[i]);
+      if (MASK) mv[i] = *reinterpret_cast<const f32x4*>(p.mask + off[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(ot + (pr + 16 * i) * BE_LD + c4 * 4);
+      if (MASK) {
+        v[0] = mv[i][0] > 0.f ? v[0] : 0.f;
+        v[1] = mv[i][1] > 0.f ? v[1] : 0.f;
+        v[2] = mv[i][2] > 0.f ? v[2] : 0.f;
+        v[3] = mv[i][3] > 0.f ? v[3] : 0.f;
+      }
+      if (RES) v += rv[i];
+      if (ok[i]) *reinterpret_cast<f32x4*>(p.y + off[i]) = v;
     }
   }
 }
@@ -857,7 +869,9 @@ extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const
   const long nblk = (long)p.tiles_w * p.tiles_h * B;
   if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
   const dim3 grid((unsigned)nblk, p.cout_chunks);
-  const size_t lb = HALO_H * HALO_W * BH_PIX;
+  if (gap_partial && (mask || res)) return SISR_ERR_UNSUPPORTED;
+  const size_t lb_halo = HALO_H * HALO_W * BH_PIX, lb_out = TH * TW * BE_LD * sizeof(float);
+  const size_t lb = lb_halo > lb_out ? lb_halo : lb_out;
   hipStream_t st = (hipStream_t)stream;
   const int sel = (in_scale ? 4 : 0) | (mask ? 2 : 0) | (res ? 1 : 0);
   switch (sel) {
