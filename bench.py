@@ -38,6 +38,7 @@ WORKLOADS = {
     "rcan": ("rcan", {}, 1.565),
     "qrcan": ("qrcan", {"metadata": ["blur_kernel"], "style": "standard", "include_q_layer": True}, 1.565),
     "edsr": ("edsr", {}, 0.195),
+    "edsr256": ("edsr", {"num_features": 256, "num_blocks": 32, "res_scale": 0.1}, 4.940),  # the paper's EDSR
     "qedsr": ("qedsr", {"metadata": ["blur_kernel"]}, 0.195),
     "han": ("han", {}, 1.614),
     "qhan": ("qhan", {"metadata": ["blur_kernel"]}, 1.614),
@@ -50,14 +51,14 @@ WORKLOADS = {
 class ConvTimer:
     """HIP-event timing of every 64->64 body conv launch (recorded on the launch stream)."""
 
-    def __init__(self, ops):
-        self.ops, self.orig, self.events, self.on = ops, ops.conv_c64, [], False
+    def __init__(self, ops, width=64):
+        self.ops, self.orig, self.events, self.on, self.width = ops, ops.conv_c64, [], False, width
 
     def install(self):
         def timed(x, xview, packed, bias, bnq, y, yview, B, H, W, cin, cout, **kw):
             # forward launches only: in backward the data-gradient convs share the GPU with the
             # weight-gradient kernels of the side stream, so their individual durations say nothing about the kernel
-            if self.on and cin == 64 and cout == 64 and not self.ops.IN_BACKWARD:
+            if self.on and cin == self.width and cout == self.width and not self.ops.IN_BACKWARD:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 self.orig(x, xview, packed, bias, bnq, y, yview, B, H, W, cin, cout, **kw)
@@ -71,7 +72,7 @@ class ConvTimer:
         if not self.events:
             return None
         ms = [a.elapsed_time(b) for a, b, _ in self.events]
-        flop = [p * CONV_BODY_FLOP_PER_PIXEL for _, _, p in self.events]
+        flop = [p * CONV_BODY_FLOP_PER_PIXEL * (self.width // 64) ** 2 for _, _, p in self.events]
         return {"launches": len(ms), "avg_us": 1e3 * sum(ms) / len(ms), "tflops": sum(flop) / (sum(ms) * 1e-3) / 1e12,
                 "flop_per_launch": sum(flop) / len(flop)}
 
@@ -85,7 +86,8 @@ def cpu_baseline(workload, seconds_budget=30.0):
     torch.set_num_threads(min(16, os.cpu_count() or 1))  # the GPU box grants 16 host cores per GPU
     torch.manual_seed(8)
     h = sisr.available_models[name](device=torch.device("cpu"), model_save_dir="/tmp", eval_mode=False, scale=4, **params)
-    cfg = {"rcan": dict(n_resgroups=10, n_resblocks=20, scale=4), "edsr": dict(num_blocks=16, scale=4, res_scale=0.1),
+    cfg = {"rcan": dict(n_resgroups=10, n_resblocks=20, scale=4),
+           "edsr": dict(num_blocks=params.get("num_blocks", 16), scale=4, res_scale=0.1),
            "qrcan": dict(n_resgroups=10, n_resblocks=20, scale=4, style="standard", include_q_layer=True),
            "qedsr": dict(num_blocks=16, scale=4, res_scale=0.1, q_layer_nonlinearity=False),
            "han": dict(n_resgroups=10, n_resblocks=20, scale=4), "qhan": dict(n_resgroups=10, n_resblocks=20, scale=4),
@@ -158,7 +160,7 @@ def main():
     if "metadata" in params:
         kw["extra_channels"] = (torch.rand(B, 10, 1, 1, generator=g) * 0.4).to(dev)
 
-    timer = ConvTimer(sisr.ops)
+    timer = ConvTimer(sisr.ops, width=params.get("num_features", 64))
     if not args.no_kernel_timing:
         timer.install()
 
@@ -185,6 +187,8 @@ def main():
     loss_val = float(loss.item())
 
     if rank == 0:
+        label = name.upper() + (f" ({params['num_features']} features, {params['num_blocks']} blocks)"
+                                if "num_features" in params else "")
         value = world * B * args.steps / dt
         line = {
             "metric": "LR-patches/sec (128x128x3, x4) fwd+bwd", "value": value, "unit": "patches/s", "n_gpus": world,
@@ -192,7 +196,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands, f32 accumulate and storage",
             "data": "synthetic",
-            "config": {"workload": f"{name.upper()} x4 full depth, 128x128 LR -> 512x512 tiles, train step = "
+            "config": {"workload": f"{label} x4 full depth, 128x128 LR -> 512x512 tiles, train step = "
                                    f"fwd + L1 + bwd + Adam + scheduler", "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "final_loss": loss_val,
                        "algorithmic_tflops": value * tflop_per_patch},
@@ -200,7 +204,7 @@ def main():
         ks = timer.summary()
         if ks and args.precision == "bf16":
             # the bf16 conv is HBM-bound: one fp32 map in, one out (weights / bias are L2-resident)
-            nbytes = 2 * (ks["flop_per_launch"] / CONV_BODY_FLOP_PER_PIXEL) * 64 * 4
+            nbytes = 2 * (ks["flop_per_launch"] / (CONV_BODY_FLOP_PER_PIXEL * (timer.width // 64) ** 2)) * timer.width * 4
             gbs = nbytes / (ks["avg_us"] * 1e-6) / 1e9
             line["roofline"] = {"bound": "hbm", "kernel": "conv3x3_c64_bf16_kernel (64->64 body conv, forward launches)",
                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -212,7 +216,8 @@ def main():
             if os.path.exists(tj):
                 with open(tj) as f:
                     traffic = json.load(f).get(str(B))
-            line["roofline"] = {"bound": "mfma", "kernel": "conv3x3_c64_v4_kernel (64->64 body conv, forward launches)",
+            line["roofline"] = {"bound": "mfma",
+                                "kernel": f"conv3x3_c64_v4_kernel ({timer.width}->{timer.width} body conv, forward launches)",
                                 "achieved": ks["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": ks["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                 "avg_launch_us": ks["avg_us"], "launches_timed": ks["launches"],

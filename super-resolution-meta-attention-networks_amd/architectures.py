@@ -36,8 +36,9 @@ def _ca_params(seq):
 
 # ----------------------------------------------------------------------------- plain blocks
 class Upsampler(nn.Sequential):
-    """ref: advanced/common.py:20-45.  conv(C -> r^2 C) + PixelShuffle(r); the shuffle is fused into the
-    conv's store (an address map), so the nn.PixelShuffle children only keep the module indices."""
+    """ref: advanced/common.py:20-45.  conv(C -> r^2 C) + PixelShuffle(r); for n_feat = 64 the shuffle is fused
+    into the conv's store (an address map) and the nn.PixelShuffle children only keep the module indices; wider
+    nets (EDSR 256) run the conv to a plain channels-last map and shuffle with torch (two launches of 34)."""
 
     def __init__(self, conv, scale, n_feat, bn=False, act=False, bias=True):
         if bn or act:
@@ -57,7 +58,11 @@ class Upsampler(nn.Sequential):
     def forward(self, x):
         mods = list(self)
         for i in range(0, len(mods), 2):
-            x = _conv(mods[i], x, shuffle=mods[i + 1].upscale_factor)
+            r = mods[i + 1].upscale_factor
+            if mods[i].weight.shape[0] == 64 * r * r:
+                x = _conv(mods[i], x, shuffle=r)
+            else:
+                x = F.pixel_shuffle(_conv(mods[i], x), r)
         return x
 
 

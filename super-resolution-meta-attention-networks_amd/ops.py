@@ -330,25 +330,28 @@ class _ResBlock(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, caw1, cab1, caw2, cab2, m, res_scale):
         B, C, H, W = x.shape
-        if C != 64 or tuple(w1.shape) != (64, 64, 3, 3) or tuple(w2.shape) != (64, 64, 3, 3):
-            raise NotImplementedError("fused residual block is specialised for n_feats = 64")
+        has_ca, has_m = caw1 is not None, m is not None
+        if C % 64 or tuple(w1.shape) != (C, C, 3, 3) or tuple(w2.shape) != (C, C, 3, 3):
+            raise NotImplementedError("fused residual block needs n_feats to be a multiple of 64")
+        if C != 64 and (has_ca or has_m):
+            raise NotImplementedError("the gated residual blocks (RCAB / QRCAB / ParamResBlock) are specialised for "
+                                      "n_feats = 64; the plain ResBlock runs at any multiple of 64 (EDSR 256)")
         _join_pending.clear()  # a backward pass that died mid-way must not leave the join flag set
         dev = x.device
         x = _cl(x)
         w1, w2 = w1.contiguous(), w2.contiguous()
-        v = hip.view_plain(H, W, 64)
-        has_ca, has_m = caw1 is not None, m is not None
-        t1 = _empty_cl(B, 64, H, W, dev)
+        v = hip.view_plain(H, W, C)
+        t1 = _empty_cl(B, C, H, W, dev)
         if any(ctx.needs_input_grad):
             p1, ctx.pd1 = pack_pair(w1)
             p2, ctx.pd2 = pack_pair(w2)
         else:
             p1, p2 = pack_weight(w1, "fwd"), pack_weight(w2, "fwd")
-        conv_c64(x, v, p1, b1, (1, 64), t1, v, B, H, W, 64, 64, relu=True)
-        y = _empty_cl(B, 64, H, W, dev)
+        conv_c64(x, v, p1, b1, (1, 64), t1, v, B, H, W, C, C, relu=True)
+        y = _empty_cl(B, C, H, W, dev)
         saved_vecs = []
         if not has_ca and not has_m:  # ResBlock: everything fuses into conv2's epilogue
-            conv_c64(t1, v, p2, b2, (1, 64), y, v, B, H, W, 64, 64, res=x, alpha=res_scale)
+            conv_c64(t1, v, p2, b2, (1, 64), y, v, B, H, W, C, C, res=x, alpha=res_scale)
             t2 = None
         else:
             t2 = _empty_cl(B, 64, H, W, dev)
@@ -386,10 +389,11 @@ class _ResBlock(Function):
             has_ca, has_m, rs, (B, H, W), s_caw1, s_caw2 = ctx.cfg
             sv = list(ctx.saved_tensors)
             x, w1, w2, t1 = sv[:4]
+            C = x.shape[1]  # 64 for the gated modes; any multiple of 64 for the plain ResBlock
             dev = x.device
             L = hip.lib()
             dy = _cl(dy)
-            v = hip.view_plain(H, W, 64)
+            v = hip.view_plain(H, W, C)
             hw = H * W
             dcaw1 = dcab1 = dcaw2 = dcab2 = dm = None
             scale = shift = None
@@ -420,27 +424,27 @@ class _ResBlock(Function):
                               "sisr_sum_partials")
                     scale = g
             # conv2 backward: dt2 = dy*scale + shift is rebuilt on load, never stored
-            dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
-            dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
+            dw2, db2 = torch.empty_like(w2), torch.empty(C, device=dev)
+            dw1, db1 = torch.empty_like(w1), torch.empty(C, device=dev)
                 # plain first-order backward only; not under hipGraph capture (record_stream + private pools)
             side = (WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False
                     and not torch.cuda.is_current_stream_capturing())
 
             def wgrad2():
-                wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, alpha=rs, dy_scale=scale, dy_shift=shift)
+                wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, C, C, alpha=rs, dy_scale=scale, dy_shift=shift)
 
             if side:
                 ev = torch.cuda.Event()
                 ev.record()
                 _on_side(dev, ev, wgrad2, (t1, dy, scale, shift, dw2, db2))
-            dt1 = _empty_cl(B, 64, H, W, dev)
-            conv_c64(dy, v, ctx.pd2, None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1, in_scale=scale, in_shift=shift,
+            dt1 = _empty_cl(B, C, H, W, dev)
+            conv_c64(dy, v, ctx.pd2, None, (1, 64), dt1, v, B, H, W, C, C, mask=t1, in_scale=scale, in_shift=shift,
                      alpha=rs)
             if not side:
                 wgrad2()
 
             def wgrad1():
-                wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64)
+                wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, C, C)
 
             # conv1 backward (+ skip connection gradient)
             if side:
@@ -449,8 +453,8 @@ class _ResBlock(Function):
                 _on_side(dev, ev, wgrad1, (x, dt1, dw1, db1))
             dx = None
             if ctx.needs_input_grad[0]:
-                dx = _empty_cl(B, 64, H, W, dev)
-                conv_c64(dt1, v, ctx.pd1, None, (1, 64), dx, v, B, H, W, 64, 64, res=dy)
+                dx = _empty_cl(B, C, H, W, dev)
+                conv_c64(dt1, v, ctx.pd1, None, (1, 64), dx, v, B, H, W, C, C, res=dy)
             if not side:
                 wgrad1()
             return dx, dw1, db1, dw2, db2, dcaw1, dcab1, dcaw2, dcab2, (dm if has_m else None), None

@@ -244,6 +244,14 @@ def test_edsr_reduced_vs_oracle(scale):
     net_vs_oracle(net, "edsr", dict(num_blocks=2, scale=scale, res_scale=0.1), rnd(1, 3, 17, 23, seed=32, scale=0.5))
 
 
+def test_edsr_paper_width_vs_oracle():
+    """EDSR at the paper's width (n_feats = 256): multi-chunk fused ResBlock, 256 -> 1024
+    upsampler convs, 256 -> 3 tail."""
+    torch.manual_seed(8)
+    net = A.EDSR(net_features=256, num_blocks=2, scale=4, res_scale=0.1)
+    net_vs_oracle(net, "edsr", dict(num_blocks=2, scale=4, res_scale=0.1), rnd(1, 3, 18, 35, seed=37, scale=0.5))
+
+
 def test_qrcan_reduced_vs_oracle():
     torch.manual_seed(8)
     net = A.QRCAN(n_resblocks=3, n_resgroups=2, n_feats=64, scale=4, style="standard", num_metadata=10,
