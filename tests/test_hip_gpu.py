@@ -385,6 +385,44 @@ def test_two_ranks_share_one_gpu_grad_reducer(tmp_path):
     assert np.isfinite(line["config"]["final_loss"])
 
 
+def test_rccl_backend_single_rank_grad_reducer():
+    """The nccl (= RCCL) transport of GradReducer on the one GPU this box has: a world of one rank still runs
+    init_process_group('nccl'), the bucketed asynchronous all_reduce on the side stream and the join, and must
+    reproduce the plain single-process losses bit for bit (sum over one rank, times 1/1)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, json, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import sisr_amd\n"
+        "use_dp = sys.argv[1] == '1'\n"
+        "torch.cuda.set_device(0)\n"
+        "if use_dp:\n"
+        "    dist.init_process_group(backend='nccl', rank=0, world_size=1)\n"
+        "torch.manual_seed(8)\n"
+        "h = sisr_amd.available_models['edsr'](device=0, model_save_dir='/tmp', eval_mode=False, scale=4, lr=1e-4)\n"
+        "if use_dp:\n"
+        "    h.set_multi_gpu()\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "out = []\n"
+        "for _ in range(3):\n"
+        "    x, y = torch.rand(2, 3, 24, 24, generator=g), torch.rand(2, 3, 96, 96, generator=g)\n"
+        "    loss, _ = h.run_train(x, y)\n"
+        "    out.append(float(loss))\n"
+        "print(json.dumps(out))\n"
+        "if use_dp:\n"
+        "    dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741")
+    res = {}
+    for flag in ("0", "1"):
+        out = subprocess.run([sys.executable, "-c", code, flag], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[flag] = [ln for ln in out.stdout.splitlines() if ln.startswith("[")][-1]
+    assert res["0"] == res["1"], res
+
+
 def test_set5_training_psnr_parity_at_equal_steps():
     """north_star: 'PSNR on Set5 within 0.02 dB of the reference at equal steps'.  EDSR-baseline (16 blocks,
     full depth) trained for 40 Adam steps on seeded Set5 crops, once on the HIP kernels and once by the CPU
