@@ -49,7 +49,8 @@ int sisr_pack_conv3x3(const float* w, float* packed, int cout, int cin, int64_t 
 int sisr_pack_conv3x3_both(const float* w, float* packed_fwd, float* packed_dgrad, int cout, int cin, int shuffle_r,
                            void* stream);
 int sisr_conv3x3_c64_gap_parts(int H, int W);
-int sisr_conv3x3_c64_set_variant(int v); /* 4 issue-lean kernel + general fallback (default), 2 general kernel only,
+int sisr_conv3x3_c64_set_variant(int v); /* 4 issue-lean kernel, tile height by grid size, + general fallback (default);
+                                             5 / 6 force its 4-row / 2-row tile; 2 general kernel only;
                                              13 / 16 diagnostic builds (no operand loads / phase stamps) */
 int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked, const float* bias, int bias_n,
                      int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,

@@ -185,9 +185,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
   float os = p.alpha;
   if (p.out_scale) os *= p.out_scale[(long)b * Cout + q * 64 + co];
   const long ybase = (long)b * p.yv.sB + p.yv.chunk(q) + co;
-  float gsum = 0.f;
+  float grow[2];  // GAP partial of the 2-row strip = (row 0) + (row 1), the order every conv kernel uses
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
+    float gsum = 0.f;
     const int row = h0 + 2 * ph + m;
     const f32x16 acc = m ? acc1 : acc0;
 #pragma unroll
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
         gsum += v;
       }
     }
+    grow[m] = gsum + __shfl_xor(gsum, 32);
   }
   if (ABL == 6) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -218,11 +220,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
     return;
   }
   if (p.gap) {
-    gsum += __shfl_xor(gsum, 32);
     if (hh == 0) {
       const int tile = th * p.tiles_w + tw;
       const long parts = (long)p.tiles_w * p.tiles_h * 2;
-      p.gap[(((long)b * parts) + tile * 2 + ph) * Cout + q * 64 + co] = gsum;
+      p.gap[(((long)b * parts) + tile * 2 + ph) * Cout + q * 64 + co] = grow[0] + grow[1];
     }
   }
 }
@@ -242,8 +243,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
 //     tiles take a predicate-free path.
 // Covers the block-hot combinations (plain/ReLU/scale, +GAP, +residual, +mask, +mask+affine prologue); anything
 // else is routed to conv3x3_c64_kernel.  Results are bit-identical to it (same MFMA order).
-template <bool AFFINE, bool MASK, bool RES>
-__global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
+// MT = output rows (32-pixel M-tiles) per wave: 2 -> the 4-row tile described above; 1 -> 2-row tiles (four rows
+// of halo, 34.8 KB, one accumulator) for launches whose 4-row grid has fewer workgroups than the chip has CUs (one 128x128 sample: 22.7 -> 14.3 us).
+// Both produce bit-identical outputs and GAP partials (same MFMA order per output element; partials are per
+// 2-row strip, summed row by row).
+template <bool AFFINE, bool MASK, bool RES, int MT>
+__global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(ConvParams p) {
+  constexpr int THv = 2 * MT, HHv = THv + 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.y;
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
   bid /= p.tiles_w;
   const int th = bid % p.tiles_h;
   const int b = bid / p.tiles_h;
-  const int h0 = th * TH, w0 = tw * TW;
+  const int h0 = th * THv, w0 = tw * TW;
   const int ph = __builtin_amdgcn_readfirstlane(wave >> 1), ch = __builtin_amdgcn_readfirstlane(wave & 1);
   const int n = lane & 31, hh = lane >> 5;
   const int H = p.H, W = p.W;
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
   const int Cout = p.cout_chunks * 64;
 
   const float bv = p.bias ? p.bias[co * p.bias_n + q * p.bias_q] : 0.f;
-  f32x16 acc0, acc1;
+  f32x16 acc0, acc1;  // acc1 is dead code for MT == 1
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = bv;
 
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
   for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      aoff[kw][j] = ((2 * ph) * HALO_W + n + kw) * 64 + (((2 * j + hh) ^ ((n + kw) & 15)) << 2);
+      aoff[kw][j] = ((MT * ph) * HALO_W + n + kw) * 64 + (((2 * j + hh) ^ ((n + kw) & 15)) << 2);
   const unsigned boff = hh * 256 + co * 4;
 
   for (int c = 0; c < p.cin_chunks; ++c) {
@@ -300,9 +306,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
         goff[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c4 * 4);
         loff[k] = col * 64 + ((c4 ^ (col & 15)) << 2);
       }
-      f32x4 v[HALO_H][3];
+      f32x4 v[HHv][3];
 #pragma unroll
-      for (int r = 0; r < HALO_H; ++r) {
+      for (int r = 0; r < HHv; ++r) {
         const int gh = h0 - 1 + r;
         const float* xrow = xb + (long)min(max(gh, 0), H - 1) * p.xv.sH;  // scalar
 #pragma unroll
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
           if (k < 2 || pcol < 2) v[r][k] = *reinterpret_cast<const f32x4*>(xrow + goff[k]);
       }
 #pragma unroll
-      for (int r = 0; r < HALO_H; ++r) {
+      for (int r = 0; r < HHv; ++r) {
         const int gh = h0 - 1 + r;
         const bool rok = gh >= 0 && gh < H;  // scalar
 #pragma unroll
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       aq[s][0] = V4_LOAD_A(0, s);
-      aq[s][1] = V4_LOAD_A(1, s);
+      if (MT == 2) aq[s][1] = V4_LOAD_A(1, s);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
       if (s + 6 < 72) bq[(s + 6) & 7] = V4_LOAD_B(s + 6);
       if (s + 2 < 72) {
         aq[(s + 2) & 3][0] = V4_LOAD_A(0, s + 2);
-        aq[(s + 2) & 3][1] = V4_LOAD_A(1, s + 2);
+        if (MT == 2) aq[(s + 2) & 3][1] = V4_LOAD_A(1, s + 2);
       }
       const f32x4 bb = bq[s & 7];
       const f32x4 a0 = aq[s & 3][0];
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bb[e], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bb[e], acc1, 0, 0, 0);
+        if (MT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bb[e], acc1, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -366,11 +372,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
   const float lo = p.relu ? 0.f : -3.402823466e38f;
   const unsigned loff_y = (unsigned)(co + 4 * hh * (int)p.yv.sW);  // lane part of every output address
   const long tile_base = (long)b * p.yv.sB + p.yv.chunk(q) + (long)w0 * p.yv.sW;  // scalar
-  const bool full = (h0 + TH <= H) && (w0 + TW <= W);                              // scalar
-  float gsum = 0.f;
+  const bool full = (h0 + THv <= H) && (w0 + TW <= W);                             // scalar
+  float grow[2] = {0.f, 0.f};  // per output row: the GAP partial is (row 0) + (row 1) of a 2-row strip
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int row = h0 + 2 * ph + m;
+  for (int m = 0; m < MT; ++m) {
+    float gsum = 0.f;
+    const int row = h0 + MT * ph + m;
     const f32x16 acc = m ? acc1 : acc0;
     const long row_base = tile_base + (long)row * p.yv.sH;  // scalar
     if (full) {
@@ -397,13 +404,21 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_v4_kernel(ConvParams p) {
         }
       }
     }
+    grow[m] = gsum + __shfl_xor(gsum, 32);
   }
   if (p.gap) {
-    gsum += __shfl_xor(gsum, 32);
-    if (hh == 0) {
-      const int tile = th * p.tiles_w + tw;
-      const long parts = (long)p.tiles_w * p.tiles_h * 2;
-      p.gap[(((long)b * parts) + tile * 2 + ph) * Cout + q * 64 + co] = gsum;
+    const long parts = (long)p.tiles_w * ((H + 3) / 4) * 2;  // one partial per (2-row strip, 32 columns)
+    if (MT == 2) {
+      if (hh == 0) p.gap[(((long)b * parts) + (th * p.tiles_w + tw) * 2 + ph) * Cout + q * 64 + co] = grow[0] + grow[1];
+    } else {  // the strip's two rows live in waves ph = 0 and ph = 1: add them through LDS in row order
+      __syncthreads();
+      if (ph == 1 && hh == 0) lds[co] = grow[0];
+      __syncthreads();
+      if (ph == 0 && hh == 0) {
+        float* g = p.gap + (((long)b * parts) + ((th >> 1) * p.tiles_w + tw) * 2 + (th & 1)) * Cout + q * 64 + co;
+        g[0] = grow[0] + lds[co];
+        if ((th & 1) == 0 && th + 1 >= p.tiles_h) g[Cout] = 0.f;  // H % 4 in {1, 2}: the tile's second strip is empty
+      }
     }
   }
 }
@@ -562,9 +577,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) 
   const float lo = p.relu ? 0.f : -3.402823466e38f;
   float* ot = reinterpret_cast<float*>(ldsb);  // [TH*TW pixels][64] fp32, row stride BE_LD
   __syncthreads();                              // every wave is done reading the halo
-  float gsum = 0.f;
+  float grow[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
+    float gsum = 0.f;
     const f32x16 acc = m ? acc1 : acc0;
     const int prow = (2 * ph + m) * TW;
 #pragma unroll
@@ -574,13 +590,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) 
       ot[(prow + pc) * BE_LD + co] = v;
       if (h0 + 2 * ph + m < H && w0 + pc < W) gsum += v;
     }
+    grow[m] = gsum + __shfl_xor(gsum, 32);
   }
   if (p.gap) {  // only offered without mask / residual (host checks): v above is the final value
-    gsum += __shfl_xor(gsum, 32);
     if (hh == 0) {
       const int tile = th * p.tiles_w + tw;
       const long parts = (long)p.tiles_w * p.tiles_h * 2;
-      p.gap[(((long)b * parts) + tile * 2 + ph) * Cout + q * 64 + co] = gsum;
+      p.gap[(((long)b * parts) + tile * 2 + ph) * Cout + q * 64 + co] = grow[0] + grow[1];
     }
   }
   __syncthreads();
@@ -743,11 +759,13 @@ extern "C" int sisr_pack_conv3x3_both(const float* w, float* packed_fwd, float* 
   return sisr_check_launch();
 }
 
-// Kernel selection (process-wide, read-only during launches): 4 = issue-lean kernel with the general kernel as
-// fallback (default), 2 = general kernel only, 13 / 16 = diagnostic builds of the general kernel (see above).
+// Kernel selection (process-wide, read-only during launches): 4 = issue-lean kernel (2-row tiles on small grids,
+// 4-row tiles otherwise) with the general kernel as fallback (default); 5 / 6 = the same with the 4-row / 2-row
+// tile forced; 2 = general kernel only; 13 / 16 = diagnostic builds of the general kernel (see above).
 static int g_conv_variant = 4;
+#define SMALL_GRID_BLOCKS 200  // 4-row-tile workgroups below which the 2-row kernel is used (measured: 1.6x at 128, a tie or worse from 256 up)
 extern "C" int sisr_conv3x3_c64_set_variant(int v) {
-  if (v != 4 && v != 2 && v != 13 && v != 16) return SISR_ERR_ARG;
+  if (v != 4 && v != 5 && v != 6 && v != 2 && v != 13 && v != 16) return SISR_ERR_ARG;
   g_conv_variant = v;
   return SISR_OK;
 }
@@ -791,21 +809,39 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   const long nblk = (long)p.tiles_w * p.tiles_h * B;
   if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
   const dim3 grid((unsigned)nblk, p.cout_chunks);
-  if (g_conv_variant == 4) {
+  if (g_conv_variant == 4 || g_conv_variant == 5 || g_conv_variant == 6) {
     const bool aff = in_scale != nullptr, msk = mask != nullptr, rs = res != nullptr;
-    const size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (!(in_shift && !in_scale) && !(aff && !msk) && !(msk && rs)) {
+      // Grids with fewer 4-row workgroups than CUs (a single 128x128 sample) leave half the chip idle: halve the tile.  Variant 5 / 6 force
+      // the 4-row / 2-row kernel (A/B measurements); results are bit-identical either way.
+      const bool small = g_conv_variant == 6 || (g_conv_variant == 4 && nblk * p.cout_chunks < SMALL_GRID_BLOCKS);
+      if (small) {
+        p.tiles_h = (H + 1) / 2;
+        const dim3 grid2((unsigned)((long)p.tiles_w * p.tiles_h * B), p.cout_chunks);
+        const size_t lb2 = 4 * HALO_W * 64 * sizeof(float);
+        if (aff)
+          hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 1>), grid2, dim3(256), lb2, st, p);
+        else if (msk)
+          hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, true, false, 1>), grid2, dim3(256), lb2, st, p);
+        else if (rs)
+          hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, true, 1>), grid2, dim3(256), lb2, st, p);
+        else
+          hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, 1>), grid2, dim3(256), lb2, st, p);
+        return sisr_check_launch();
+      }
+      const size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
       if (aff)
-        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false>), grid, dim3(256), lb, st, p);
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 2>), grid, dim3(256), lb, st, p);
       else if (msk)
-        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, true, false>), grid, dim3(256), lb, st, p);
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, true, false, 2>), grid, dim3(256), lb, st, p);
       else if (rs)
-        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, true>), grid, dim3(256), lb, st, p);
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, true, 2>), grid, dim3(256), lb, st, p);
       else
-        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false>), grid, dim3(256), lb, st, p);
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, 2>), grid, dim3(256), lb, st, p);
       return sisr_check_launch();
     }
+    const size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
     hipLaunchKernelGGL(conv3x3_c64_kernel<0>, grid, dim3(256), lb, st, p);
     return sisr_check_launch();
   }

@@ -51,6 +51,44 @@ def test_conv64_fwd_bwd(B, H, W):
     close(bg.grad, b.grad, 2e-4, 2e-5, "db")
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 16, 16), (1, 13, 9), (1, 57, 86), (2, 4, 32), (1, 5, 33), (1, 128, 128)])
+def test_conv_tile_heights_are_bit_identical(B, H, W):
+    """The issue-lean conv picks 2-row tiles on small grids and 4-row tiles on large ones (variant 4); forcing
+    either (variants 6 / 5) must give the same bits for outputs and GAP partials, for every epilogue it serves."""
+    hip = sisr_amd.hip
+    cl = torch.channels_last
+    x = rnd(B, 64, H, W, seed=50).to(DEV).contiguous(memory_format=cl)
+    res = rnd(B, 64, H, W, seed=51).to(DEV).contiguous(memory_format=cl)
+    mask = rnd(B, 64, H, W, seed=52).to(DEV).contiguous(memory_format=cl)
+    w = rnd(64, 64, 3, 3, seed=53, scale=0.05).to(DEV)
+    b = rnd(64, seed=54).to(DEV)
+    sc, sh = (rnd(B, 64, seed=55).abs() + 0.5).to(DEV), rnd(B, 64, seed=56).to(DEV)
+    v = hip.view_plain(H, W, 64)
+    pk = ops.pack_weight(w, "fwd")
+    cases = [dict(bias=b, relu=True, gap=True), dict(res=res, alpha=0.3), dict(mask=mask),
+             dict(mask=mask, in_scale=sc, in_shift=sh)]
+    outs = {}
+    try:
+        for variant in (5, 6):
+            hip.check(hip.lib().sisr_conv3x3_c64_set_variant(variant), "set_variant")
+            for i, kw in enumerate(cases):
+                kw = dict(kw)
+                y = torch.zeros(B, 64, H, W, device=DEV).contiguous(memory_format=cl)
+                gap = torch.full((B, ops.gap_parts(H, W), 64), float("nan"), device=DEV) if kw.pop("gap", False) else None
+                ops.conv_c64(x, v, pk, kw.pop("bias", None), (1, 64), y, v, B, H, W, 64, 64, gap=gap, **kw)
+                outs[(variant, i)] = (y, gap)
+    finally:
+        hip.lib().sisr_conv3x3_c64_set_variant(4)
+    for i in range(len(cases)):
+        y5, g5 = outs[(5, i)]
+        y6, g6 = outs[(6, i)]
+        assert torch.equal(y5, y6), f"case {i}: outputs differ between tile heights"
+        if g5 is not None:
+            assert torch.equal(g5, g6), f"case {i}: GAP partials differ between tile heights"
+    want = F.relu(F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1))
+    close(outs[(5, 0)][0], want, 2e-5, 2e-6, "4-row tile vs ATen")
+
+
 def test_conv_residual_alpha_and_multichunk():
     # 128 -> 192 channels, y = conv*alpha + res  (multi-chunk K loop and multiple output chunks)
     B, H, W = 1, 9, 35

@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--hw", type=int, default=128)
     ap.add_argument("--only", default="")
-    ap.add_argument("--variants", default="4,2")
+    ap.add_argument("--variants", default="4,2", help="conv kernel selections to time: 4 auto, 5 / 6 forced 4-row / 2-row tile, 2 general")
     ap.add_argument("--rounds", type=int, default=0, help="interleaved A/B rounds over --variants (conv only)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     a = ap.parse_args()
