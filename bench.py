@@ -206,9 +206,14 @@ def main():
             # the bf16 conv is HBM-bound: one fp32 map in, one out (weights / bias are L2-resident)
             nbytes = 2 * (ks["flop_per_launch"] / (CONV_BODY_FLOP_PER_PIXEL * (timer.width // 64) ** 2)) * timer.width * 4
             gbs = nbytes / (ks["avg_us"] * 1e-6) / 1e9
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "traffic_conv3x3_c64_bf16.json")
+            if os.path.exists(tj) and timer.width == 64:
+                with open(tj) as f:
+                    traffic = json.load(f).get(str(B))
             line["roofline"] = {"bound": "hbm", "kernel": "conv3x3_c64_bf16_kernel (64->64 body conv, forward launches)",
                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                "traffic": None, "avg_launch_us": ks["avg_us"], "launches_timed": ks["launches"],
+                                "traffic": traffic, "avg_launch_us": ks["avg_us"], "launches_timed": ks["launches"],
                                 "bytes_per_launch": nbytes, "mfma_tflops": ks["tflops"]}
         elif ks:
             traffic = None
