@@ -55,7 +55,14 @@ int sisr_conv3x3_c64_set_variant(int v); /* 4 issue-lean kernel, tile height by 
 int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked, const float* bias, int bias_n,
                      int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,
                      const float* in_scale, const float* in_shift, const float* out_scale, float alpha, int relu,
-                     float* gap_partial, int B, int H, int W, int cin, int cout, void* stream);
+                     float* gap_partial, const float* gate_add, float* gate_out, const float* dot, int B, int H,
+                     int W, int cin, int cout, void* stream);
+/* gate_add / gate_out / dot (all nullable; 64 -> 64, x and y in one layout) fuse the gated-residual chain of
+ * RCAB / QRCAB stacks (ref: advanced/architectures.py:68-71, :107-110) into the neighbouring convs:
+ *   gate_add + gate_out : the conv reads  x * in_scale[b,c] + gate_add  (the previous block's `res * y + x`) and
+ *                         writes that map to gate_out once -- no separate gate pass in forward;
+ *   dot                 : gap_partial receives sum(v * dot) instead of sum(v): the gate gradient sum(dY * t) of
+ *                         the block below, taken while its dY is being produced -- no separate reduction pass. */
 
 /* ---- 3x3 convolution weight + bias gradient (fp32 MFMA), deterministic two-stage reduction ------
  * ref: autograd's convolution_backward for default_conv (loss.backward(), SISR/models/__init__.py:483).
@@ -147,7 +154,8 @@ int sisr_pack_conv3x3_bf16_both(const float* w, void* packed_fwd, void* packed_d
 int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const void* wpacked_bf16, const float* bias, int bias_n,
                           int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,
                           const float* in_scale, const float* in_shift, const float* out_scale, float alpha, int relu,
-                          float* gap_partial, int B, int H, int W, int cin, int cout, void* stream);
+                          float* gap_partial, const float* gate_add, float* gate_out, const float* dot,
+                          int B, int H, int W, int cin, int cout, void* stream);
 size_t sisr_wgrad3x3_c64_bf16_workspace_bytes(int B, int H, int W, int cin, int cout);
 int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
                            const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so, int64_t si,

@@ -123,8 +123,12 @@ class ResidualGroup(nn.Module):
         self.body = nn.Sequential(*body)
 
     def forward(self, x):
-        res = x
         mods = list(self.body)
+        if ops.fused_groups_enabled() and x.shape[1] == 64:
+            blocks = [(b.body[0].weight, b.body[0].bias, b.body[2].weight, b.body[2].bias,
+                       _ca_params(b.body[3].conv_du), None) for b in mods[:-1]]
+            return ops.gated_group(x, blocks, mods[-1].weight, mods[-1].bias)
+        res = x
         for blk in mods[:-1]:
             res = blk(res)
         return _conv(mods[-1], res, residual=x)
@@ -343,6 +347,11 @@ class QResidualGroup(nn.Module):
 
     def forward(self, x):
         feat, md = x
+        if (ops.fused_groups_enabled() and feat.shape[1] == 64
+                and all(not b.pa and b.final_body.style == 'standard' for b in self.body)):
+            blocks = [(b.body[0].weight, b.body[0].bias, b.body[2].weight, b.body[2].bias,
+                       _ca_params(b.final_body.conv_du), b.q_node.gate(md) if b.q_layer else None) for b in self.body]
+            return ops.gated_group(feat, blocks, self.final_body.weight, self.final_body.bias), md
         res = feat
         for blk in self.body:
             res, _ = blk((res, md))

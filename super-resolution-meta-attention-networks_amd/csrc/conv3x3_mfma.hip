@@ -20,6 +20,7 @@
 // Fused epilogue: +bias, ReLU, scalar and per-(b,co) scale, ReLU-mask, residual add, pixel-shuffle
 // address map, and per-wave partial sums for the global average pool.
 #include "sisr_common.h"
+#include <string.h>
 
 #define TH 4
 #define TW 32
@@ -41,6 +42,9 @@ struct ConvParams {
   const float* in_shift;
   const float* out_scale;
   float* gap;
+  const float* gate_add;  // GATE prologue: input = x * in_scale[b,c] + gate_add (x's layout), ...
+  float* gate_out;        // ... whose in-image value is also written here once (by the tile that owns the pixel)
+  const float* dot;       // DOT epilogue: gap partials hold sum(v * dot) instead of sum(v) (y's layout)
   float alpha;
   int bias_n, bias_q;
   int B, H, W, cin_chunks, cout_chunks, relu, tiles_w, tiles_h;
@@ -247,7 +251,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
 // of halo, 34.8 KB, one accumulator) for launches whose 4-row grid has fewer workgroups than the chip has CUs (one 128x128 sample: 22.7 -> 14.3 us).
 // Both produce bit-identical outputs and GAP partials (same MFMA order per output element; partials are per
 // 2-row strip, summed row by row).
-template <bool AFFINE, bool MASK, bool RES, int MT>
+// GATE (forward of a gated residual chain): the conv's input is the previous block's output
+//   y = t * gate[b,c] + skip,  built while the halo is staged instead of by a separate pass; the tile that owns a
+// pixel also writes y out (the next skip / weight-gradient operand), so the map is read and written exactly once
+// more than by a plain conv, hidden under the MFMA-bound K loop.  DOT (backward of the same chain): the GAP
+// partial slot receives sum(v * dot) -- the gate gradient sum(dY * t) of the block that produced this conv's
+// input -- saving that block's separate reduction pass over two maps.
+template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false>
 __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(ConvParams p) {
   constexpr int THv = 2 * MT, HHv = THv + 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -306,26 +316,61 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
         goff[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c4 * 4);
         loff[k] = col * 64 + ((c4 ^ (col & 15)) << 2);
       }
-      f32x4 v[HHv][3];
+      if (!GATE) {
+        f32x4 v[HHv][3];
 #pragma unroll
-      for (int r = 0; r < HHv; ++r) {
-        const int gh = h0 - 1 + r;
-        const float* xrow = xb + (long)min(max(gh, 0), H - 1) * p.xv.sH;  // scalar
+        for (int r = 0; r < HHv; ++r) {
+          const int gh = h0 - 1 + r;
+          const float* xrow = xb + (long)min(max(gh, 0), H - 1) * p.xv.sH;  // scalar
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (k < 2 || pcol < 2) v[r][k] = *reinterpret_cast<const f32x4*>(xrow + goff[k]);
-      }
+          for (int k = 0; k < 3; ++k)
+            if (k < 2 || pcol < 2) v[r][k] = *reinterpret_cast<const f32x4*>(xrow + goff[k]);
+        }
 #pragma unroll
-      for (int r = 0; r < HHv; ++r) {
-        const int gh = h0 - 1 + r;
-        const bool rok = gh >= 0 && gh < H;  // scalar
+        for (int r = 0; r < HHv; ++r) {
+          const int gh = h0 - 1 + r;
+          const bool rok = gh >= 0 && gh < H;  // scalar
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (k < 2 || pcol < 2) {
-            f32x4 t = v[r][k];
-            if (AFFINE) t = t * s4 + t4;
-            *reinterpret_cast<f32x4*>(lds + r * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
+          for (int k = 0; k < 3; ++k)
+            if (k < 2 || pcol < 2) {
+              f32x4 t = v[r][k];
+              if (AFFINE) t = t * s4 + t4;
+              *reinterpret_cast<f32x4*>(lds + r * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
+            }
+        }
+      } else {  // y = t * gate + skip on the fly; rows in batches of HHv / 2 (two operand tensors in flight)
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.in_scale + (long)b * 64 + c4 * 4);
+        const long boffs = (long)b * p.xv.sB;
+        constexpr int RB = HHv / 2;
+#pragma unroll
+        for (int r0 = 0; r0 < HHv; r0 += RB) {
+          f32x4 v[RB][3], u[RB][3];
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            const long ro = boffs + (long)min(max(h0 - 1 + r0 + r, 0), H - 1) * p.xv.sH;  // scalar
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              if (k < 2 || pcol < 2) {
+                v[r][k] = *reinterpret_cast<const f32x4*>(p.x + ro + goff[k]);
+                u[r][k] = *reinterpret_cast<const f32x4*>(p.gate_add + ro + goff[k]);
+              }
           }
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            const int hr = r0 + r, gh = h0 - 1 + hr;
+            const bool rok = gh >= 0 && gh < H;               // scalar
+            const bool rown = hr >= 1 && hr <= THv && gh < H;  // scalar: a row this tile owns
+            const long ro = boffs + (long)min(max(gh, 0), H - 1) * p.xv.sH;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              if (k < 2 || pcol < 2) {
+                const f32x4 t = v[r][k] * g4 + u[r][k];
+                *reinterpret_cast<f32x4*>(lds + hr * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
+                const int col = pcol + 16 * k;
+                if (rown && cok[k] && col >= 1 && col <= TW) *reinterpret_cast<f32x4*>(p.gate_out + ro + goff[k]) = t;
+              }
+          }
+        }
       }
     }
     __syncthreads();
@@ -388,7 +433,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
         if (MASK) v = (p.mask + off)[loff_y] > 0.f ? v : 0.f;
         if (RES) v += (p.res + off)[loff_y];
         (p.y + off)[loff_y] = v;
-        gsum += v;
+        gsum += DOT ? v * (p.dot + off)[loff_y] : v;
       }
     } else if (row < H) {
 #pragma unroll
@@ -400,7 +445,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
           if (MASK) v = (p.mask + off)[loff_y] > 0.f ? v : 0.f;
           if (RES) v += (p.res + off)[loff_y];
           (p.y + off)[loff_y] = v;
-          gsum += v;
+          gsum += DOT ? v * (p.dot + off)[loff_y] : v;
         }
       }
     }
@@ -775,8 +820,9 @@ extern "C" int sisr_conv3x3_c64_gap_parts(int H, int W) { return ((H + TH - 1) /
 extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked, const float* bias,
                                 int bias_n, int bias_q, float* y, const int64_t* yview, const float* res,
                                 const float* mask, const float* in_scale, const float* in_shift,
-                                const float* out_scale, float alpha, int relu, float* gap_partial, int B, int H,
-                                int W, int cin, int cout, void* stream) {
+                                const float* out_scale, float alpha, int relu, float* gap_partial,
+                                const float* gate_add, float* gate_out, const float* dot, int B, int H, int W, int cin,
+                                int cout, void* stream) {
   if (!x || !wpacked || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
   if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
   if (!sisr_aligned16(x) || !sisr_aligned16(wpacked) || !sisr_aligned16(in_scale) || !sisr_aligned16(in_shift))
@@ -795,6 +841,9 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   p.in_shift = in_shift;
   p.out_scale = out_scale;
   p.gap = gap_partial;
+  p.gate_add = gate_add;
+  p.gate_out = gate_out;
+  p.dot = dot;
   p.alpha = alpha;
   p.bias_n = bias_n;
   p.bias_q = bias_q;
@@ -809,6 +858,35 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   const long nblk = (long)p.tiles_w * p.tiles_h * B;
   if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
   const dim3 grid((unsigned)nblk, p.cout_chunks);
+  if (gate_add || gate_out || dot) {
+    // fused gated-residual chain (64 -> 64 only): GATE prologue [+ residual], or DOT epilogue [+ residual]
+    const bool gate = gate_add != nullptr;
+    if (gate != (gate_out != nullptr) || (gate && !in_scale) || (gate && dot) || (dot && !gap_partial) ||
+        (!gate && in_scale) || in_shift || mask || out_scale || cin != 64 || cout != 64 ||
+        !sisr_aligned16(gate_add) || !sisr_aligned16(gate_out))
+      return SISR_ERR_UNSUPPORTED;
+    if (memcmp(xview, yview, 6 * sizeof(int64_t)) != 0) return SISR_ERR_UNSUPPORTED;  // skip / dot share one layout
+    hipStream_t st = (hipStream_t)stream;
+    const bool small = g_conv_variant == 6 || (g_conv_variant != 5 && nblk < SMALL_GRID_BLOCKS);
+    const bool rs = res != nullptr;
+    dim3 g = grid;
+    size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
+    if (small) {
+      p.tiles_h = (H + 1) / 2;
+      g = dim3((unsigned)((long)p.tiles_w * p.tiles_h * B), 1);
+      lb = 4 * HALO_W * 64 * sizeof(float);
+    }
+#define V4X(RS, MTV, GT, DT) hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, RS, MTV, GT, DT>), g, dim3(256), lb, st, p)
+    if (gate) {
+      if (small) { if (rs) V4X(true, 1, true, false); else V4X(false, 1, true, false); }
+      else       { if (rs) V4X(true, 2, true, false); else V4X(false, 2, true, false); }
+    } else {
+      if (small) { if (rs) V4X(true, 1, false, true); else V4X(false, 1, false, true); }
+      else       { if (rs) V4X(true, 2, false, true); else V4X(false, 2, false, true); }
+    }
+#undef V4X
+    return sisr_check_launch();
+  }
   if (g_conv_variant == 4 || g_conv_variant == 5 || g_conv_variant == 6) {
     const bool aff = in_scale != nullptr, msk = mask != nullptr, rs = res != nullptr;
     hipStream_t st = (hipStream_t)stream;
@@ -870,9 +948,11 @@ extern "C" int sisr_pack_conv3x3_bf16_both(const float* w, void* packed_fwd, voi
 extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const void* wpacked_bf16, const float* bias,
                                      int bias_n, int bias_q, float* y, const int64_t* yview, const float* res,
                                      const float* mask, const float* in_scale, const float* in_shift,
-                                     const float* out_scale, float alpha, int relu, float* gap_partial, int B, int H,
-                                     int W, int cin, int cout, void* stream) {
+                                     const float* out_scale, float alpha, int relu, float* gap_partial,
+                                     const float* gate_add, float* gate_out, const float* dot, int B, int H, int W,
+                                     int cin, int cout, void* stream) {
   if (!x || !wpacked_bf16 || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if (gate_add || gate_out || dot) return SISR_ERR_UNSUPPORTED;  // the fused chain is built on the fp32 kernel only
   if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
   if (in_shift && !in_scale) return SISR_ERR_UNSUPPORTED;
   if (!sisr_aligned16(x) || !sisr_aligned16(wpacked_bf16) || !sisr_aligned16(in_scale) || !sisr_aligned16(in_shift))
@@ -891,6 +971,9 @@ extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const
   p.in_shift = in_shift;
   p.out_scale = out_scale;
   p.gap = gap_partial;
+  p.gate_add = nullptr;
+  p.gate_out = nullptr;
+  p.dot = nullptr;
   p.alpha = alpha;
   p.bias_n = bias_n;
   p.bias_q = bias_q;

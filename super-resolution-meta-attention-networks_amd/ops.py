@@ -84,6 +84,7 @@ def _vec(B, C, device):
 #           fp32 feature maps / gradients / optimiser state in HBM (BASELINE config "HAN x4 bf16 ... MFMA")
 # Process-wide; packed weights are rebuilt every step, so switching between steps is safe.
 PRECISION = os.environ.get("SISR_PRECISION", "fp32")
+FUSED_GROUPS = os.environ.get("SISR_FUSED_GROUPS", "1") != "0"  # group-level autograd node for CA block stacks
 
 
 def set_precision(name):
@@ -132,13 +133,13 @@ def pack_pair(w, shuffle=1):
 
 
 def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=None, mask=None, in_scale=None,
-             in_shift=None, out_scale=None, alpha=1.0, relu=False, gap=None):
+             in_shift=None, out_scale=None, alpha=1.0, relu=False, gap=None, gate_add=None, gate_out=None, dot=None):
     L = hip.lib()
     bf16 = packed.dtype == torch.bfloat16  # the packing decides: a weight packed under one mode runs under it
     fn, name = (L.sisr_conv3x3_c64_bf16, "sisr_conv3x3_c64_bf16") if bf16 else (L.sisr_conv3x3_c64, "sisr_conv3x3_c64")
     rc = fn(hip.ptr(x), xview, _wptr(packed), hip.ptr(bias), bias_nq[0], bias_nq[1], hip.ptr(y), yview, hip.ptr(res),
             hip.ptr(mask), hip.ptr(in_scale), hip.ptr(in_shift), hip.ptr(out_scale), float(alpha), int(relu),
-            hip.ptr(gap), B, H, W, cin, cout, hip.stream())
+            hip.ptr(gap), hip.ptr(gate_add), hip.ptr(gate_out), hip.ptr(dot), B, H, W, cin, cout, hip.stream())
     hip.check(rc, name)
 
 
@@ -460,6 +461,161 @@ class _ResBlock(Function):
             return dx, dw1, db1, dw2, db2, dcaw1, dcab1, dcaw2, dcab2, (dm if has_m else None), None
         finally:
             IN_BACKWARD = False
+
+
+class _GatedGroup(Function):
+    """A whole residual group of channel-attention blocks as ONE autograd node:
+
+        out = x + conv_t(u_n),   u_k = u_{k-1} + g_k * conv2_k(relu(conv1_k(u_{k-1}))),   u_0 = x,
+        g_k = sigmoid(CA_k(mean_hw(conv2_k(..)))) [* m_k]          (ref: advanced/architectures.py:68-71, :107-110;
+                                                                    attention_manipulators/architectures.py:172-180, :229-233)
+
+    Same kernels and arithmetic as the per-block node, but the two passes a block cannot fuse on its own move into
+    its neighbours: the gated skip  u_k = t2_k * g_k + u_{k-1}  is built (and written once) by the NEXT conv's
+    halo staging, and the gate gradient  sum(dU_k * t2_k)  is taken by the PREVIOUS backward conv's epilogue while
+    it produces dU_k.  Per block that removes two HBM-bound launches (3 + 2 map passes with the MFMA units idle)."""
+
+    PER = 9  # w1, b1, w2, b2, caw1, cab1, caw2, cab2, m
+
+    @staticmethod
+    def forward(ctx, x, n, *args):
+        B, C, H, W = x.shape
+        if C != 64:
+            raise NotImplementedError("fused residual group is specialised for n_feats = 64")
+        _join_pending.clear()
+        dev, L = x.device, hip.lib()
+        x = _cl(x)
+        v = hip.view_plain(H, W, 64)
+        need = any(ctx.needs_input_grad)
+        parts = gap_parts(H, W)
+        PER = _GatedGroup.PER
+        cur, pend = x, None
+        tensors, packs, meta = [], [], []
+
+        def pack(w):
+            return pack_pair(w) if need else (pack_weight(w, "fwd"), None)
+
+        for k in range(n):
+            w1, b1, w2, b2, caw1, cab1, caw2, cab2, m = args[k * PER:(k + 1) * PER]
+            w1, w2 = w1.contiguous(), w2.contiguous()
+            p1, pd1 = pack(w1)
+            p2, pd2 = pack(w2)
+            t1 = _empty_cl(B, 64, H, W, dev)
+            if pend is None:
+                conv_c64(cur, v, p1, b1, (1, 64), t1, v, B, H, W, 64, 64, relu=True)
+            else:
+                u = _empty_cl(B, 64, H, W, dev)
+                conv_c64(pend[0], v, p1, b1, (1, 64), t1, v, B, H, W, 64, 64, relu=True, in_scale=pend[1], gate_add=cur,
+                         gate_out=u)
+                cur = u
+            t2 = _empty_cl(B, 64, H, W, dev)
+            gap = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
+            conv_c64(t1, v, p2, b2, (1, 64), t2, v, B, H, W, 64, 64, gap=gap)
+            R = caw1.shape[0]
+            caw1c, caw2c = caw1.reshape(R, 64).contiguous(), caw2.reshape(64, R).contiguous()
+            sv, hid, ca, g = _vec(B, 64, dev), _vec(B, R, dev), _vec(B, 64, dev), _vec(B, 64, dev)
+            mm = m.contiguous() if m is not None else None
+            hip.check(L.sisr_ca_gate_fwd(hip.ptr(gap), parts, B, 1.0 / (H * W), hip.ptr(caw1c), hip.ptr(cab1.contiguous()),
+                                         hip.ptr(caw2c), hip.ptr(cab2.contiguous()), 64, R, hip.ptr(mm), hip.ptr(sv),
+                                         hip.ptr(hid), hip.ptr(ca), hip.ptr(g), hip.stream()), "sisr_ca_gate_fwd")
+            pend = (t2, g)
+            blk = [cur, w1, w2, t1, t2, caw1c, caw2c, sv, hid, ca, g] + ([mm] if mm is not None else [])
+            meta.append((len(blk), mm is not None, tuple(caw1.shape), tuple(caw2.shape)))
+            tensors += blk
+            packs.append((pd1, pd2))
+        wt, bt = args[n * PER:n * PER + 2]
+        wt = wt.contiguous()
+        pt, pdt = pack(wt)
+        un, out = _empty_cl(B, 64, H, W, dev), _empty_cl(B, 64, H, W, dev)
+        conv_c64(pend[0], v, pt, bt, (1, 64), out, v, B, H, W, 64, 64, in_scale=pend[1], gate_add=cur, gate_out=un, res=x)
+        ctx.save_for_backward(*tensors, un, wt)
+        ctx.cfg = (n, (B, H, W), meta, parts)
+        ctx.packs, ctx.pdt = packs, pdt
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        global IN_BACKWARD
+        IN_BACKWARD = True
+        try:
+            n, (B, H, W), meta, parts = ctx.cfg
+            sv_all = list(ctx.saved_tensors)
+            un, wt = sv_all[-2], sv_all[-1]
+            dev, L = un.device, hip.lib()
+            v = hip.view_plain(H, W, 64)
+            hw = H * W
+            dout = _cl(dout)
+            side = (WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False
+                    and not torch.cuda.is_current_stream_capturing())
+
+            def run(fn, keep):
+                if side:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    _on_side(dev, ev, fn, keep)
+                else:
+                    fn()
+
+            blocks, pos = [], 0
+            for cnt, has_m, s1, s2 in meta:
+                blocks.append((sv_all[pos:pos + cnt], has_m, s1, s2))
+                pos += cnt
+            # tail conv: weight gradient from (u_n, dout); dU_n = convT(dout), with sum(dU_n * t2_n) on the side
+            dwt, dbt = torch.empty_like(wt), torch.empty(64, device=dev)
+            run(lambda: wgrad_c64(un, v, dout, v, dwt, dbt, B, H, W, 64, 64), (un, dout, dwt, dbt))
+            dy = _empty_cl(B, 64, H, W, dev)
+            dgp = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
+            conv_c64(dout, v, ctx.pdt, None, (1, 64), dy, v, B, H, W, 64, 64, gap=dgp, dot=blocks[-1][0][4])
+            grads = [None] * (n * _GatedGroup.PER)
+            for k in range(n - 1, -1, -1):
+                tens, has_m, s_caw1, s_caw2 = blocks[k]
+                xk, w1, w2, t1, t2, caw1c, caw2c, s, hid, ca, g = tens[:11]
+                mm = tens[11] if has_m else None
+                pd1, pd2 = ctx.packs[k]
+                R = caw1c.shape[0]
+                shift = _vec(B, 64, dev)
+                dmv = _vec(B, 64, dev) if has_m else None
+                dcaw1, dcab1 = torch.empty(s_caw1, device=dev), torch.empty(R, device=dev)
+                dcaw2, dcab2 = torch.empty(s_caw2, device=dev), torch.empty(64, device=dev)
+                hip.check(L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
+                                             hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
+                                             hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
+                                             hip.ptr(_vec(B, 80, dev)), hip.stream()), "sisr_ca_gate_bwd")
+                dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
+                dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
+                run(lambda t1=t1, dy=dy, dw2=dw2, db2=db2, g=g, shift=shift:
+                    wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, dy_scale=g, dy_shift=shift),
+                    (t1, dy, g, shift, dw2, db2))
+                dt1 = _empty_cl(B, 64, H, W, dev)
+                conv_c64(dy, v, pd2, None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1, in_scale=g, in_shift=shift)
+                run(lambda xk=xk, dt1=dt1, dw1=dw1, db1=db1: wgrad_c64(xk, v, dt1, v, dw1, db1, B, H, W, 64, 64),
+                    (xk, dt1, dw1, db1))
+                dprev = _empty_cl(B, 64, H, W, dev)
+                if k > 0:
+                    dgp = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
+                    conv_c64(dt1, v, pd1, None, (1, 64), dprev, v, B, H, W, 64, 64, res=dy, gap=dgp, dot=blocks[k - 1][0][4])
+                else:
+                    conv_c64(dt1, v, pd1, None, (1, 64), dprev, v, B, H, W, 64, 64, res=dy)
+                dy = dprev
+                grads[k * _GatedGroup.PER:(k + 1) * _GatedGroup.PER] = [dw1, db1, dw2, db2, dcaw1, dcab1, dcaw2, dcab2,
+                                                                       dmv if has_m else None]
+            dx = _affine(dy, None, None, dout, B, H, W, 64) if ctx.needs_input_grad[0] else None
+            return (dx, None, *grads, dwt, dbt)
+        finally:
+            IN_BACKWARD = False
+
+
+def gated_group(x, blocks, tail_w, tail_b):
+    """blocks: list of (w1, b1, w2, b2, (caw1, cab1, caw2, cab2), m or None); see _GatedGroup."""
+    flat = []
+    for w1, b1, w2, b2, ca, m in blocks:
+        flat += [w1, b1, w2, b2, *ca, m]
+    return _GatedGroup.apply(x, len(blocks), *flat, tail_w, tail_b)
+
+
+def fused_groups_enabled():
+    """The neighbour-fused group node needs the GATE / DOT conv variants, which exist for the fp32 kernel."""
+    return FUSED_GROUPS and PRECISION == "fp32"
 
 
 def res_block(x, w1, b1, w2, b2, ca=None, m=None, res_scale=1.0):

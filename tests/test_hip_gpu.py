@@ -89,6 +89,67 @@ def test_conv_tile_heights_are_bit_identical(B, H, W):
     close(outs[(5, 0)][0], want, 2e-5, 2e-6, "4-row tile vs ATen")
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 13, 9), (2, 16, 40), (1, 57, 86), (1, 128, 128), (10, 128, 128)])
+def test_conv_gate_prologue_and_dot_epilogue(B, H, W):
+    """The neighbour-fusion hooks of the 64->64 conv: GATE (input = t*g + skip, also written out) and DOT (GAP
+    slots hold sum(v * dot)), on both tile heights (B = 10 at 128x128 uses the 4-row tile)."""
+    hip = sisr_amd.hip
+    cl = torch.channels_last
+    dev4 = lambda t: t.to(DEV).contiguous(memory_format=cl)  # noqa: E731
+    t, skip, res, dot = (rnd(B, 64, H, W, seed=60 + i) for i in range(4))
+    g = rnd(B, 64, seed=64).abs() + 0.25
+    w, b = rnd(64, 64, 3, 3, seed=65, scale=0.05), rnd(64, seed=66)
+    td, skd, resd, dotd, gd, wd, bd = dev4(t), dev4(skip), dev4(res), dev4(dot), g.to(DEV), w.to(DEV), b.to(DEV)
+    v = hip.view_plain(H, W, 64)
+    pk = ops.pack_weight(wd, "fwd")
+    u = t * g.view(B, 64, 1, 1) + skip
+    # GATE + ReLU (conv1 of the next block) and GATE + residual (group tail)
+    for kw, want in ((dict(relu=True), F.relu(F.conv2d(u, w, b, padding=1))),
+                     (dict(res=resd), F.conv2d(u, w, b, padding=1) + res)):
+        y = torch.full((B, 64, H, W), float("nan"), device=DEV).contiguous(memory_format=cl)
+        uo = torch.full((B, 64, H, W), float("nan"), device=DEV).contiguous(memory_format=cl)
+        ops.conv_c64(td, v, pk, bd, (1, 64), y, v, B, H, W, 64, 64, in_scale=gd, gate_add=skd, gate_out=uo, **kw)
+        close(uo, u, 1e-6, 1e-6, "gate_out")
+        close(y, want, 2e-5, 2e-6, "gated conv")
+    # DOT with and without residual
+    for kw, want in ((dict(), F.conv2d(t, w, None, padding=1)), (dict(res=resd), F.conv2d(t, w, None, padding=1) + res)):
+        y = torch.empty(B, 64, H, W, device=DEV).contiguous(memory_format=cl)
+        gap = torch.full((B, ops.gap_parts(H, W), 64), float("nan"), device=DEV)
+        ops.conv_c64(td, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, gap=gap, dot=dotd, **kw)
+        close(y, want, 2e-5, 2e-6, "dot conv output")
+        close(gap.sum(dim=1), (want * dot).sum(dim=(2, 3)), 2e-4, 2e-5, "dot partials")
+
+
+@pytest.mark.parametrize("meta", [False, True])
+def test_fused_group_node_matches_per_block_nodes(meta):
+    """ops._GatedGroup (one autograd node per residual group, gate passes folded into the neighbouring convs) against
+    the per-block nodes it replaces: same outputs and gradients to fp32 reduction-order tolerance."""
+    torch.manual_seed(8)
+    if meta:
+        net = A.QRCAN(n_resblocks=3, n_resgroups=2, n_feats=64, scale=2, style="standard", num_metadata=10,
+                      include_q_layer=True, num_q_layers_inner_residual=2).to(DEV)
+    else:
+        net = A.RCAN(n_resblocks=3, n_resgroups=2, n_feats=64, scale=2).to(DEV)
+    x = rnd(2, 3, 21, 30, seed=70, scale=0.5).to(DEV)
+    md = rnd(2, 10, 1, 1, seed=71, scale=0.3).to(DEV)
+    cot = None
+    res = {}
+    try:
+        for fused in (True, False):
+            ops.FUSED_GROUPS = fused
+            net.zero_grad(set_to_none=True)
+            out = net(x, md) if meta else net(x)
+            if cot is None:
+                cot = rnd(*out.shape, seed=72).to(DEV)
+            out.backward(cot)
+            res[fused] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    finally:
+        ops.FUSED_GROUPS = True
+    close(res[True][0], res[False][0], 1e-5, 1e-6, "group output")
+    for k in res[True][1]:
+        close(res[True][1][k], res[False][1][k], 2e-4, 2e-5, k)
+
+
 def test_conv_residual_alpha_and_multichunk():
     # 128 -> 192 channels, y = conv*alpha + res  (multi-chunk K loop and multiple output chunks)
     B, H, W = 1, 9, 35
