@@ -73,6 +73,19 @@ def _empty_cl(B, C, H, W, device):
     return torch.empty((B, C, H, W), device=device, dtype=torch.float32, memory_format=CL)
 
 
+# Data-parallel runs register, per conv weight, the slice of the all-reduce bucket its gradient belongs to
+# (parallel.GradReducer): the weight-gradient kernels then write straight into the bucket and the reducer has
+# nothing to copy.  Keyed by the parameter's data pointer; empty in single-process runs.
+GRAD_SINK = {}
+
+
+def _grad_buf(w):
+    sink = GRAD_SINK.get(w.data_ptr())
+    if sink is not None and sink.shape == w.shape:
+        return sink.view(sink.shape)  # a fresh alias: autograd adopts a gradient it holds the only reference to
+    return torch.empty_like(w)
+
+
 def _vec(B, C, device):
     return torch.empty((B, C), device=device, dtype=torch.float32)
 
@@ -237,7 +250,7 @@ class _Conv3x3(Function):
                     conv_c64(dy, dyview, packed, None, (1, 64), dx, hip.view_plain(H, W, cin), B, H, W, cout, cin,
                              alpha=ctx.alpha)
                 if need_w or need_b:
-                    dw = torch.empty_like(w)
+                    dw = _grad_buf(w)
                     db = torch.empty(cout, device=dev, dtype=torch.float32) if ctx.has_bias else None
                     wgrad_c64(x, hip.view_plain(H, W, cin), dy, dyview, dw, db, B, H, W, cin, cout, alpha=ctx.alpha,
                               shuffle=r)
@@ -425,8 +438,8 @@ class _ResBlock(Function):
                               "sisr_sum_partials")
                     scale = g
             # conv2 backward: dt2 = dy*scale + shift is rebuilt on load, never stored
-            dw2, db2 = torch.empty_like(w2), torch.empty(C, device=dev)
-            dw1, db1 = torch.empty_like(w1), torch.empty(C, device=dev)
+            dw2, db2 = _grad_buf(w2), torch.empty(C, device=dev)
+            dw1, db1 = _grad_buf(w1), torch.empty(C, device=dev)
                 # plain first-order backward only; not under hipGraph capture (record_stream + private pools)
             side = (WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False
                     and not torch.cuda.is_current_stream_capturing())
@@ -561,7 +574,7 @@ class _GatedGroup(Function):
                 blocks.append((sv_all[pos:pos + cnt], has_m, s1, s2))
                 pos += cnt
             # tail conv: weight gradient from (u_n, dout); dU_n = convT(dout), with sum(dU_n * t2_n) on the side
-            dwt, dbt = torch.empty_like(wt), torch.empty(64, device=dev)
+            dwt, dbt = _grad_buf(wt), torch.empty(64, device=dev)
             run(lambda: wgrad_c64(un, v, dout, v, dwt, dbt, B, H, W, 64, 64), (un, dout, dwt, dbt))
             dy = _empty_cl(B, 64, H, W, dev)
             dgp = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
@@ -581,8 +594,8 @@ class _GatedGroup(Function):
                                              hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
                                              hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
                                              hip.ptr(_vec(B, 80, dev)), hip.stream()), "sisr_ca_gate_bwd")
-                dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
-                dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
+                dw2, db2 = _grad_buf(w2), torch.empty(64, device=dev)
+                dw1, db1 = _grad_buf(w1), torch.empty(64, device=dev)
                 run(lambda t1=t1, dy=dy, dw2=dw2, db2=db2, g=g, shift=shift:
                     wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, dy_scale=g, dy_shift=shift),
                     (t1, dy, g, shift, dw2, db2))

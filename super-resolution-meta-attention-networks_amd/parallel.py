@@ -91,6 +91,16 @@ class GradReducer:
         for bi, b in enumerate(self.buckets):
             for p in b:
                 self.bucket_of[p] = bi
+        # views of the buckets in parameter shapes; conv weights advertise theirs to the weight-gradient kernels
+        self.views = {}
+        for b, flat in zip(self.buckets, self.flat):
+            for p, piece in zip(b, flat.split([p.numel() for p in b])):
+                self.views[p] = piece.view_as(p)
+        if self.cuda:
+            from . import ops
+            for p, view in self.views.items():
+                if p.dim() == 4 and p.is_contiguous():
+                    ops.GRAD_SINK[p.data_ptr()] = view
         self.pending = [len(b) for b in self.buckets]
         self.works = [None] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
@@ -114,7 +124,10 @@ class GradReducer:
 
     def _launch(self, bi):
         bucket, flat = self.buckets[bi], self.flat[bi]
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
+        # gradients the kernels already wrote into the bucket (ops.GRAD_SINK) need no copy
+        todo = [p for p in bucket if p.grad is None or p.grad.data_ptr() != self.views[p].data_ptr()]
+        dst = [self.views[p] for p in todo]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in todo]
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
             from . import ops
@@ -122,10 +135,12 @@ class GradReducer:
             if wside is not None:
                 self.stream.wait_stream(wside)
             with torch.cuda.stream(self.stream):
-                torch._foreach_copy_(list(flat.split([p.numel() for p in bucket])), [g.reshape(-1) for g in grads])
+                if todo:
+                    torch._foreach_copy_(dst, grads)
                 self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            torch._foreach_copy_(list(flat.split([p.numel() for p in bucket])), [g.reshape(-1) for g in grads])
+            if todo:
+                torch._foreach_copy_(dst, grads)
             self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.launched[bi] = True
 
@@ -141,8 +156,9 @@ class GradReducer:
                 torch.cuda.current_stream().wait_stream(self.stream)
             flat = self.flat[bi]
             flat.mul_(inv)  # one kernel per bucket; the averaged gradients are handed out as views of it
-            for p, piece in zip(bucket, flat.split([p.numel() for p in bucket])):
-                p.grad = piece.view_as(p)
+            for p in bucket:
+                if p.grad is not self.views[p]:
+                    p.grad = self.views[p]
             self.pending[bi] = len(bucket)
             self.launched[bi] = False
             self.works[bi] = None
@@ -151,3 +167,7 @@ class GradReducer:
         for h in self.handles:
             h.remove()
         self.handles = []
+        if self.cuda:
+            from . import ops
+            for p in self.views:
+                ops.GRAD_SINK.pop(p.data_ptr(), None)
