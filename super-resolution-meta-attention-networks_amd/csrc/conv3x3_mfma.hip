@@ -492,7 +492,7 @@ __device__ __forceinline__ u32x4 sisr_pack_bf16x8(f32x4 a, f32x4 b) {
 #define BH_PIX 128  // bytes per halo pixel
 #define BE_LD 68    // floats per pixel row of the epilogue transpose buffer (64 + 4: rows 272 B apart)
 
-template <bool AFFINE, bool MASK, bool RES>
+template <bool AFFINE, bool MASK, bool RES, bool GATE = false, bool DOT = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -557,37 +557,80 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) 
         goff[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c8 * 8);
         loff[k] = col * BH_PIX + ((c8 ^ ((col >> 1) & 7)) << 4);
       }
+      if (!GATE) {
 #pragma unroll
-      for (int r0 = 0; r0 < HALO_H; r0 += 3) {
-        f32x4 v[3][2][2];
+        for (int r0 = 0; r0 < HALO_H; r0 += 3) {
+          f32x4 v[3][2][2];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const int gh = h0 - 1 + r0 + r;
-          const float* xrow = xb + (long)min(max(gh, 0), H - 1) * p.xv.sH;  // scalar
+          for (int r = 0; r < 3; ++r) {
+            const int gh = h0 - 1 + r0 + r;
+            const float* xrow = xb + (long)min(max(gh, 0), H - 1) * p.xv.sH;  // scalar
 #pragma unroll
-          for (int k = 0; k < 2; ++k)
-            if (k == 0 || pcol < 2) {
-              v[r][k][0] = *reinterpret_cast<const f32x4*>(xrow + goff[k]);
-              v[r][k][1] = *reinterpret_cast<const f32x4*>(xrow + goff[k] + 4);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const int gh = h0 - 1 + r0 + r;
-          const bool rok = gh >= 0 && gh < H;  // scalar
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-            if (k == 0 || pcol < 2) {
-              f32x4 ta = v[r][k][0], tb = v[r][k][1];
-              if (AFFINE) {
-                ta = ta * s4a + t4a;
-                tb = tb * s4b + t4b;
+            for (int k = 0; k < 2; ++k)
+              if (k == 0 || pcol < 2) {
+                v[r][k][0] = *reinterpret_cast<const f32x4*>(xrow + goff[k]);
+                v[r][k][1] = *reinterpret_cast<const f32x4*>(xrow + goff[k] + 4);
               }
-              u32x4 pk = sisr_pack_bf16x8(ta, tb);
-              const unsigned m = (rok && cok[k]) ? 0xffffffffu : 0u;
-              pk &= (u32x4){m, m, m, m};
-              *reinterpret_cast<u32x4*>(ldsb + (r0 + r) * (HALO_W * BH_PIX) + loff[k]) = pk;
-            }
+          }
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int gh = h0 - 1 + r0 + r;
+            const bool rok = gh >= 0 && gh < H;  // scalar
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              if (k == 0 || pcol < 2) {
+                f32x4 ta = v[r][k][0], tb = v[r][k][1];
+                if (AFFINE) {
+                  ta = ta * s4a + t4a;
+                  tb = tb * s4b + t4b;
+                }
+                u32x4 pk = sisr_pack_bf16x8(ta, tb);
+                const unsigned m = (rok && cok[k]) ? 0xffffffffu : 0u;
+                pk &= (u32x4){m, m, m, m};
+                *reinterpret_cast<u32x4*>(ldsb + (r0 + r) * (HALO_W * BH_PIX) + loff[k]) = pk;
+              }
+          }
+        }
+      } else {  // GATE: u = t * gate + skip in fp32, written out once by the owning tile, then rounded for the MFMA
+        const float* gp = p.in_scale + (long)b * 64 + c8 * 8;
+        const f32x4 g4a = *reinterpret_cast<const f32x4*>(gp), g4b = *reinterpret_cast<const f32x4*>(gp + 4);
+        const long boffs = (long)b * p.xv.sB;
+#pragma unroll
+        for (int r0 = 0; r0 < HALO_H; r0 += 2) {
+          f32x4 v[2][2][2], u[2][2][2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const long ro = boffs + (long)min(max(h0 - 1 + r0 + r, 0), H - 1) * p.xv.sH;  // scalar
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              if (k == 0 || pcol < 2) {
+                v[r][k][0] = *reinterpret_cast<const f32x4*>(p.x + ro + goff[k]);
+                v[r][k][1] = *reinterpret_cast<const f32x4*>(p.x + ro + goff[k] + 4);
+                u[r][k][0] = *reinterpret_cast<const f32x4*>(p.gate_add + ro + goff[k]);
+                u[r][k][1] = *reinterpret_cast<const f32x4*>(p.gate_add + ro + goff[k] + 4);
+              }
+          }
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int hr = r0 + r, gh = h0 - 1 + hr;
+            const bool rok = gh >= 0 && gh < H;              // scalar
+            const bool rown = hr >= 1 && hr <= TH && gh < H;  // scalar
+            const long ro = boffs + (long)min(max(gh, 0), H - 1) * p.xv.sH;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              if (k == 0 || pcol < 2) {
+                const f32x4 ta = v[r][k][0] * g4a + u[r][k][0], tb = v[r][k][1] * g4b + u[r][k][1];
+                const int col = pcol + 32 * k;
+                if (rown && cok[k] && col >= 1 && col <= TW) {
+                  *reinterpret_cast<f32x4*>(p.gate_out + ro + goff[k]) = ta;
+                  *reinterpret_cast<f32x4*>(p.gate_out + ro + goff[k] + 4) = tb;
+                }
+                u32x4 pk = sisr_pack_bf16x8(ta, tb);
+                const unsigned m = (rok && cok[k]) ? 0xffffffffu : 0u;
+                pk &= (u32x4){m, m, m, m};
+                *reinterpret_cast<u32x4*>(ldsb + hr * (HALO_W * BH_PIX) + loff[k]) = pk;
+              }
+          }
         }
       }
     }
@@ -637,7 +680,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) 
     }
     grow[m] = gsum + __shfl_xor(gsum, 32);
   }
-  if (p.gap) {  // only offered without mask / residual (host checks): v above is the final value
+  if (!DOT && p.gap) {  // only offered without mask / residual (host checks): v above is the final value
     if (hh == 0) {
       const int tile = th * p.tiles_w + tw;
       const long parts = (long)p.tiles_w * p.tiles_h * 2;
@@ -648,7 +691,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) 
   {
     const int c4 = tid & 15, pr = tid >> 4;  // pixel pr + 16 i  ->  tile row i >> 1, column pr + 16 (i & 1)
     const long tile_base = (long)b * p.yv.sB + p.yv.chunk(q) + (long)w0 * p.yv.sW + c4 * 4;
-    f32x4 rv[8], mv[8];
+    f32x4 rv[8], mv[8], dv[8];
     bool ok[8];
     long off[8];
 #pragma unroll
@@ -658,7 +701,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) 
       off[i] = tile_base + (long)min(row, H - 1) * p.yv.sH + (long)min(col, W - 1 - w0) * p.yv.sW;
       if (RES) rv[i] = *reinterpret_cast<const f32x4*>(p.res + off[i]);
       if (MASK) mv[i] = *reinterpret_cast<const f32x4*>(p.mask + off[i]);
+      if (DOT) dv[i] = *reinterpret_cast<const f32x4*>(p.dot + off[i]);
     }
+    f32x4 dsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // DOT: per 2-row strip (i < 4 / i >= 4)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       f32x4 v = *reinterpret_cast<const f32x4*>(ot + (pr + 16 * i) * BE_LD + c4 * 4);
@@ -669,7 +714,26 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) 
         v[3] = mv[i][3] > 0.f ? v[3] : 0.f;
       }
       if (RES) v += rv[i];
-      if (ok[i]) *reinterpret_cast<f32x4*>(p.y + off[i]) = v;
+      if (ok[i]) {
+        *reinterpret_cast<f32x4*>(p.y + off[i]) = v;
+        if (DOT) dsum[i >> 2] += v * dv[i];
+      }
+    }
+    if (DOT) {  // sum(v * dot) per strip and channel: the 16 pixel-column threads of a channel quad, in order
+      __syncthreads();  // everyone is done with the transpose buffer
+      float* red = ot;  // [2 strips][16][64]
+      *reinterpret_cast<f32x4*>(red + (0 * 16 + pr) * 64 + c4 * 4) = dsum[0];
+      *reinterpret_cast<f32x4*>(red + (1 * 16 + pr) * 64 + c4 * 4) = dsum[1];
+      __syncthreads();
+      if (tid < 128) {
+        const int strip = tid >> 6, chn = tid & 63;
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sacc += red[(strip * 16 + j) * 64 + chn];
+        const int tile = th * p.tiles_w + tw;
+        const long parts = (long)p.tiles_w * p.tiles_h * 2;
+        p.gap[(((long)b * parts) + tile * 2 + strip) * Cout + q * 64 + chn] = sacc;
+      }
     }
   }
 }
@@ -952,7 +1016,13 @@ extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const
                                      const float* gate_add, float* gate_out, const float* dot, int B, int H, int W,
                                      int cin, int cout, void* stream) {
   if (!x || !wpacked_bf16 || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
-  if (gate_add || gate_out || dot) return SISR_ERR_UNSUPPORTED;  // the fused chain is built on the fp32 kernel only
+  const bool gate = gate_add != nullptr;
+  if (gate_add || gate_out || dot) {  // fused gated-residual chain, same contract as the fp32 entry
+    if (gate != (gate_out != nullptr) || (gate && !in_scale) || (gate && dot) || (dot && !gap_partial) ||
+        (!gate && in_scale) || in_shift || mask || out_scale || cin != 64 || cout != 64 || !sisr_aligned16(gate_add) ||
+        !sisr_aligned16(gate_out) || memcmp(xview, yview, 6 * sizeof(int64_t)) != 0)
+      return SISR_ERR_UNSUPPORTED;
+  }
   if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
   if (in_shift && !in_scale) return SISR_ERR_UNSUPPORTED;
   if (!sisr_aligned16(x) || !sisr_aligned16(wpacked_bf16) || !sisr_aligned16(in_scale) || !sisr_aligned16(in_shift))
@@ -971,9 +1041,9 @@ extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const
   p.in_shift = in_shift;
   p.out_scale = out_scale;
   p.gap = gap_partial;
-  p.gate_add = nullptr;
-  p.gate_out = nullptr;
-  p.dot = nullptr;
+  p.gate_add = gate_add;
+  p.gate_out = gate_out;
+  p.dot = dot;
   p.alpha = alpha;
   p.bias_n = bias_n;
   p.bias_q = bias_q;
@@ -988,10 +1058,17 @@ extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const
   const long nblk = (long)p.tiles_w * p.tiles_h * B;
   if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
   const dim3 grid((unsigned)nblk, p.cout_chunks);
-  if (gap_partial && (mask || res)) return SISR_ERR_UNSUPPORTED;
+  if (gap_partial && !dot && (mask || res)) return SISR_ERR_UNSUPPORTED;
   const size_t lb_halo = HALO_H * HALO_W * BH_PIX, lb_out = TH * TW * BE_LD * sizeof(float);
   const size_t lb = lb_halo > lb_out ? lb_halo : lb_out;
   hipStream_t st = (hipStream_t)stream;
+  if (gate || dot) {
+#define BFX(RS, GT, DT) hipLaunchKernelGGL((conv3x3_c64_bf16_kernel<false, false, RS, GT, DT>), grid, dim3(256), lb, st, p)
+    if (gate) { if (res) BFX(true, true, false); else BFX(false, true, false); }
+    else      { if (res) BFX(true, false, true); else BFX(false, false, true); }
+#undef BFX
+    return sisr_check_launch();
+  }
   const int sel = (in_scale ? 4 : 0) | (mask ? 2 : 0) | (res ? 1 : 0);
   switch (sel) {
 #define BF_CASE(i, a, m, r) \

@@ -627,8 +627,8 @@ def gated_group(x, blocks, tail_w, tail_b):
 
 
 def fused_groups_enabled():
-    """The neighbour-fused group node needs the GATE / DOT conv variants, which exist for the fp32 kernel."""
-    return FUSED_GROUPS and PRECISION == "fp32"
+    """Group-level node (GATE / DOT conv variants) on or off; SISR_FUSED_GROUPS=0 keeps the per-block nodes."""
+    return FUSED_GROUPS
 
 
 def res_block(x, w1, b1, w2, b2, ca=None, m=None, res_scale=1.0):

@@ -116,6 +116,34 @@ def test_conv_options_bf16():
     close(run(out_scale=oscd), base(x) * osc.view(B, 64, 1, 1), 2e-5, 2e-6, "out scale")
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 13, 9), (2, 16, 40), (1, 57, 86), (1, 128, 128)])
+def test_conv_gate_and_dot_hooks_bf16(B, H, W):
+    """GATE prologue (input = t*g + skip built in fp32, written out, then rounded) and DOT epilogue of the bf16 conv."""
+    cl = torch.channels_last
+    dev4 = lambda t: t.to(DEV).contiguous(memory_format=cl)  # noqa: E731
+    t, skip, res, dot = (rnd(B, 64, H, W, seed=60 + i) for i in range(4))
+    g = rnd(B, 64, seed=64).abs() + 0.25
+    w, b = rnd(64, 64, 3, 3, seed=65, scale=0.05), rnd(64, seed=66)
+    td, skd, resd, dotd, gd, wd, bd = dev4(t), dev4(skip), dev4(res), dev4(dot), g.to(DEV), w.to(DEV), b.to(DEV)
+    v = hip.view_plain(H, W, 64)
+    pk = ops.pack_weight(wd, "fwd")
+    u = t * g.view(B, 64, 1, 1) + skip
+    conv16 = lambda xin, bias: F.conv2d(r16(xin), r16(w), bias, padding=1)  # noqa: E731
+    for kw, want in ((dict(relu=True), F.relu(conv16(u, b))), (dict(res=resd), conv16(u, b) + res)):
+        y = torch.full((B, 64, H, W), float("nan"), device=DEV).contiguous(memory_format=cl)
+        uo = torch.full((B, 64, H, W), float("nan"), device=DEV).contiguous(memory_format=cl)
+        ops.conv_c64(td, v, pk, bd, (1, 64), y, v, B, H, W, 64, 64, in_scale=gd, gate_add=skd, gate_out=uo, **kw)
+        close(uo, u, 1e-6, 1e-6, "gate_out")
+        # u itself may differ by an fp32 ulp (fused multiply-add), which can flip a bf16 rounding: compare via rms
+        assert rms(y.cpu() - want) < 2e-4 * rms(want), kw
+    for kw, want in ((dict(), conv16(t, None)), (dict(res=resd), conv16(t, None) + res)):
+        y = torch.empty(B, 64, H, W, device=DEV).contiguous(memory_format=cl)
+        gap = torch.full((B, ops.gap_parts(H, W), 64), float("nan"), device=DEV)
+        ops.conv_c64(td, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, gap=gap, dot=dotd, **kw)
+        close(y, want, 2e-5, 2e-6, "dot conv output")
+        close(gap.sum(dim=1), (want * dot).sum(dim=(2, 3)), 2e-4, 2e-5, "dot partials")
+
+
 @pytest.mark.parametrize("kind", ["rcab", "resblock", "paramresblock"])
 def test_fused_block_bf16_vs_oracle_restatement(kind):
     """Two chained convs per direction: still comparable element-wise (one rounding layer of amplification)."""
