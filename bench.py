@@ -33,6 +33,8 @@ import torch.distributed as dist  # noqa: E402
 CONV_BODY_FLOP_PER_PIXEL = 2 * 64 * 64 * 9
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
 HBM_PEAK_GBS = 8000.0          # same guide: HBM3E ~8 TB/s
+# algorithmic HBM bytes per LR patch, fwd + bwd, fp32 maps, layer at a time with the legal fusions
+HBM_GB_PER_PATCH = {"rcan": 16.5, "qrcan": 16.5, "edsr": 1.4, "qedsr": 1.4}
 WORKLOADS = {
     # name: (registry name, handler kwargs, fwd+bwd algorithmic TFLOP per LR patch)
     "rcan": ("rcan", {}, 1.565),
@@ -231,6 +233,16 @@ def main():
                                 "frac": ks["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                 "avg_launch_us": ks["avg_us"], "launches_timed": ks["launches"],
                                 "flop_per_launch": ks["flop_per_launch"]}
+        if "roofline" in line and args.workload in HBM_GB_PER_PATCH:
+            # the other roof, for reference (SURVEY.md §8d asks for both): whole-step algorithmic HBM rate
+            gbs = value / world * HBM_GB_PER_PATCH[args.workload]
+            line["roofline"]["secondary"] = {"bound": "mfma" if args.precision == "bf16" else "hbm",
+                                             "what": "whole step, algorithmic bytes per patch x patches/s per GPU",
+                                             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": gbs / HBM_PEAK_GBS} if args.precision == "fp32" else {
+                "bound": "mfma", "what": "whole step, algorithmic TFLOP/s per GPU against the dense bf16 MFMA peak",
+                "achieved": value / world * tflop_per_patch, "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": value / world * tflop_per_patch / 2500.0}
         if world == 1 and not args.no_cpu_baseline and args.precision == "fp32":
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)
