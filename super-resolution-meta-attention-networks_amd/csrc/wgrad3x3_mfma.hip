@@ -253,7 +253,18 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_bf16_kernel(WgradParams p
 
   const int tiles_per_img = p.tiles_w * p.tiles_h;
   const int total = tiles_per_img * p.B;
-  for (int tile = blockIdx.x; tile < total; tile += p.S) {
+  // Tile walk.  Workgroup s lands on XCD s % 8; give every XCD a contiguous eighth of the tiles and let its S / 8
+  // workgroups sweep it together, so that vertically adjacent tiles (whose 10-row halos share two rows) are read
+  // through the same L2 at about the same time.  (HBM-bound kernel: measured 316 MB read per launch with the
+  // strided walk against 268 MB algorithmic.)  Falls back to the strided walk when S is not a multiple of 8.
+  int t_begin = blockIdx.x, t_end = total, t_step = p.S;
+  if ((p.S & 7) == 0) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = (total + 7) >> 3;
+    t_begin = xcd * per + idx;
+    t_end = min(total, (xcd + 1) * per);
+    t_step = p.S >> 3;
+  }
+  for (int tile = t_begin; tile < t_end; tile += t_step) {
     const int b = tile / tiles_per_img;
     const int tr = tile - b * tiles_per_img;
     const int th = tr / p.tiles_w, tw = tr - th * p.tiles_w;
