@@ -156,6 +156,7 @@ int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const void* wpac
                           const float* in_scale, const float* in_shift, const float* out_scale, float alpha, int relu,
                           float* gap_partial, const float* gate_add, float* gate_out, const float* dot,
                           int B, int H, int W, int cin, int cout, void* stream);
+int sisr_conv3x3_c64_bf16_set_persistent(int on); /* A/B switch: persistent double-buffered tile loop (default 1) */
 size_t sisr_wgrad3x3_c64_bf16_workspace_bytes(int B, int H, int W, int cin, int cout);
 int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
                            const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so, int64_t si,

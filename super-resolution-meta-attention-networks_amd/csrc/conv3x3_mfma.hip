@@ -738,6 +738,258 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) 
   }
 }
 
+// ------------------------------------------------------------------ persistent bf16 kernel (64 -> 64)
+// PMC showed the kernel above to be bound by memory-level parallelism: a workgroup has its halo loads in flight
+// for ~15 % of its life, so a CU keeps ~22 KB outstanding -- enough for ~3 TB/s.  Here a workgroup walks tiles
+// g, g + G, ... and loads tile i+1 (96 VGPRs of prefetch per thread) while tile i is in its K loop: two workgroups
+// per CU keep ~100 KB in flight nearly all the time.  LDS: two buffers of 34.8 KB, each first the bf16 halo of a
+// tile (26 KB) and then, once its K loop is done, that tile's fp32 transpose buffer for the float4 epilogue.
+// Arithmetic, fragment order and results are those of conv3x3_c64_bf16_kernel.
+#define PB_BUF (TH * TW * BE_LD * 4)
+
+template <bool AFFINE, bool MASK, bool RES, bool GATE, bool DOT>
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvParams p, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = gridDim.x;
+  int g;
+  {
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const unsigned qn = nb >> 3, rn = nb & 7;
+    g = (int)((xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx);
+  }
+  const int ph = __builtin_amdgcn_readfirstlane(wave >> 1), ch = __builtin_amdgcn_readfirstlane(wave & 1);
+  const int n = lane & 31, hh = lane >> 5;
+  const int H = p.H, W = p.W;
+  const int co = ch * 32 + n;
+  const float bv = p.bias ? p.bias[co * p.bias_n] : 0.f;
+  unsigned aoff[3][4];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+      aoff[kw][kb] = ((2 * ph) * HALO_W + n + kw) * BH_PIX + (((2 * kb + hh) ^ (((n + kw) >> 1) & 7)) << 4);
+  const unsigned boff = (hh * 64 + co) * 16;
+  const unsigned char* wq0 = reinterpret_cast<const unsigned char*>(p.w);
+  const int c8 = tid & 7, pcol = tid >> 3;
+  const int tiles_per_img = p.tiles_w * p.tiles_h;
+
+  // ---- halo staging, split into "issue the loads" and "convert + write LDS".  Thread (c8, pcol) owns channels
+  // 8 c8 .. +7 of halo column pcol + 1 in all six rows; the two edge columns (0 and 33: 6 rows x 2 x 8 chunks = 96
+  // items) go one per thread to tid % 96 (threads 96.. load a duplicate and do not write), so every load is
+  // unconditional and a thread holds 14 float4 pairs per tile.
+  struct Halo {
+    f32x4 in[HALO_H][2];
+    f32x4 ed[2];
+  };
+  Halo v;
+  const int eidx = tid % 96, er = eidx >> 4, eside = (eidx >> 3) & 1, ec8 = eidx & 7;
+  auto decode = [&](int tile, int& b, int& h0, int& w0) {
+    b = tile / tiles_per_img;
+    const int r = tile - b * tiles_per_img;
+    const int th = r / p.tiles_w;
+    h0 = th * TH;
+    w0 = (r - th * p.tiles_w) * TW;
+  };
+  auto issue = [&](const float* src, int tile, Halo& dst) {
+    int b, h0, w0;
+    decode(tile, b, h0, w0);
+    const float* xb = src + (long)b * p.xv.sB;
+    const int gwi = min(w0 + pcol, W - 1);
+#pragma unroll
+    for (int r = 0; r < HALO_H; ++r) {
+      const float* a = xb + (long)min(max(h0 - 1 + r, 0), H - 1) * p.xv.sH + gwi * (int)p.xv.sW + c8 * 8;
+      dst.in[r][0] = *reinterpret_cast<const f32x4*>(a);
+      dst.in[r][1] = *reinterpret_cast<const f32x4*>(a + 4);
+    }
+    const int gwe = min(max(eside ? w0 + TW : w0 - 1, 0), W - 1);
+    const float* e = xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8;
+    dst.ed[0] = *reinterpret_cast<const f32x4*>(e);
+    dst.ed[1] = *reinterpret_cast<const f32x4*>(e + 4);
+  };
+  auto commit = [&](unsigned char* buf, int tile) {
+    int b, h0, w0;
+    decode(tile, b, h0, w0);
+    f32x4 s4a = {1.f, 1.f, 1.f, 1.f}, s4b = s4a, t4a = {0.f, 0.f, 0.f, 0.f}, t4b = t4a, e4a = s4a, e4b = s4a,
+          f4a = t4a, f4b = t4a;
+    if (AFFINE || GATE) {
+      const float* sp = p.in_scale + (long)b * 64;
+      s4a = *reinterpret_cast<const f32x4*>(sp + c8 * 8);
+      s4b = *reinterpret_cast<const f32x4*>(sp + c8 * 8 + 4);
+      e4a = *reinterpret_cast<const f32x4*>(sp + ec8 * 8);
+      e4b = *reinterpret_cast<const f32x4*>(sp + ec8 * 8 + 4);
+      if (AFFINE && p.in_shift) {
+        const float* tp = p.in_shift + (long)b * 64;
+        t4a = *reinterpret_cast<const f32x4*>(tp + c8 * 8);
+        t4b = *reinterpret_cast<const f32x4*>(tp + c8 * 8 + 4);
+        f4a = *reinterpret_cast<const f32x4*>(tp + ec8 * 8);
+        f4b = *reinterpret_cast<const f32x4*>(tp + ec8 * 8 + 4);
+      }
+    }
+    Halo u;
+    if (GATE) issue(p.gate_add, tile, u);
+    const int col = pcol + 1, gw = w0 + pcol;
+    const bool cok = gw < W;
+    const unsigned lo_in = col * BH_PIX + ((c8 ^ ((col >> 1) & 7)) << 4);
+#pragma unroll
+    for (int r = 0; r < HALO_H; ++r) {
+      const int gh = h0 - 1 + r;
+      const bool rok = gh >= 0 && gh < H;
+      f32x4 ta = v.in[r][0], tb = v.in[r][1];
+      if (AFFINE) {
+        ta = ta * s4a + t4a;
+        tb = tb * s4b + t4b;
+      }
+      if (GATE) {
+        ta = ta * s4a + u.in[r][0];
+        tb = tb * s4b + u.in[r][1];
+        if (r >= 1 && r <= TH && gh < H && cok) {  // interior columns are exactly the pixels this tile owns
+          float* o = p.gate_out + (long)b * p.xv.sB + (long)gh * p.xv.sH + (long)gw * p.xv.sW + c8 * 8;
+          *reinterpret_cast<f32x4*>(o) = ta;
+          *reinterpret_cast<f32x4*>(o + 4) = tb;
+        }
+      }
+      u32x4 pk = sisr_pack_bf16x8(ta, tb);
+      const unsigned m = (rok && cok) ? 0xffffffffu : 0u;
+      pk &= (u32x4){m, m, m, m};
+      *reinterpret_cast<u32x4*>(buf + r * (HALO_W * BH_PIX) + lo_in) = pk;
+    }
+    {
+      const int ecol = eside ? HALO_W - 1 : 0, gwe = eside ? w0 + TW : w0 - 1, ghe = h0 - 1 + er;
+      f32x4 ta = v.ed[0], tb = v.ed[1];
+      if (AFFINE) {
+        ta = ta * e4a + f4a;
+        tb = tb * e4b + f4b;
+      }
+      if (GATE) {
+        ta = ta * e4a + u.ed[0];
+        tb = tb * e4b + u.ed[1];
+      }
+      u32x4 pk = sisr_pack_bf16x8(ta, tb);
+      const unsigned m = (ghe >= 0 && ghe < H && gwe >= 0 && gwe < W) ? 0xffffffffu : 0u;
+      pk &= (u32x4){m, m, m, m};
+      if (tid < 96)
+        *reinterpret_cast<u32x4*>(buf + er * (HALO_W * BH_PIX) + ecol * BH_PIX + ((ec8 ^ ((ecol >> 1) & 7)) << 4)) = pk;
+    }
+  };
+
+  int tile = g;
+  if (tile >= total_tiles) return;
+  issue(p.x, tile, v);
+  commit(ldsb, tile);
+  __syncthreads();
+  for (int it = 0;; ++it) {
+    unsigned char* cur = ldsb + (it & 1) * PB_BUF;
+    unsigned char* nxt = ldsb + ((it + 1) & 1) * PB_BUF;
+    const int next = tile + G;
+    const bool has_next = next < total_tiles;  // uniform
+    if (has_next) issue(p.x, next, v);         // in flight across the K loop and the epilogue of this tile
+    int b, h0, w0;
+    decode(tile, b, h0, w0);
+
+    // ---- K loop (36 steps x 2 MFMAs), B fragments eight steps ahead
+    const unsigned char* wq = wq0;
+    asm volatile("" : "+s"(wq));  // per-iteration copy: keeps 36 loop-invariant 64-bit B addresses from being hoisted
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = bv;
+#define PB_LOAD_B(s) (*reinterpret_cast<const bf16x8*>(wq + (s) * 2048 + boff))
+#define PB_LOAD_A(m, s) \
+  (*reinterpret_cast<const bf16x8*>(cur + ((((s) >> 2) / 3 + (m)) * (HALO_W * BH_PIX)) + aoff[((s) >> 2) % 3][(s) & 3]))
+    {
+      bf16x8 bq[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) bq[s] = PB_LOAD_B(s);
+#pragma unroll
+      for (int s = 0; s < 36; ++s) {
+        const bf16x8 bb = bq[s & 7];
+        if (s + 8 < 36) bq[s & 7] = PB_LOAD_B(s + 8);
+        const bf16x8 a0 = PB_LOAD_A(0, s);
+        const bf16x8 a1 = PB_LOAD_A(1, s);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the fragment loads next to their step: 96 prefetch VGPRs are live
+      }
+    }
+#undef PB_LOAD_A
+#undef PB_LOAD_B
+
+    // ---- epilogue through `cur` (its halo is dead once every wave has left the K loop)
+    float os = p.alpha;
+    if (p.out_scale) os *= p.out_scale[(long)b * 64 + co];
+    const float lo = p.relu ? 0.f : -3.402823466e38f;
+    float* ot = reinterpret_cast<float*>(cur);
+    const int c4 = tid & 15, pr = tid >> 4;
+    const long tile_base = (long)b * p.yv.sB + (long)w0 * p.yv.sW + c4 * 4;
+    __syncthreads();
+    float grow[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float gsum = 0.f;
+      const f32x16 acc = m ? acc1 : acc0;
+      const int prow = (2 * ph + m) * TW;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pc = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float val = fmaxf(acc[r], lo) * os;
+        ot[(prow + pc) * BE_LD + co] = val;
+        if (h0 + 2 * ph + m < H && w0 + pc < W) gsum += val;
+      }
+      grow[m] = gsum + __shfl_xor(gsum, 32);
+    }
+    const int tile_in_img = tile - b * tiles_per_img;
+    const long parts = (long)tiles_per_img * 2;
+    if (!DOT && p.gap && hh == 0) p.gap[(((long)b * parts) + tile_in_img * 2 + ph) * 64 + co] = grow[0] + grow[1];
+    f32x4 rv[8], mv[8], dv[8];
+    bool ok[8];
+    long off[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // epilogue operands (the accumulators are dead by now)
+      const int row = h0 + (i >> 1), col = pr + 16 * (i & 1);
+      ok[i] = row < H && w0 + col < W;
+      off[i] = tile_base + (long)min(row, H - 1) * p.yv.sH + (long)min(col, W - 1 - w0) * p.yv.sW;
+      if (RES) rv[i] = *reinterpret_cast<const f32x4*>(p.res + off[i]);
+      if (MASK) mv[i] = *reinterpret_cast<const f32x4*>(p.mask + off[i]);
+      if (DOT) dv[i] = *reinterpret_cast<const f32x4*>(p.dot + off[i]);
+    }
+    __syncthreads();
+    f32x4 dsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f32x4 val = *reinterpret_cast<const f32x4*>(ot + (pr + 16 * i) * BE_LD + c4 * 4);
+      if (MASK) {
+        val[0] = mv[i][0] > 0.f ? val[0] : 0.f;
+        val[1] = mv[i][1] > 0.f ? val[1] : 0.f;
+        val[2] = mv[i][2] > 0.f ? val[2] : 0.f;
+        val[3] = mv[i][3] > 0.f ? val[3] : 0.f;
+      }
+      if (RES) val += rv[i];
+      if (ok[i]) {
+        *reinterpret_cast<f32x4*>(p.y + off[i]) = val;
+        if (DOT) dsum[i >> 2] += val * dv[i];
+      }
+    }
+    if (DOT) {
+      __syncthreads();
+      float* red = ot;
+      *reinterpret_cast<f32x4*>(red + (0 * 16 + pr) * 64 + c4 * 4) = dsum[0];
+      *reinterpret_cast<f32x4*>(red + (1 * 16 + pr) * 64 + c4 * 4) = dsum[1];
+      __syncthreads();
+      if (tid < 128) {
+        const int strip = tid >> 6, chn = tid & 63;
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sacc += red[(strip * 16 + j) * 64 + chn];
+        p.gap[(((long)b * parts) + tile_in_img * 2 + strip) * 64 + chn] = sacc;
+      }
+    }
+    if (!has_next) break;
+    commit(nxt, next);  // the prefetched halo of the next tile (nxt's previous reader finished one iteration ago)
+    __syncthreads();
+    tile = next;
+  }
+}
+
 // bf16 packings of one OIHW weight (forward and input-gradient orders) in one launch:
 // packed[q][c][s][h][n][j] = bf16(w[o][i][t]),  t = s >> 2,  i_local = 16*(s & 3) + 8h + j,  o_local = n.
 __global__ void pack_conv3x3_bf16_both_kernel(const float* __restrict__ w, __bf16* __restrict__ pf,
@@ -997,6 +1249,14 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   return sisr_check_launch();
 }
 
+// Process-wide A/B switch for the bf16 conv: 1 = persistent double-buffered kernel where it applies (default),
+// 0 = one workgroup per tile everywhere.
+static int g_bf16_persist = 1;
+extern "C" int sisr_conv3x3_c64_bf16_set_persistent(int on) {
+  g_bf16_persist = on ? 1 : 0;
+  return SISR_OK;
+}
+
 extern "C" int sisr_pack_conv3x3_bf16_both(const float* w, void* packed_fwd, void* packed_dgrad, int cout, int cin,
                                            int shuffle_r, void* stream) {
   if (!w || !packed_fwd || !packed_dgrad || cout <= 0 || cin <= 0 || shuffle_r < 1) return SISR_ERR_ARG;
@@ -1062,6 +1322,35 @@ extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const
   const size_t lb_halo = HALO_H * HALO_W * BH_PIX, lb_out = TH * TW * BE_LD * sizeof(float);
   const size_t lb = lb_halo > lb_out ? lb_halo : lb_out;
   hipStream_t st = (hipStream_t)stream;
+  if (g_bf16_persist && cin == 64 && cout == 64 && nblk >= 1024) {
+    // 64 -> 64 with enough tiles to give every persistent workgroup at least two: the double-buffered tile loop
+    const int G = 512;  // two workgroups per CU
+    const size_t plb = 2 * (size_t)PB_BUF;
+    const dim3 pg(G);
+    const int total = (int)nblk;
+#define PBX(AF, MK, RS, GT, DT)                                                                              \
+  do {                                                                                                       \
+    SISR_ALLOW_LDS((conv3x3_c64_bf16_persist_kernel<AF, MK, RS, GT, DT>), plb);                              \
+    hipLaunchKernelGGL((conv3x3_c64_bf16_persist_kernel<AF, MK, RS, GT, DT>), pg, dim3(256), plb, st, p, total); \
+  } while (0)
+    if (gate) { if (res) PBX(false, false, true, true, false); else PBX(false, false, false, true, false); }
+    else if (dot) { if (res) PBX(false, false, true, false, true); else PBX(false, false, false, false, true); }
+    else {
+      const int sel = (in_scale ? 4 : 0) | (mask ? 2 : 0) | (res ? 1 : 0);
+      switch (sel) {
+        case 0: PBX(false, false, false, false, false); break;
+        case 1: PBX(false, false, true, false, false); break;
+        case 2: PBX(false, true, false, false, false); break;
+        case 3: PBX(false, true, true, false, false); break;
+        case 4: PBX(true, false, false, false, false); break;
+        case 5: PBX(true, false, true, false, false); break;
+        case 6: PBX(true, true, false, false, false); break;
+        case 7: PBX(true, true, true, false, false); break;
+      }
+    }
+#undef PBX
+    return sisr_check_launch();
+  }
   if (gate || dot) {
 #define BFX(RS, GT, DT) hipLaunchKernelGGL((conv3x3_c64_bf16_kernel<false, false, RS, GT, DT>), grid, dim3(256), lb, st, p)
     if (gate) { if (res) BFX(true, true, false); else BFX(false, true, false); }

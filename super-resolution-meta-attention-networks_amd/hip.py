@@ -59,6 +59,7 @@ _SIGS.update({
 })
 _SIGS.update({  # bf16 matrix-core variants (csrc/conv3x3_mfma.hip, csrc/wgrad3x3_mfma.hip)
     "sisr_pack_conv3x3_bf16_both": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "sisr_conv3x3_c64_bf16_set_persistent": (c_int, [c_int]),
     "sisr_conv3x3_c64_bf16": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int, c_int,
                                  c_int, c_int, c_int, P]),
     "sisr_wgrad3x3_c64_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -116,6 +116,43 @@ def test_conv_options_bf16():
     close(run(out_scale=oscd), base(x) * osc.view(B, 64, 1, 1), 2e-5, 2e-6, "out scale")
 
 
+@pytest.mark.parametrize("B,H,W", [(8, 128, 128), (5, 126, 150), (33, 64, 64)])
+def test_persistent_conv_is_bit_identical_to_per_tile_conv(B, H, W):
+    """Grids of >= 1024 tiles run the persistent double-buffered bf16 kernel; it must reproduce the one-workgroup-
+    per-tile kernel bit for bit (same fragment order), for every prologue / epilogue it serves."""
+    cl = torch.channels_last
+    dev4 = lambda t: t.to(DEV).contiguous(memory_format=cl)  # noqa: E731
+    x, res, mask, skip, dot = (dev4(rnd(B, 64, H, W, seed=80 + i)) for i in range(5))
+    w, b = rnd(64, 64, 3, 3, seed=86, scale=0.05).to(DEV), rnd(64, seed=87).to(DEV)
+    sc, sh = (rnd(B, 64, seed=88).abs() + 0.5).to(DEV), rnd(B, 64, seed=89).to(DEV)
+    v = hip.view_plain(H, W, 64)
+    pk = ops.pack_weight(w, "fwd")
+    cases = [dict(bias=b, relu=True, gap=True), dict(res=res, alpha=0.3), dict(mask=mask), dict(mask=mask, res=res),
+             dict(mask=mask, in_scale=sc, in_shift=sh), dict(in_scale=sc, res=res), dict(in_scale=sc),
+             dict(bias=b, relu=True, in_scale=sc, gate_add=skip, gate_out=True),
+             dict(in_scale=sc, gate_add=skip, gate_out=True, res=res), dict(gap=True, dot=dot),
+             dict(gap=True, dot=dot, res=res)]
+    outs = {}
+    try:
+        for persist in (1, 0):
+            hip.check(hip.lib().sisr_conv3x3_c64_bf16_set_persistent(persist), "set_persistent")
+            for i, kw in enumerate(cases):
+                kw = dict(kw)
+                y = torch.full((B, 64, H, W), float("nan"), device=DEV).contiguous(memory_format=cl)
+                gap = torch.full((B, ops.gap_parts(H, W), 64), float("nan"), device=DEV) if kw.pop("gap", False) else None
+                go = torch.full((B, 64, H, W), float("nan"), device=DEV).contiguous(memory_format=cl) \
+                    if kw.pop("gate_out", False) else None
+                ops.conv_c64(x, v, pk, kw.pop("bias", None), (1, 64), y, v, B, H, W, 64, 64, gap=gap, gate_out=go, **kw)
+                outs[(persist, i)] = (y, gap, go)
+    finally:
+        hip.lib().sisr_conv3x3_c64_bf16_set_persistent(1)
+    for i in range(len(cases)):
+        for a, bb, what in zip(outs[(1, i)], outs[(0, i)], ("output", "gap / dot partials", "gate_out")):
+            if a is not None:
+                assert not torch.isnan(a).any(), f"case {i}: {what} has unwritten elements"
+                assert torch.equal(a, bb), f"case {i}: {what} differs between the two kernels"
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 13, 9), (2, 16, 40), (1, 57, 86), (1, 128, 128)])
 def test_conv_gate_and_dot_hooks_bf16(B, H, W):
     """GATE prologue (input = t*g + skip built in fp32, written out, then rounded) and DOT epilogue of the bf16 conv."""

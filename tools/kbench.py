@@ -75,6 +75,24 @@ def main():
         print(json.dumps({"kernel": name, "batch": B, **res[name]}), flush=True)
 
     variants = [int(t) for t in a.variants.split(",")]
+    if a.precision == "bf16" and a.rounds > 0:
+        # interleaved A/B of the persistent (1) and per-tile (0) bf16 conv kernels, plain and dgrad-with-mask forms
+        forms = {"conv": lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64),
+                 "conv_dgrad2": lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1, in_scale=sc,
+                                                     in_shift=sh),
+                 "conv_res": lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, res=x)}
+        for name, fn in forms.items():
+            times = {0: [], 1: []}
+            for r in range(a.rounds):
+                for mode in (1, 0):
+                    hip.lib().sisr_conv3x3_c64_bf16_set_persistent(mode)
+                    times[mode].append(timeit(fn, a.iters, warm=1))
+            for mode in (1, 0):
+                ts = sorted(times[mode])
+                print(json.dumps({"kernel": f"{name}_persist{mode}", "batch": B, "median_us": ts[len(ts) // 2] * 1e6,
+                                  "min_us": ts[0] * 1e6}), flush=True)
+        hip.lib().sisr_conv3x3_c64_bf16_set_persistent(1)
+        return
     if a.rounds > 0 and (not only or "conv" in only):
         # interleaved A/B (guide rule 24): rounds x variants in one process, median and min per variant
         times = {var: [] for var in variants}
