@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
         if (MASK) v = (p.mask + off)[loff_y] > 0.f ? v : 0.f;
         if (RES) v += (p.res + off)[loff_y];
         (p.y + off)[loff_y] = v;
-        gsum += DOT ? v * (p.dot + off)[loff_y] : v;
+        gsum = DOT ? __builtin_fmaf(v, (p.dot + off)[loff_y], gsum) : gsum + v;  // explicit fma: same bits in every build
       }
     } else if (row < H) {
 #pragma unroll
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
           if (MASK) v = (p.mask + off)[loff_y] > 0.f ? v : 0.f;
           if (RES) v += (p.res + off)[loff_y];
           (p.y + off)[loff_y] = v;
-          gsum += DOT ? v * (p.dot + off)[loff_y] : v;
+          gsum = DOT ? __builtin_fmaf(v, (p.dot + off)[loff_y], gsum) : gsum + v;  // explicit fma: same bits in every build
         }
       }
     }
