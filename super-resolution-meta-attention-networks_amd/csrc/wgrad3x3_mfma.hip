@@ -402,10 +402,13 @@ struct ReduceParams {
   int S, units, cin_chunks, cout_chunks, flip, on, oq, in_, iq, bias_n, bias_q;
 };
 
-// blockDim = (64, 4): x = element within a 64-run (coalesced across slabs), y = slab group (S split 4 ways,
-// 8 loads in flight); the four group sums are added in group order through LDS.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceParams p) {
-  __shared__ float red[4][64];
+// blockDim = (64, RG): x = element within a 64-run (coalesced across slabs), y = slab group (S split RG ways, up to
+// 8 loads in flight per thread; with RG = 16 the 128 slabs of a 64 -> 64 gradient are one round of loads); the
+// group sums are added in group order through LDS.  Latency-bound (5.5 us stand-alone for 18.9 MB of slabs), so the
+// point of RG is parallelism.
+#define RG 16
+__global__ __launch_bounds__(64 * RG) void wgrad_reduce_kernel(ReduceParams p) {
+  __shared__ float red[RG][64];
   const long total = (long)p.units * SLAB;
   const long gid = (long)blockIdx.x * 64 + threadIdx.x;
   const int grp = threadIdx.y;
@@ -417,19 +420,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceParams p) {
     const float* src = is_w ? p.slabs + gid : p.bias_slabs + j;
     const long stride = is_w ? (long)p.units * SLAB : (long)p.cout_chunks * 64;
     int k = grp;
-    for (; k + 28 < p.S; k += 32) {
+    for (; k + 7 * RG < p.S; k += 8 * RG) {
       float t[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = src[(long)(k + 4 * u) * stride];
+      for (int u = 0; u < 8; ++u) t[u] = src[(long)(k + RG * u) * stride];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += t[u];
     }
-    for (; k < p.S; k += 4) s += src[(long)k * stride];
+    for (; k < p.S; k += RG) s += src[(long)k * stride];
   }
   red[grp][threadIdx.x] = s;
   __syncthreads();
   if (grp != 0) return;
-  s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  s = red[0][threadIdx.x];
+#pragma unroll
+  for (int g = 1; g < RG; ++g) s += red[g][threadIdx.x];
   if (is_w) {
     const int unit = (int)(gid / SLAB);
     const int e = (int)(gid - (long)unit * SLAB);
@@ -529,7 +534,7 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   r.bias_n = bias_n;
   r.bias_q = bias_q;
   const long total = (long)units * SLAB + (dbias ? cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, 4), 0, (hipStream_t)stream, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, RG), 0, (hipStream_t)stream, r);
   return sisr_check_launch();
 }
 
@@ -605,6 +610,6 @@ extern "C" int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, cons
   r.bias_n = bias_n;
   r.bias_q = bias_q;
   const long total = (long)units * SLAB + (dbias ? cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, 4), 0, (hipStream_t)stream, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, RG), 0, (hipStream_t)stream, r);
   return sisr_check_launch();
 }
