@@ -197,6 +197,12 @@ int sisr_l1_loss(const float* a, const float* b, long n, float* loss, float* gra
 int sisr_adam_flat(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
                    float step_size, float inv_bc2_sqrt, float grad_scale, void* stream);
 
+/* ---- training tiles cut on the device (the step in front of the path) ---------------
+ * ref: sr_tools/image_manipulation.py:233-257 random_flip_rotate + random_matched_crop, in the order
+ * data_handler.py:500-513 applies them.  src: B device pointers to planar [C][H_b][W_b] fp32 images; params: B records
+ * of 8 ints {H, W, top, left, hflip, vflip, transpose, 0} (top / left in the augmented image); dst [B][C][crop][crop]. */
+int sisr_crop_augment(const float* const* src, const int* params, float* dst, int B, int C, int crop, void* stream);
+
 /* ---- diagnostics (not on the product path): sustained fp32-MFMA rate and in-kernel clock ---------- */
 int sisr_diag_mfma_peak(int blocks, int iters, float* out, unsigned long long* clk, void* stream);
 

@@ -101,3 +101,35 @@ extern "C" int sisr_adam_flat(float* p, const float* g, float* m, float* v, long
                      beta2, eps, step_size, inv_bc2_sqrt, grad_scale);
   return sisr_check_launch();
 }
+
+// ---------------------------------------------------------------- training tiles cut on the device
+// dst[b][c][i][j] = aug_b[c][top + i][left + j], aug = transpose?(vflip?(hflip?(src_b)))  -- the reference's
+// random_flip_rotate followed by random_matched_crop (ref: sr_tools/image_manipulation.py:233-257, applied in that
+// order by data_handler.py:500-513) as ONE gather over a device-resident copy of the dataset.  The random draws
+// stay on the host (Python `random`, the reference's call order); params[b] = {H, W, top, left, hflip, vflip,
+// transpose, 0} with H, W the SOURCE image size.  Planar fp32 in, NCHW fp32 out.
+struct CropRec {
+  int H, W, top, left, hflip, vflip, rot, pad;
+};
+
+__global__ __launch_bounds__(256) void crop_augment_kernel(const float* const* __restrict__ src,
+                                                           const CropRec* __restrict__ prm, float* __restrict__ dst,
+                                                           int C, int crop) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= crop * crop) return;
+  const CropRec r = prm[b];
+  const int i = idx / crop, j = idx - i * crop;
+  const int y = r.top + i, x = r.left + j;          // coordinates in the augmented image
+  const int y2 = r.rot ? x : y, x2 = r.rot ? y : x;  // undo the transpose
+  const int sy = r.vflip ? r.H - 1 - y2 : y2, sx = r.hflip ? r.W - 1 - x2 : x2;
+  dst[(((long)b * C + c) * crop + i) * crop + j] = src[b][((long)c * r.H + sy) * r.W + sx];
+}
+
+extern "C" int sisr_crop_augment(const float* const* src, const int* params, float* dst, int B, int C, int crop,
+                                 void* stream) {
+  if (!src || !params || !dst || B <= 0 || C <= 0 || crop <= 0 || B > 65535 || C > 65535) return SISR_ERR_ARG;
+  hipLaunchKernelGGL(crop_augment_kernel, dim3((crop * crop + 255) / 256, C, B), dim3(256), 0, (hipStream_t)stream, src,
+                     reinterpret_cast<const CropRec*>(params), dst, C, crop);
+  return sisr_check_launch();
+}

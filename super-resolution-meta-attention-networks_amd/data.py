@@ -78,6 +78,70 @@ def random_matched_crop(lr, hr, crop_size, scale):
     return c_lr, c_hr
 
 
+class DeviceTileSampler:
+    """Training tiles cut on the GPU from a device-resident copy of the dataset.
+
+    The reference decodes, augments and crops every sample on the host and ships float tensors through a
+    DataLoader (data_handler.py:433-525).  A MI355X holds 288 GB: DIV2K + Flickr2K as planar fp32 is ~100 GB, so
+    the decoded images are uploaded once and a step's batch is ONE gather kernel (`sisr_crop_augment`) -- no
+    worker processes, no per-step host-to-device copy of pixels.  Results are exactly the reference's
+    `random_flip_rotate` followed by `random_matched_crop`: the random draws are made here, on the host, with
+    Python's `random` in the reference's call order (three `random()` for hflip / vflip / transpose, then two
+    `randint` for the crop origin), only the pixel movement happens on the device.
+    """
+
+    def __init__(self, lr_images, hr_images, scale, crop, device, augment=True):
+        from . import hip
+        if len(lr_images) != len(hr_images) or not lr_images:
+            raise ValueError("need the same, non-zero number of LR and HR images")
+        self.hip, self.scale, self.crop, self.augment = hip, int(scale), int(crop), bool(augment)
+        self.device = torch.device(device)
+        self.lr = [t.to(self.device, torch.float32).contiguous() for t in lr_images]
+        self.hr = [t.to(self.device, torch.float32).contiguous() for t in hr_images]
+        for a, b in zip(self.lr, self.hr):
+            if a.dim() != 3 or b.dim() != 3 or b.shape[1] != a.shape[1] * self.scale or b.shape[2] != a.shape[2] * self.scale:
+                raise ValueError(f"HR {tuple(b.shape)} is not {self.scale}x LR {tuple(a.shape)}")
+            if min(a.shape[1], a.shape[2]) < self.crop:
+                raise ValueError(f"LR image {tuple(a.shape)} is smaller than the {self.crop}-pixel tile")
+        self.channels = self.lr[0].shape[0]
+
+    def __len__(self):
+        return len(self.lr)
+
+    def draw(self, index, rng=random):
+        """(top, left, hflip, vflip, transpose) for one sample, consuming `rng` exactly like the reference."""
+        _, h, w = self.lr[index].shape
+        hflip = vflip = rot = False
+        if self.augment:
+            hflip = rng.random() < 0.5
+            vflip = rng.random() < 0.5
+            rot = rng.random() < 0.5
+        ah, aw = (w, h) if rot else (h, w)  # size of the augmented LR image
+        top = rng.randint(0, max(0, ah - self.crop))
+        left = rng.randint(0, max(0, aw - self.crop))
+        return top, left, hflip, vflip, rot
+
+    def sample(self, indices, rng=random):
+        """-> (lr [B][C][crop][crop], hr [B][C][s*crop][s*crop]) fp32 tensors on the device."""
+        hip, s = self.hip, self.scale
+        B = len(indices)
+        rec_lr, rec_hr = [], []
+        for i in indices:
+            top, left, hf, vf, rot = self.draw(i, rng)
+            _, h, w = self.lr[i].shape
+            rec_lr.append([h, w, top, left, int(hf), int(vf), int(rot), 0])
+            rec_hr.append([h * s, w * s, top * s, left * s, int(hf), int(vf), int(rot), 0])
+        out = []
+        for imgs, recs, c in ((self.lr, rec_lr, self.crop), (self.hr, rec_hr, self.crop * s)):
+            ptrs = torch.tensor([imgs[i].data_ptr() for i in indices], dtype=torch.int64).to(self.device)
+            prm = torch.tensor(recs, dtype=torch.int32).to(self.device)
+            dst = torch.empty((B, self.channels, c, c), device=self.device, dtype=torch.float32)
+            hip.check(hip.lib().sisr_crop_augment(ptrs.data_ptr(), prm.data_ptr(), hip.ptr(dst), B, self.channels, c,
+                                                  hip.stream()), "sisr_crop_augment")
+            out.append(dst)
+        return out[0], out[1]
+
+
 def read_degradation_metadata(metadata_file, filenames):
     """CSV (index = image name) -> ({name: vector}, keys).  List columns (JSON) expand to repeated keys; integer
     columns are min-max normalised (QPI over the fixed 20..40 range)."""
