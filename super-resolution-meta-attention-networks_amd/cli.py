@@ -79,6 +79,7 @@ class TrainingHandler:
         if epoch_cutoff is not None:
             self.num_epochs = epoch_cutoff - self.starting_epoch
         self.train_data, self.val_data = sisr_data_setup(scale=model_params['internal_params']['scale'],
+                                                         device=self.model.model.device,
                                                          **self.model.configuration, **data_params)
 
     def train(self):

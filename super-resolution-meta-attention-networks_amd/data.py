@@ -142,6 +142,73 @@ class DeviceTileSampler:
         return out[0], out[1]
 
 
+class DeviceTileLoader:
+    """Drop-in for the training DataLoader (`[data] device_tiles = true`): same batch dicts, same order, same
+    random streams as `DataLoader(shuffle=True, num_workers=0)` over the same SuperResImages datasets -- but the
+    images are decoded once, kept on the device, and every batch is cut there by DeviceTileSampler.
+
+    Stream compatibility with torch's loader (so that a seeded run gives the same summary.csv either way): per
+    epoch one int64 draw from the global torch RNG for the loader's base seed, one for the RandomSampler's seed,
+    a `torch.randperm(n)` from a generator with that seed; per sample the five `random` draws of the sampler.
+    """
+
+    def __init__(self, datasets, batch_size, device, drop_last=False):
+        self.batch_size, self.drop_last = int(batch_size), bool(drop_last)
+        crops = {d.patch_crop for d in datasets}
+        augs = {d.random_augment is not None for d in datasets}
+        scales = {d.scale for d in datasets}
+        if len(crops) != 1 or None in crops or len(augs) != 1 or len(scales) != 1:
+            raise ValueError("device_tiles needs one common `crop` size, augmentation flag and scale on all training sets")
+        lr, hr, self.tags, self.hr_tags, meta = [], [], [], [], []
+        self.metadata_keys = datasets[0].metadata_keys
+        for d in datasets:
+            if d.hr_base is None:
+                raise ValueError("device_tiles needs HR images (training sets)")
+            if d.metadata_keys != self.metadata_keys:
+                raise ValueError("training sets disagree on their metadata columns")
+            for i in range(len(d)):
+                base_name, image_name = d.base_filenames[i], d.lr_filenames[i]
+                lr_im = read_image(os.path.join(d.lr_base, image_name))
+                hr_im = read_image(os.path.join(d.hr_base, base_name))
+                h, w = lr_im.height * d.scale, lr_im.width * d.scale
+                if hr_im.width != w or hr_im.height != h:
+                    hr_im = center_crop(hr_im, height=h, width=w)
+                lr.append(to_tensor(lr_im))
+                hr.append(to_tensor(hr_im))
+                self.tags.append(image_name)
+                self.hr_tags.append(base_name)
+                meta.append(d.metadata[i] if d.metadata is not None else None)
+        self.metadata = meta
+        self.sampler = DeviceTileSampler(lr, hr, scale=scales.pop(), crop=crops.pop(), device=device, augment=augs.pop())
+        self.dataset = self.sampler  # len(loader.dataset), as callers of a DataLoader expect
+
+    def __len__(self):
+        n = len(self.sampler)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.sampler)
+        torch.empty((), dtype=torch.int64).random_()                      # the loader iterator's base seed
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())   # RandomSampler's generator seed
+        g = torch.Generator()
+        g.manual_seed(seed)
+        order = torch.randperm(n, generator=g).tolist()
+        for start in range(0, n, self.batch_size):
+            idx = order[start:start + self.batch_size]
+            if len(idx) < self.batch_size and self.drop_last:
+                return
+            lr, hr = self.sampler.sample(idx)
+            B = len(idx)
+            zeros = torch.zeros(B, dtype=torch.int64)
+            if self.metadata[idx[0]] is not None:
+                md = torch.from_numpy(np.stack([self.metadata[i] for i in idx]))
+            else:
+                md = zeros.clone()
+            yield {'lr': lr, 'hr': hr, 'tag': [self.tags[i] for i in idx], 'hr_tag': [self.hr_tags[i] for i in idx],
+                   'mask': zeros.clone(), 'halfway_data': zeros.clone(), 'metadata': md,
+                   'metadata_keys': [tuple(k for _ in range(B)) for k in self.metadata_keys], 'blur_kernels': zeros.clone()}
+
+
 def read_degradation_metadata(metadata_file, filenames):
     """CSV (index = image name) -> ({name: vector}, keys).  List columns (JSON) expand to repeated keys; integer
     columns are min-max normalised (QPI over the fixed 20..40 range)."""
@@ -232,8 +299,10 @@ class SuperResImages(Dataset):
 
 
 def sisr_data_setup(training_sets, eval_sets, batch_size=16, eval_batch_size=1, dataloader_threads=8,
-                    drop_last_training_batch=False, **common):
-    """TOML [data] block -> (train DataLoader, val DataLoader).  ref: training/data_setup.py:9-125"""
+                    drop_last_training_batch=False, device_tiles=False, device=None, **common):
+    """TOML [data] block -> (train DataLoader, val DataLoader).  ref: training/data_setup.py:9-125
+    `device_tiles = true` (not a reference option): training batches are cut on the GPU from a device-resident copy
+    of the training images (DeviceTileLoader) instead of by DataLoader workers."""
     common = {k: v for k, v in common.items() if k in ('scale', 'input', 'colorspace')}
 
     def setup(ds, split):
@@ -256,8 +325,13 @@ def sisr_data_setup(training_sets, eval_sets, batch_size=16, eval_batch_size=1, 
 
     train = [setup(d, 'train') for d in training_sets.values()]
     val = [setup(d, 'eval') for d in eval_sets.values()]
-    train = train[0] if len(train) == 1 else ConcatDataset(train)
     val = val[0] if len(val) == 1 else ConcatDataset(val)
+    if device_tiles:
+        if device is None or not torch.cuda.is_available():
+            raise RuntimeError("device_tiles needs a HIP device")
+        return (DeviceTileLoader(train, batch_size, device, drop_last=drop_last_training_batch),
+                DataLoader(dataset=val, batch_size=eval_batch_size))
+    train = train[0] if len(train) == 1 else ConcatDataset(train)
     train_loader = DataLoader(dataset=train, batch_size=batch_size, shuffle=True, num_workers=dataloader_threads,
                               pin_memory=torch.cuda.is_available(), drop_last=drop_last_training_batch)
     return train_loader, DataLoader(dataset=val, batch_size=eval_batch_size)

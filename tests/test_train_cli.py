@@ -97,3 +97,19 @@ def test_train_and_eval_entry_points_on_hip(name, tmp_path):
                                      full_directory=True, scale=4, out_loc=str(tmp_path), results_name="ev")
     assert len(df) == 5 and abs(float(avg["PSNR"].iloc[0]) - ref["val-PSNR"][1]) < 5e-3
     assert os.path.isfile(os.path.join(str(tmp_path), "ev", "standard_metrics", "average_metrics.csv"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["edsr", "qedsr"])
+def test_device_tiles_reproduce_the_reference_run(name, tmp_path):
+    """`[data] device_tiles = true`: the same experiment with the training batches cut on the GPU from a device-
+    resident copy of the images must land on the reference's summary.csv too (same shuffle, same crops / flips)."""
+    ref = golden_json("g5_train_sisr")[name]["summary"]
+    cfg = _config(name, tmp_path)
+    cfg["training"]["gpu"] = "single"
+    cfg["training"]["sp_gpu"] = 0
+    cfg["data"]["device_tiles"] = True
+    total = sisr_amd.cli.train_sisr(cfg)
+    np.testing.assert_allclose(total["train-loss"], ref["train-loss"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(total["val-loss"], ref["val-loss"], rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(total["val-PSNR"], ref["val-PSNR"], rtol=0, atol=5e-3)
