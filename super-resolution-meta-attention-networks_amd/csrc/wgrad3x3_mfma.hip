@@ -218,7 +218,7 @@ __device__ __forceinline__ bf16x8 wg_tr_frag(const unsigned char* base, unsigned
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad3x3_c64_bf16_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_kernel(WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* ldx = ldsb;
   unsigned char* ldy = ldsb + BW_X_BYTES;
@@ -264,90 +264,104 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_bf16_kernel(WgradParams p
     t_end = min(total, (xcd + 1) * per);
     t_step = p.S >> 3;
   }
-  for (int tile = t_begin; tile < t_end; tile += t_step) {
-    const int b = tile / tiles_per_img;
+  // ---- staging split into "issue the loads" and "convert + write LDS": one workgroup per CU (512 VGPRs per wave),
+  // the loads of tile i+1 (38 float4 per thread) are in flight while tile i is in its K loop.  Thread (c8, pcol)
+  // owns channels 8 c8 .. +7 of x halo column pcol + 1 (ten rows) and of dY column pcol (eight rows); the two edge
+  // columns of the halo (10 x 2 x 8 = 160 items) go one per thread to tid < 160 -- every load is unconditional.
+  struct Stage {
+    f32x4 x[WH_H][2];
+    f32x4 xe[2];
+    f32x4 y[WT_H][2];
+  };
+  Stage st;
+  const int c8 = tid & 7, pcol = tid >> 3;
+  const int eidx = tid % 160, er = eidx >> 4, eside = (eidx >> 3) & 1, ec8 = eidx & 7;
+  auto decode = [&](int tile, int& b, int& h0, int& w0) {
+    b = tile / tiles_per_img;
     const int tr = tile - b * tiles_per_img;
-    const int th = tr / p.tiles_w, tw = tr - th * p.tiles_w;
-    const int h0 = th * WT_H, w0 = tw * WT_W;
-    __syncthreads();
-    {  // staging: thread = (8-channel chunk c8, column pcol [+32])
-      int tl = tid;
-      asm volatile("" : "+v"(tl));
-      const int c8 = tl & 7, pcol = tl >> 3;
-      const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(cc);
-      unsigned gx[2], lx[2];
-      bool okx[2];
+    const int th = tr / p.tiles_w;
+    h0 = th * WT_H;
+    w0 = (tr - th * p.tiles_w) * WT_W;
+  };
+  auto issue = [&](int tile) {
+    int b, h0, w0;
+    decode(tile, b, h0, w0);
+    const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(cc);
+    const int gxi = min(w0 + pcol, W - 1) * (int)p.xv.sW + c8 * 8;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int col = pcol + 32 * k;
-        const int gw = w0 - 1 + col;
-        okx[k] = gw >= 0 && gw < W && col < WH_W;
-        gx[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c8 * 8);
-        lx[k] = col * BW_PIX + ((c8 ^ (((col >> 1) & 1) << 2)) << 4);
-      }
-#pragma unroll
-      for (int r0 = 0; r0 < WH_H; r0 += 2) {
-        f32x4 v[2][2][2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const float* xrow = xb + (long)min(max(h0 - 1 + r0 + r, 0), H - 1) * p.xv.sH;  // scalar
-          v[r][0][0] = *reinterpret_cast<const f32x4*>(xrow + gx[0]);
-          v[r][0][1] = *reinterpret_cast<const f32x4*>(xrow + gx[0] + 4);
-          if (pcol < 2) {
-            v[r][1][0] = *reinterpret_cast<const f32x4*>(xrow + gx[1]);
-            v[r][1][1] = *reinterpret_cast<const f32x4*>(xrow + gx[1] + 4);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int gh = h0 - 1 + r0 + r;
-          const bool rok = gh >= 0 && gh < H;  // scalar
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-            if (k == 0 || pcol < 2) {
-              u32x4 pk = wg_pack_bf16x8(v[r][k][0], v[r][k][1]);
-              const unsigned m = (rok && okx[k]) ? 0xffffffffu : 0u;
-              pk &= (u32x4){m, m, m, m};
-              *reinterpret_cast<u32x4*>(ldx + (r0 + r) * (WH_W * BW_PIX) + lx[k]) = pk;
-            }
-        }
-      }
-      const float* yb = p.dy + (long)b * p.yv.sB + p.yv.chunk(cq);
-      f32x4 s4a = {1.f, 1.f, 1.f, 1.f}, s4b = s4a, t4a = {0.f, 0.f, 0.f, 0.f}, t4b = t4a;
-      if (p.dy_scale) {
-        const float* sp = p.dy_scale + (long)b * Cout + cq * 64 + c8 * 8;
-        s4a = *reinterpret_cast<const f32x4*>(sp);
-        s4b = *reinterpret_cast<const f32x4*>(sp + 4);
-      }
-      if (p.dy_shift) {
-        const float* tp = p.dy_shift + (long)b * Cout + cq * 64 + c8 * 8;
-        t4a = *reinterpret_cast<const f32x4*>(tp);
-        t4b = *reinterpret_cast<const f32x4*>(tp + 4);
-      }
-      const int gwy = w0 + pcol;
-      const bool oky = gwy < W;
-      const unsigned gy = (unsigned)(min(gwy, W - 1) * (int)p.yv.sW + c8 * 8);
-      const unsigned ly = pcol * BW_PIX + ((c8 ^ (((pcol >> 1) & 1) << 2)) << 4);
-#pragma unroll
-      for (int r0 = 0; r0 < WT_H; r0 += 2) {
-        f32x4 u[2][2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const float* yrow = yb + (long)min(h0 + r0 + r, H - 1) * p.yv.sH;
-          u[r][0] = *reinterpret_cast<const f32x4*>(yrow + gy);
-          u[r][1] = *reinterpret_cast<const f32x4*>(yrow + gy + 4);
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const bool ok = oky && (h0 + r0 + r < H);
-          const f32x4 ta = sisr_keep_if(u[r][0] * s4a + t4a, ok), tb = sisr_keep_if(u[r][1] * s4b + t4b, ok);
-          bsa += ta;
-          bsb += tb;
-          *reinterpret_cast<u32x4*>(ldy + (r0 + r) * (WT_W * BW_PIX) + ly) = wg_pack_bf16x8(ta, tb);
-        }
-      }
+    for (int r = 0; r < WH_H; ++r) {
+      const float* a = xb + (long)min(max(h0 - 1 + r, 0), H - 1) * p.xv.sH + gxi;
+      st.x[r][0] = *reinterpret_cast<const f32x4*>(a);
+      st.x[r][1] = *reinterpret_cast<const f32x4*>(a + 4);
     }
-    __syncthreads();
+    {
+      const int gwe = min(max(eside ? w0 + WT_W : w0 - 1, 0), W - 1);
+      const float* e = xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8;
+      st.xe[0] = *reinterpret_cast<const f32x4*>(e);
+      st.xe[1] = *reinterpret_cast<const f32x4*>(e + 4);
+    }
+    const float* yb = p.dy + (long)b * p.yv.sB + p.yv.chunk(cq);
+    const int gyi = min(w0 + pcol, W - 1) * (int)p.yv.sW + c8 * 8;
+#pragma unroll
+    for (int r = 0; r < WT_H; ++r) {
+      const float* a = yb + (long)min(h0 + r, H - 1) * p.yv.sH + gyi;
+      st.y[r][0] = *reinterpret_cast<const f32x4*>(a);
+      st.y[r][1] = *reinterpret_cast<const f32x4*>(a + 4);
+    }
+  };
+  auto commit = [&](int tile) {
+    int b, h0, w0;
+    decode(tile, b, h0, w0);
+    const int col = pcol + 1;
+    const bool cokx = w0 + pcol < W;
+    const unsigned lx = col * BW_PIX + ((c8 ^ (((col >> 1) & 1) << 2)) << 4);
+#pragma unroll
+    for (int r = 0; r < WH_H; ++r) {
+      const int gh = h0 - 1 + r;
+      u32x4 pk = wg_pack_bf16x8(st.x[r][0], st.x[r][1]);
+      const unsigned m = (gh >= 0 && gh < H && cokx) ? 0xffffffffu : 0u;
+      pk &= (u32x4){m, m, m, m};
+      *reinterpret_cast<u32x4*>(ldx + r * (WH_W * BW_PIX) + lx) = pk;
+    }
+    {
+      const int ecol = eside ? WH_W - 1 : 0, gwe = eside ? w0 + WT_W : w0 - 1, ghe = h0 - 1 + er;
+      u32x4 pk = wg_pack_bf16x8(st.xe[0], st.xe[1]);
+      const unsigned m = (ghe >= 0 && ghe < H && gwe >= 0 && gwe < W) ? 0xffffffffu : 0u;
+      pk &= (u32x4){m, m, m, m};
+      if (tid < 160)
+        *reinterpret_cast<u32x4*>(ldx + er * (WH_W * BW_PIX) + ecol * BW_PIX + ((ec8 ^ (((ecol >> 1) & 1) << 2)) << 4)) = pk;
+    }
+    f32x4 s4a = {1.f, 1.f, 1.f, 1.f}, s4b = s4a, t4a = {0.f, 0.f, 0.f, 0.f}, t4b = t4a;
+    if (p.dy_scale) {
+      const float* sp = p.dy_scale + (long)b * Cout + cq * 64 + c8 * 8;
+      s4a = *reinterpret_cast<const f32x4*>(sp);
+      s4b = *reinterpret_cast<const f32x4*>(sp + 4);
+    }
+    if (p.dy_shift) {
+      const float* tp = p.dy_shift + (long)b * Cout + cq * 64 + c8 * 8;
+      t4a = *reinterpret_cast<const f32x4*>(tp);
+      t4b = *reinterpret_cast<const f32x4*>(tp + 4);
+    }
+    const bool coky = w0 + pcol < W;
+    const unsigned ly = pcol * BW_PIX + ((c8 ^ (((pcol >> 1) & 1) << 2)) << 4);
+#pragma unroll
+    for (int r = 0; r < WT_H; ++r) {
+      const bool ok = coky && (h0 + r < H);
+      const f32x4 ta = sisr_keep_if(st.y[r][0] * s4a + t4a, ok), tb = sisr_keep_if(st.y[r][1] * s4b + t4b, ok);
+      bsa += ta;
+      bsb += tb;
+      *reinterpret_cast<u32x4*>(ldy + r * (WT_W * BW_PIX) + ly) = wg_pack_bf16x8(ta, tb);
+    }
+  };
+
+  if (t_begin < t_end) {
+    issue(t_begin);
+    commit(t_begin);
+  }
+  __syncthreads();
+  for (int tile = t_begin; tile < t_end; tile += t_step) {
+    const bool has_next = tile + t_step < t_end;  // uniform
+    if (has_next) issue(tile + t_step);
 
     // ---- 16 K-steps of 16 pixels (tile row r, half hf), nine taps each
 #pragma unroll 1
@@ -364,6 +378,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_bf16_kernel(WgradParams p
           if (t % 3 == 2) __builtin_amdgcn_sched_barrier(0);  // keep at most three taps' fragments in flight
         }
       }
+    }
+    __syncthreads();  // every wave is done with this tile's LDS image
+    if (has_next) {
+      commit(tile + t_step);
+      __syncthreads();
     }
   }
 
@@ -540,7 +559,7 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
 
 static int wgrad_bf16_split(int B, int H, int W, int pairs) {
   const long tiles = (long)B * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
-  long S = 512 / pairs;  // two workgroups per CU resident across the whole grid
+  long S = 256 / pairs;  // one persistent workgroup per CU (it prefetches its next tile: 152 KB in flight per CU)
   if (S < 1) S = 1;
   if (S > tiles) S = tiles;
   return (int)S;
