@@ -97,7 +97,10 @@ size_t sisr_ca_gate_bwd_workspace_bytes(int B);
 int sisr_ca_gate_bwd(const float* dg_partial, int parts, int B, float inv_hw, const float* w1, const float* w2,
                      int channels, int hidden, const float* s, const float* hid, const float* ca, const float* mul,
                      float* shift, float* dmul, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
-                     void* stream);
+                     unsigned* counter, void* stream);
+/* counter: one zero-initialised device word owned by the caller and reused across calls on a stream (the kernel
+ * returns it to zero): the sample blocks count themselves on it and the last one sums the parameter gradients,
+ * so the whole gate backward is ONE launch on the block's serial backward chain. */
 
 /* ---- meta-attention gate --------------------------------------------------------------------------
  * ref: attention_manipulators/q_layer.py:4-43 ParaCALayer: m = sigmoid(V2 act(V1 md + c1) + c2) */

@@ -64,64 +64,68 @@ __global__ __launch_bounds__(256) void ca_gate_fwd_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------- CA gate backward
-// Stage 1 (one block per sample): dg = sum of the partials of sum_hw dOut*t, then the per-sample chain
-//   dca = dg*mul; dz2 = dca*ca*(1-ca); dh = W2^T dz2; dz1 = dh*[hid>0]; ds = W1^T dz1
-// -> shift[b][c] = ds*inv_hw (the GAP backward broadcast, consumed as the dgrad/wgrad prologue shift),
-//    dmul = dg*ca, and the per-sample dz2 [B][64], dz1 [B][R] for stage 2.
-// Stage 2 (one block): parameter gradients summed over the batch in batch order.
-__global__ __launch_bounds__(256) void ca_gate_bwd_sample_kernel(const float* __restrict__ dgpart, int parts,
-                                                                 float inv_hw, const float* __restrict__ w1,
-                                                                 const float* __restrict__ w2, int R,
-                                                                 const float* __restrict__ hid,
-                                                                 const float* __restrict__ ca_in,
-                                                                 const float* __restrict__ mul, float* __restrict__ shift,
-                                                                 float* __restrict__ dmul, float* __restrict__ dz2_out,
-                                                                 float* __restrict__ dz1_out) {
+// One launch (it sits on the serial backward chain of every block).  Per sample (one block each):
+//   dg = sum of the partials of sum_hw dOut*t;  dca = dg*mul; dz2 = dca*ca*(1-ca); dh = W2^T dz2;
+//   dz1 = dh*[hid>0]; ds = W1^T dz1  ->  shift[b][c] = ds*inv_hw (the GAP backward broadcast, consumed as the
+//   dgrad / wgrad prologue shift), dmul = dg*ca, and dz2 [B][64], dz1 [B][R] into the workspace.
+// The block that finishes last (device-scope counter, reset for the next launch) then sums the parameter
+// gradients over the batch in batch order -- which block does it does not change the result.
+__global__ __launch_bounds__(256) void ca_gate_bwd_kernel(const float* __restrict__ dgpart, int parts, float inv_hw,
+                                                          const float* __restrict__ w1, const float* __restrict__ w2,
+                                                          int R, const float* __restrict__ s_in,
+                                                          const float* __restrict__ hid, const float* __restrict__ ca_in,
+                                                          const float* __restrict__ mul, float* __restrict__ shift,
+                                                          float* __restrict__ dmul, float* dz2_out, float* dz1_out,
+                                                          float* __restrict__ dw1, float* __restrict__ db1,
+                                                          float* __restrict__ dw2, float* __restrict__ db2,
+                                                          unsigned* counter, int B) {
   __shared__ float red[256];
+  __shared__ int is_last;
   const int b = blockIdx.x, c = threadIdx.x & 63;
   const float dg = block_sum_parts(dgpart + (long)b * parts * 64, parts, red);
-  if (threadIdx.x >= 64) return;
-  const float ca = ca_in[b * 64 + c];
-  float dca = dg;
-  if (mul) {
-    dmul[b * 64 + c] = dg * ca;
-    dca = dg * mul[b * 64 + c];
+  if (threadIdx.x < 64) {
+    const float ca = ca_in[b * 64 + c];
+    float dca = dg;
+    if (mul) {
+      dmul[b * 64 + c] = dg * ca;
+      dca = dg * mul[b * 64 + c];
+    }
+    const float dz2 = dca * ca * (1.f - ca);
+    dz2_out[b * 64 + c] = dz2;
+    float ds = 0.f;
+    for (int j = 0; j < R; ++j) {
+      const float dh = wave_sum(w2[c * R + j] * dz2);
+      const float dz1 = hid[b * R + j] > 0.f ? dh : 0.f;
+      if (c == 0) dz1_out[b * R + j] = dz1;
+      ds += w1[j * 64 + c] * dz1;
+    }
+    shift[b * 64 + c] = ds * inv_hw;
   }
-  const float dz2 = dca * ca * (1.f - ca);
-  dz2_out[b * 64 + c] = dz2;
-  float ds = 0.f;
-  for (int j = 0; j < R; ++j) {
-    const float dh = wave_sum(w2[c * R + j] * dz2);
-    const float dz1 = hid[b * R + j] > 0.f ? dh : 0.f;
-    if (c == 0) dz1_out[b * R + j] = dz1;
-    ds += w1[j * 64 + c] * dz1;
-  }
-  shift[b * 64 + c] = ds * inv_hw;
-}
-
-__global__ __launch_bounds__(256) void ca_gate_bwd_param_kernel(const float* __restrict__ dz2, const float* __restrict__ dz1,
-                                                                const float* __restrict__ s_in,
-                                                                const float* __restrict__ hid, int B, int R,
-                                                                float* __restrict__ dw1, float* __restrict__ db1,
-                                                                float* __restrict__ dw2, float* __restrict__ db2) {
+  __threadfence();  // this block's dz2 / dz1 are visible device-wide before it is counted
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(counter, 1u) == (unsigned)(B - 1);
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  if (threadIdx.x == 0) *counter = 0u;
   const int n = 64 * R;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * n + 64 + R; i += gridDim.x * 256) {
+  for (int i = threadIdx.x; i < 2 * n + 64 + R; i += 256) {
     float acc = 0.f;
     if (i < n) {  // dw2[c][j] = sum_b dz2[b][c] * hid[b][j]
-      const int c = i / R, j = i - c * R;
-      for (int b = 0; b < B; ++b) acc += dz2[b * 64 + c] * hid[b * R + j];
+      const int cc = i / R, j = i - cc * R;
+      for (int bb = 0; bb < B; ++bb) acc += __builtin_nontemporal_load(dz2_out + bb * 64 + cc) * hid[bb * R + j];
       dw2[i] = acc;
     } else if (i < 2 * n) {  // dw1[j][c] = sum_b dz1[b][j] * s[b][c]
-      const int k = i - n, j = k >> 6, c = k & 63;
-      for (int b = 0; b < B; ++b) acc += dz1[b * R + j] * s_in[b * 64 + c];
+      const int k = i - n, j = k >> 6, cc = k & 63;
+      for (int bb = 0; bb < B; ++bb) acc += __builtin_nontemporal_load(dz1_out + bb * R + j) * s_in[bb * 64 + cc];
       dw1[k] = acc;
     } else if (i < 2 * n + 64) {
-      const int c = i - 2 * n;
-      for (int b = 0; b < B; ++b) acc += dz2[b * 64 + c];
-      db2[c] = acc;
+      const int cc = i - 2 * n;
+      for (int bb = 0; bb < B; ++bb) acc += __builtin_nontemporal_load(dz2_out + bb * 64 + cc);
+      db2[cc] = acc;
     } else {
       const int j = i - 2 * n - 64;
-      for (int b = 0; b < B; ++b) acc += dz1[b * R + j];
+      for (int bb = 0; bb < B; ++bb) acc += __builtin_nontemporal_load(dz1_out + bb * R + j);
       db1[j] = acc;
     }
   }
@@ -416,21 +420,16 @@ extern "C" size_t sisr_ca_gate_bwd_workspace_bytes(int B) { return B > 0 ? (size
 extern "C" int sisr_ca_gate_bwd(const float* dg_partial, int parts, int B, float inv_hw, const float* w1,
                                 const float* w2, int channels, int hidden, const float* s, const float* hid,
                                 const float* ca, const float* mul, float* shift, float* dmul, float* dw1, float* db1,
-                                float* dw2, float* db2, float* workspace, void* stream) {
-  if (!dg_partial || !w1 || !w2 || !s || !hid || !ca || !shift || !dw1 || !db1 || !dw2 || !db2 || !workspace || B <= 0 ||
-      parts <= 0)
+                                float* dw2, float* db2, float* workspace, unsigned* counter, void* stream) {
+  if (!dg_partial || !w1 || !w2 || !s || !hid || !ca || !shift || !dw1 || !db1 || !dw2 || !db2 || !workspace || !counter ||
+      B <= 0 || parts <= 0)
     return SISR_ERR_ARG;
   if (mul && !dmul) return SISR_ERR_ARG;
   if (channels != 64 || hidden < 1 || hidden > 16) return SISR_ERR_UNSUPPORTED;
   float* dz2 = workspace;
   float* dz1 = workspace + (size_t)B * 64;
-  hipLaunchKernelGGL(ca_gate_bwd_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dg_partial, parts, inv_hw, w1,
-                     w2, hidden, hid, ca, mul, shift, dmul, dz2, dz1);
-  int rc = sisr_check_launch();
-  if (rc) return rc;
-  const int nout = 2 * 64 * hidden + 64 + hidden;
-  hipLaunchKernelGGL(ca_gate_bwd_param_kernel, dim3((nout + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz2, dz1, s,
-                     hid, B, hidden, dw1, db1, dw2, db2);
+  hipLaunchKernelGGL(ca_gate_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dg_partial, parts, inv_hw, w1, w2,
+                     hidden, s, hid, ca, mul, shift, dmul, dz2, dz1, dw1, db1, dw2, db2, counter, B);
   return sisr_check_launch();
 }
 

@@ -32,7 +32,7 @@ _SIGS = {
                                 c_int, P]),
     "sisr_ca_gate_fwd": (c_int, [P, c_int, c_int, c_float, P, P, P, P, c_int, c_int, P, P, P, P, P, P]),
     "sisr_ca_gate_bwd_workspace_bytes": (c_size_t, [c_int]),
-    "sisr_ca_gate_bwd": (c_int, [P, c_int, c_int, c_float, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "sisr_ca_gate_bwd": (c_int, [P, c_int, c_int, c_float, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "sisr_meta_gate_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P]),
     "sisr_meta_gate_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sisr_meta_gate_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P]),
@@ -125,6 +125,19 @@ def ptr(t):
     if t.dtype != torch.float32:
         raise RuntimeError(f"sisr HIP kernels are fp32; got {t.dtype}")
     return t.data_ptr()
+
+
+_counters = {}
+
+
+def gate_counter(device):
+    """The zero-initialised device word sisr_ca_gate_bwd counts its sample blocks on (returned to zero by every launch;
+    one per device: the gate backward only ever runs on the stream that drives the backward pass)."""
+    c = _counters.get(device.index)
+    if c is None:
+        c = torch.zeros(4, device=device, dtype=torch.int32)
+        _counters[device.index] = c
+    return c.data_ptr()
 
 
 def ptr_bf16(t):

@@ -86,6 +86,21 @@ def _grad_buf(w):
     return torch.empty_like(w)
 
 
+_gate_ws_cache = {}
+
+
+def _gate_ws(B, device):
+    """Scratch of sisr_ca_gate_bwd ([B][80] floats), one per (device, batch): a named, persistent tensor -- a
+    temporary built inside the call expression is released before the launch and the very next allocation (the
+    lazily created gate counter, once) can be handed the same block."""
+    key = (device.index, B)
+    t = _gate_ws_cache.get(key)
+    if t is None:
+        t = torch.empty((B, 80), device=device, dtype=torch.float32)
+        _gate_ws_cache[key] = t
+    return t
+
+
 def _vec(B, C, device):
     return torch.empty((B, C), device=device, dtype=torch.float32)
 
@@ -428,7 +443,7 @@ class _ResBlock(Function):
                     rc = L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
                                             hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
                                             hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
-                                            hip.ptr(_vec(B, 80, dev)), hip.stream())
+                                            hip.ptr(_gate_ws(B, dev)), hip.gate_counter(dev), hip.stream())
                     hip.check(rc, "sisr_ca_gate_bwd")
                     dm, scale = dmv, g
                 else:
@@ -593,7 +608,8 @@ class _GatedGroup(Function):
                 hip.check(L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
                                              hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
                                              hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
-                                             hip.ptr(_vec(B, 80, dev)), hip.stream()), "sisr_ca_gate_bwd")
+                                             hip.ptr(_gate_ws(B, dev)), hip.gate_counter(dev), hip.stream()),
+                          "sisr_ca_gate_bwd")
                 dw2, db2 = _grad_buf(w2), torch.empty(64, device=dev)
                 dw1, db1 = _grad_buf(w1), torch.empty(64, device=dev)
                 run(lambda t1=t1, dy=dy, dw2=dw2, db2=db2, g=g, shift=shift:
@@ -737,7 +753,7 @@ class _CALayer(Function):
         hip.check(hip.lib().sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / (H * W), hip.ptr(w1c), hip.ptr(w2c), 64, R,
                                              hip.ptr(s), hip.ptr(hid), hip.ptr(ca), None, hip.ptr(shift), None,
                                              hip.ptr(dw1), hip.ptr(db1), hip.ptr(dw2), hip.ptr(db2),
-                                             hip.ptr(_vec(B, 80, dev)), hip.stream()),
+                                             hip.ptr(_gate_ws(B, dev)), hip.gate_counter(dev), hip.stream()),
                   "sisr_ca_gate_bwd")
         dx = _affine(dy, ca, shift, None, B, H, W, 64)
         return dx, dw1.reshape(ctx.shapes[0]), db1, dw2.reshape(ctx.shapes[1]), db2
@@ -1066,7 +1082,8 @@ class _SOCA(Function):
         dw2, db2 = torch.empty_like(w2c), torch.empty(64, device=dev)
         hip.check(L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0, hip.ptr(w1c), hip.ptr(w2c), 64, R, hip.ptr(s),
                                      hip.ptr(hid), hip.ptr(ca), None, hip.ptr(dpooled), None, hip.ptr(dw1),
-                                     hip.ptr(db1), hip.ptr(dw2), hip.ptr(db2), hip.ptr(_vec(B, 80, dev)), hip.stream()),
+                                     hip.ptr(db1), hip.ptr(dw2), hip.ptr(db2), hip.ptr(_gate_ws(B, dev)),
+                                     hip.gate_counter(dev), hip.stream()),
                   "sisr_ca_gate_bwd")
         dsym = torch.empty_like(cov)
         hip.check(L.sisr_sqrtm_bwd(hip.ptr(cov), hip.ptr(saved), hip.ptr(dpooled), hip.ptr(dsym), B, 64, SOCA_ITERS,
