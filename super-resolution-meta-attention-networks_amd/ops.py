@@ -339,10 +339,10 @@ class _MetaGate(Function):
         dv1, dc1 = torch.empty(s_v1, device=dev), torch.empty(Hd, device=dev)
         dv2, dc2 = torch.empty(s_v2, device=dev), torch.empty(C, device=dev)
         dmd = torch.empty_like(md2) if ctx.needs_input_grad[0] else None
-        rc = hip.lib().sisr_meta_gate_bwd(hip.ptr(dm.contiguous()), hip.ptr(m), hip.ptr(hid), hip.ptr(md2), B, M, Hd, C,
+        dmc, ws = dm.contiguous(), _vec(B, Hd + C, dev)  # named: temporaries of a call expression may share a block
+        rc = hip.lib().sisr_meta_gate_bwd(hip.ptr(dmc), hip.ptr(m), hip.ptr(hid), hip.ptr(md2), B, M, Hd, C,
                                           hip.ptr(v1c), hip.ptr(v2c), int(ctx.relu), hip.ptr(dv1), hip.ptr(dc1),
-                                          hip.ptr(dv2), hip.ptr(dc2), hip.ptr(dmd), hip.ptr(_vec(B, Hd + C, dev)),
-                                          hip.stream())
+                                          hip.ptr(dv2), hip.ptr(dc2), hip.ptr(dmd), hip.ptr(ws), hip.stream())
         hip.check(rc, "sisr_meta_gate_bwd")
         return (dmd.reshape(s_md) if dmd is not None else None, dv1, dc1, dv2, dc2, None)
 
