@@ -4,6 +4,7 @@ This is the only place the package touches native code.  There is no fallback: i
 library is missing, or a tensor is not on a HIP device, the call raises.  PyTorch is used
 for device memory and streams only (``tensor.data_ptr()``, ``torch.cuda.current_stream()``).
 """
+import collections
 import ctypes
 import os
 from ctypes import c_float, c_int, c_int64, c_long, c_size_t, c_void_p
@@ -145,6 +146,20 @@ def ptr_bf16(t):
     if not t.is_cuda or t.dtype != torch.bfloat16:
         raise RuntimeError(f"expected a bf16 tensor on a HIP device; got {t.dtype} on {t.device}")
     return t.data_ptr()
+
+
+_recent_copies = collections.deque(maxlen=32)
+
+
+def ptr_c(t):
+    """ptr(t.contiguous()) that is safe inside a call expression: if a copy had to be made it is kept referenced for
+    the next few calls, so that another temporary of the same expression cannot be handed its block."""
+    if t is None:
+        return None
+    c = t.contiguous()
+    if c is not t:
+        _recent_copies.append(c)
+    return ptr(c)
 
 
 def stream():

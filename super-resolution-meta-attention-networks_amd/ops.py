@@ -320,8 +320,8 @@ class _MetaGate(Function):
         Hd, C = v1.shape[0], v2.shape[0]
         v1c, v2c = v1.reshape(Hd, M).contiguous(), v2.reshape(C, Hd).contiguous()
         hid, m = _vec(B, Hd, md.device), _vec(B, C, md.device)
-        rc = hip.lib().sisr_meta_gate_fwd(hip.ptr(md2), B, M, Hd, C, hip.ptr(v1c), hip.ptr(c1.contiguous()),
-                                          hip.ptr(v2c), hip.ptr(c2.contiguous()), int(relu), hip.ptr(hid), hip.ptr(m),
+        rc = hip.lib().sisr_meta_gate_fwd(hip.ptr(md2), B, M, Hd, C, hip.ptr(v1c), hip.ptr_c(c1),
+                                          hip.ptr(v2c), hip.ptr_c(c2), int(relu), hip.ptr(hid), hip.ptr(m),
                                           hip.stream())
         hip.check(rc, "sisr_meta_gate_fwd")
         ctx.save_for_backward(md2, v1c, v2c, hid, m)
@@ -393,7 +393,7 @@ class _ResBlock(Function):
                 s, hid, ca, g = _vec(B, 64, dev), _vec(B, R, dev), _vec(B, 64, dev), _vec(B, 64, dev)
                 mm = m.contiguous() if has_m else None
                 rc = hip.lib().sisr_ca_gate_fwd(hip.ptr(gap), parts, B, 1.0 / (H * W), hip.ptr(caw1c),
-                                                hip.ptr(cab1.contiguous()), hip.ptr(caw2c), hip.ptr(cab2.contiguous()),
+                                                hip.ptr_c(cab1), hip.ptr(caw2c), hip.ptr_c(cab2),
                                                 64, R, hip.ptr(mm), hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(g),
                                                 hip.stream())
                 hip.check(rc, "sisr_ca_gate_fwd")
@@ -543,8 +543,8 @@ class _GatedGroup(Function):
             caw1c, caw2c = caw1.reshape(R, 64).contiguous(), caw2.reshape(64, R).contiguous()
             sv, hid, ca, g = _vec(B, 64, dev), _vec(B, R, dev), _vec(B, 64, dev), _vec(B, 64, dev)
             mm = m.contiguous() if m is not None else None
-            hip.check(L.sisr_ca_gate_fwd(hip.ptr(gap), parts, B, 1.0 / (H * W), hip.ptr(caw1c), hip.ptr(cab1.contiguous()),
-                                         hip.ptr(caw2c), hip.ptr(cab2.contiguous()), 64, R, hip.ptr(mm), hip.ptr(sv),
+            hip.check(L.sisr_ca_gate_fwd(hip.ptr(gap), parts, B, 1.0 / (H * W), hip.ptr(caw1c), hip.ptr_c(cab1),
+                                         hip.ptr(caw2c), hip.ptr_c(cab2), 64, R, hip.ptr(mm), hip.ptr(sv),
                                          hip.ptr(hid), hip.ptr(ca), hip.ptr(g), hip.stream()), "sisr_ca_gate_fwd")
             pend = (t2, g)
             blk = [cur, w1, w2, t1, t2, caw1c, caw2c, sv, hid, ca, g] + ([mm] if mm is not None else [])
@@ -732,7 +732,7 @@ class _CALayer(Function):
         part, parts = _pixel_sums(x, None, B, H, W)
         s, hid, ca, g = _vec(B, 64, dev), _vec(B, R, dev), _vec(B, 64, dev), _vec(B, 64, dev)
         hip.check(hip.lib().sisr_ca_gate_fwd(hip.ptr(part), parts, B, 1.0 / (H * W), hip.ptr(w1c),
-                                             hip.ptr(b1.contiguous()), hip.ptr(w2c), hip.ptr(b2.contiguous()), 64, R,
+                                             hip.ptr_c(b1), hip.ptr(w2c), hip.ptr_c(b2), 64, R,
                                              None, hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(g), hip.stream()),
                   "sisr_ca_gate_fwd")
         ctx.save_for_backward(x, w1c, w2c, s, hid, ca)
@@ -1061,8 +1061,8 @@ class _SOCA(Function):
         R = w1.shape[0]
         w1c, w2c = w1.reshape(R, 64).contiguous(), w2.reshape(64, R).contiguous()
         s, hid, ca, g = _vec(B, 64, dev), _vec(B, R, dev), _vec(B, 64, dev), _vec(B, 64, dev)
-        hip.check(L.sisr_ca_gate_fwd(hip.ptr(pooled), 1, B, 1.0, hip.ptr(w1c), hip.ptr(b1.contiguous()), hip.ptr(w2c),
-                                     hip.ptr(b2.contiguous()), 64, R, None, hip.ptr(s), hip.ptr(hid), hip.ptr(ca),
+        hip.check(L.sisr_ca_gate_fwd(hip.ptr(pooled), 1, B, 1.0, hip.ptr(w1c), hip.ptr_c(b1), hip.ptr(w2c),
+                                     hip.ptr_c(b2), 64, R, None, hip.ptr(s), hip.ptr(hid), hip.ptr(ca),
                                      hip.ptr(g), hip.stream()), "sisr_ca_gate_fwd")
         ctx.save_for_backward(x, w1c, w2c, s, hid, ca, mean, cov, saved)
         ctx.shapes, ctx.win = (w1.shape, w2.shape), win
