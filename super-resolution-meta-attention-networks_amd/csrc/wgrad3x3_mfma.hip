@@ -71,60 +71,51 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) {
     const int h0 = th * WT_H, w0 = tw * WT_W;
     __syncthreads();  // previous tile fully consumed
     {  // Issue-lean staging (the fp32 MFMA owns the SIMD's issue port for its 64 cycles, so every staging
-       // instruction of this wave is paid on top of the co-resident waves' MFMAs): thread = (chunk c4, column
-       // pcol [+32]); rows are walked with a scalar row base, so an item is one global_load (scalar base + lane
-       // offset), one mask op and one ds_write.  Loads go in batches (144 accumulator VGPRs are live).
+       // instruction of this wave is paid on top of the co-resident waves' MFMAs): thread (c4, pcol) owns chunk c4
+       // of x halo column pcol + 1 and of dY column pcol; the two edge columns of the halo (10 rows x 2 x 8 chunks)
+       // go one item per thread to tid < 160, so every load is unconditional: one global_load (scalar row base + lane
+       // offset), one mask op and one ds_write per item.  Two batches of ten loads (144 accumulator VGPRs are live),
+       // x and dY rows together, so a tile waits for memory twice.
       int tl = tid;
       asm volatile("" : "+v"(tl));
       const int c4 = tl & 7, pcol = tl >> 3;
+      const int eidx = tl % 160, er = eidx >> 4, eside = (eidx >> 3) & 1, ec4 = eidx & 7;
       const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(cc) + cih * 32;
-      unsigned gx[2], lx[2];
-      bool okx[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int col = pcol + 32 * k;
-        const int gw = w0 - 1 + col;
-        okx[k] = gw >= 0 && gw < W && col < WH_W;
-        gx[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c4 * 4);
-        lx[k] = col * WSTR + c4 * 4;
-      }
-#pragma unroll
-      for (int r0 = 0; r0 < WH_H; r0 += 5) {
-        f32x4 v[5][2];
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-          const float* xrow = xb + (long)min(max(h0 - 1 + r0 + r, 0), H - 1) * p.xv.sH;  // scalar
-          v[r][0] = *reinterpret_cast<const f32x4*>(xrow + gx[0]);
-          if (pcol < 2) v[r][1] = *reinterpret_cast<const f32x4*>(xrow + gx[1]);
-        }
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-          const int gh = h0 - 1 + r0 + r;
-          const bool rok = gh >= 0 && gh < H;  // scalar
-          *reinterpret_cast<f32x4*>(ldx + (r0 + r) * (WH_W * WSTR) + lx[0]) = sisr_keep_if(v[r][0], rok && okx[0]);
-          if (pcol < 2)
-            *reinterpret_cast<f32x4*>(ldx + (r0 + r) * (WH_W * WSTR) + lx[1]) = sisr_keep_if(v[r][1], rok && okx[1]);
-        }
-      }
       const float* yb = p.dy + (long)b * p.yv.sB + p.yv.chunk(cq) + coh * 32;
+      const bool okc = w0 + pcol < W;
+      const unsigned gx = (unsigned)(min(w0 + pcol, W - 1) * (int)p.xv.sW + c4 * 4), lx = (pcol + 1) * WSTR + c4 * 4;
+      const unsigned gy = (unsigned)(min(w0 + pcol, W - 1) * (int)p.yv.sW + c4 * 4), ly = pcol * WSTR + c4 * 4;
       f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
       if (p.dy_scale) s4 = *reinterpret_cast<const f32x4*>(p.dy_scale + (long)b * Cout + cq * 64 + coh * 32 + c4 * 4);
       if (p.dy_shift) t4 = *reinterpret_cast<const f32x4*>(p.dy_shift + (long)b * Cout + cq * 64 + coh * 32 + c4 * 4);
-      const int gwy = w0 + pcol;
-      const bool oky = gwy < W;
-      const unsigned gy = (unsigned)(min(gwy, W - 1) * (int)p.yv.sW + c4 * 4);
-      const unsigned ly = pcol * WSTR + c4 * 4;
 #pragma unroll
-      for (int r0 = 0; r0 < WT_H; r0 += 4) {
-        f32x4 u[4];
+      for (int half = 0; half < 2; ++half) {
+        f32x4 v[5], u[4], e;
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+          v[r] = *reinterpret_cast<const f32x4*>(xb + (long)min(max(h0 - 1 + 5 * half + r, 0), H - 1) * p.xv.sH + gx);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          u[r] = *reinterpret_cast<const f32x4*>(yb + (long)min(h0 + r0 + r, H - 1) * p.yv.sH + gy);
+          u[r] = *reinterpret_cast<const f32x4*>(yb + (long)min(h0 + 4 * half + r, H - 1) * p.yv.sH + gy);
+        const int gwe = eside ? w0 + WT_W : w0 - 1;
+        if (half == 0)
+          e = *reinterpret_cast<const f32x4*>(xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH +
+                                              min(max(gwe, 0), W - 1) * (int)p.xv.sW + ec4 * 4);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const int gh = h0 - 1 + 5 * half + r;
+          *reinterpret_cast<f32x4*>(ldx + (5 * half + r) * (WH_W * WSTR) + lx) = sisr_keep_if(v[r], gh >= 0 && gh < H && okc);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const f32x4 t = sisr_keep_if(u[r] * s4 + t4, oky && (h0 + r0 + r < H));
-          *reinterpret_cast<f32x4*>(ldy + (r0 + r) * (WT_W * WSTR) + ly) = t;
+          const f32x4 t = sisr_keep_if(u[r] * s4 + t4, okc && (h0 + 4 * half + r < H));
+          *reinterpret_cast<f32x4*>(ldy + (4 * half + r) * (WT_W * WSTR) + ly) = t;
           bsum += t;
+        }
+        if (half == 0) {
+          const int ghe = h0 - 1 + er;
+          e = sisr_keep_if(e, ghe >= 0 && ghe < H && gwe >= 0 && gwe < W);
+          if (tl < 160) *reinterpret_cast<f32x4*>(ldx + er * (WH_W * WSTR) + (eside ? WH_W - 1 : 0) * WSTR + ec4 * 4) = e;
         }
       }
     }

@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_int64, c_long, c_size_t, c_void_p
 import torch  # noqa: F401  (must be imported first: libsisr_hip.so binds to torch's libamdhip64.so.7 by SONAME)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsisr_hip.so")
+LIB_PATH = os.environ.get("SISR_HIP_LIB") or os.path.join(_HERE, "libsisr_hip.so")  # override: A/B of two builds
 _lib = None
 
 P = c_void_p
