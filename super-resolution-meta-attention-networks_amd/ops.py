@@ -29,6 +29,7 @@ CL = torch.channels_last
 # (dgrad2 -> dgrad1 -> previous block), so they are issued on a second HIP stream: the ramp-up and tail of
 # each ~170 us MFMA launch is then filled by workgroups of the other queue.  The main stream re-joins the side
 # stream once, at the end of the backward pass (autograd engine callback), before anything reads the grads.
+# (Measured +5 % at 16 tiles per GPU when introduced; neutral at 32 with the current kernels -- see DESIGN.md §3.)
 WGRAD_SIDE_STREAM = os.environ.get("SISR_WGRAD_SIDE_STREAM", "1") != "0"
 IN_BACKWARD = False  # set while a conv operator's backward runs (bench.py times forward launches only)
 _side_streams = {}
