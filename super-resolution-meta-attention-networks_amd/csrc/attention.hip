@@ -18,23 +18,32 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 __device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
 
-// Sum `parts` rows of 64 floats with the whole 256-thread block: wave w takes rows w, w+4, ... (8 loads
-// in flight), then the four per-wave sums are added in wave order.  Result valid in wave 0 (all lanes).
+// Sum `parts` rows of 64 floats with the whole 256-thread block: thread (c4 = t & 15, group = t >> 4) adds rows
+// group, group + 16, ... of its float4 column, up to sixteen 16-byte loads in flight at once (the kernels that call
+// this sit on the serial chain between two convs and are pure latency: 256 rows used to be eight dependent load
+// rounds); the sixteen group sums are then added in group order.  Result valid in threads 0..63 (channel = t).
+// `red` must hold 16 * 64 floats.
 __device__ __forceinline__ float block_sum_parts(const float* __restrict__ pp, int parts, float* red) {
-  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float s = 0.f;
-  int k = w;
-  for (; k + 28 < parts; k += 32) {
-    float t[8];
+  const int c4 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = grp;
+  for (; k + 15 * 16 < parts; k += 16 * 16) {
+    f32x4 t[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = pp[(long)(k + 4 * u) * 64 + c];
+    for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const f32x4*>(pp + (long)(k + 16 * u) * 64 + c4 * 4);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += t[u];
+    for (int u = 0; u < 16; ++u) s += t[u];
   }
-  for (; k < parts; k += 4) s += pp[(long)k * 64 + c];
-  red[w * 64 + c] = s;
+  for (; k < parts; k += 16) s += *reinterpret_cast<const f32x4*>(pp + (long)k * 64 + c4 * 4);
+  *reinterpret_cast<f32x4*>(red + grp * 64 + c4 * 4) = s;
   __syncthreads();
-  return ((red[c] + red[64 + c]) + red[128 + c]) + red[192 + c];
+  float r = 0.f;
+  if (threadIdx.x < 64) {
+    r = red[threadIdx.x];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) r += red[g * 64 + threadIdx.x];
+  }
+  return r;
 }
 
 // ---------------------------------------------------------------- CA gate forward (C = 64, one block per sample)
@@ -45,7 +54,7 @@ __global__ __launch_bounds__(256) void ca_gate_fwd_kernel(const float* __restric
                                                           int R, const float* __restrict__ mul, float* __restrict__ s_out,
                                                           float* __restrict__ hid_out, float* __restrict__ ca_out,
                                                           float* __restrict__ g_out) {
-  __shared__ float red[256];
+  __shared__ __attribute__((aligned(16))) float red[16 * 64];
   const int b = blockIdx.x, c = threadIdx.x & 63;
   float s = block_sum_parts(part + (long)b * parts * 64, parts, red);
   if (threadIdx.x >= 64) return;
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(256) void ca_gate_bwd_kernel(const float* __restric
                                                           float* __restrict__ dw1, float* __restrict__ db1,
                                                           float* __restrict__ dw2, float* __restrict__ db2,
                                                           unsigned* counter, int B) {
-  __shared__ float red[256];
+  __shared__ __attribute__((aligned(16))) float red[16 * 64];
   __shared__ int is_last;
   const int b = blockIdx.x, c = threadIdx.x & 63;
   const float dg = block_sum_parts(dgpart + (long)b * parts * 64, parts, red);
@@ -239,9 +248,13 @@ __global__ __launch_bounds__(256) void gate_residual_fwd_kernel(const float* __r
     const int c4 = (int)(i - pix * c4n);
     const long b = pix / hw;
     f32x4 v = reinterpret_cast<const f32x4*>(t)[i];
-    if (g) v = v * *reinterpret_cast<const f32x4*>(g + b * C + c4 * 4);
-    if (shift) v = v + *reinterpret_cast<const f32x4*>(shift + b * C + c4 * 4);
-    if (x) v = v + reinterpret_cast<const f32x4*>(x)[i];
+    if (g && x && !shift) {  // the gated skip: one fused multiply-add, as the conv kernels' GATE prologue forms it
+      v = sisr_fma4(v, *reinterpret_cast<const f32x4*>(g + b * C + c4 * 4), reinterpret_cast<const f32x4*>(x)[i]);
+    } else {
+      if (g) v = v * *reinterpret_cast<const f32x4*>(g + b * C + c4 * 4);
+      if (shift) v = v + *reinterpret_cast<const f32x4*>(shift + b * C + c4 * 4);
+      if (x) v = v + reinterpret_cast<const f32x4*>(x)[i];
+    }
     reinterpret_cast<f32x4*>(y)[i] = v;
   }
 }

@@ -31,6 +31,14 @@ __device__ __forceinline__ f32x4 sisr_keep_if(f32x4 t, bool ok) {
   return __builtin_bit_cast(f32x4, b);
 }
 
+// a * b + c with ONE rounding per component, spelled out: the gated skip t * g + x is formed by the stand-alone gate
+// kernel and by the GATE prologues of the conv kernels, and the two must agree to the bit (the ReLU masks of the next
+// block are taken from it; a one-ulp difference flips a mask element now and then, which moves gradients by 1e-3).
+__device__ __forceinline__ f32x4 sisr_fma4(f32x4 a, f32x4 b, f32x4 c) {
+  return (f32x4){__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1]), __builtin_fmaf(a[2], b[2], c[2]),
+                 __builtin_fmaf(a[3], b[3], c[3])};
+}
+
 #define SISR_OK 0
 #define SISR_ERR_ARG (-1)
 #define SISR_ERR_ALIGN (-2)

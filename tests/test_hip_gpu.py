@@ -145,9 +145,12 @@ def test_fused_group_node_matches_per_block_nodes(meta):
             res[fused] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
     finally:
         ops.FUSED_GROUPS = True
-    close(res[True][0], res[False][0], 1e-5, 1e-6, "group output")
+    # the gated skip is formed by one explicit fma in both paths, so the forward pass -- and with it every ReLU mask --
+    # is bit-identical; the gradients then differ only by how the gate sums are partitioned
+    assert torch.equal(res[True][0], res[False][0])
     for k in res[True][1]:
-        close(res[True][1][k], res[False][1][k], 2e-4, 2e-5, k)
+        a, b = res[True][1][k].double(), res[False][1][k].double()
+        assert float((a - b).norm()) <= 2e-5 * float(b.norm()) + 1e-7, (k, float((a - b).norm()), float(b.norm()))
 
 
 def test_conv_residual_alpha_and_multichunk():
