@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256) void gate_residual_fwd_kernel(const float* __r
     const int c4 = (int)(i - pix * c4n);
     const long b = pix / hw;
     f32x4 v = reinterpret_cast<const f32x4*>(t)[i];
-    if (g && x && !shift) {  // the gated skip: one fused multiply-add, as the conv kernels' GATE prologue forms it
-      v = sisr_fma4(v, *reinterpret_cast<const f32x4*>(g + b * C + c4 * 4), reinterpret_cast<const f32x4*>(x)[i]);
+    if (g && x && !shift) {  // the gated skip: product rounded, then the sum -- as the conv kernels' GATE prologue forms it
+      v = sisr_mul_add4(v, *reinterpret_cast<const f32x4*>(g + b * C + c4 * 4), reinterpret_cast<const f32x4*>(x)[i]);
     } else {
       if (g) v = v * *reinterpret_cast<const f32x4*>(g + b * C + c4 * 4);
       if (shift) v = v + *reinterpret_cast<const f32x4*>(shift + b * C + c4 * 4);

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
 #pragma unroll
             for (int k = 0; k < 3; ++k)
               if (k < 2 || pcol < 2) {
-                const f32x4 t = sisr_fma4(v[r][k], g4, u[r][k]);
+                const f32x4 t = sisr_mul_add4(v[r][k], g4, u[r][k]);
                 *reinterpret_cast<f32x4*>(lds + hr * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
                 const int col = pcol + 16 * k;
                 if (rown && cok[k] && col >= 1 && col <= TW) *reinterpret_cast<f32x4*>(p.gate_out + ro + goff[k]) = t;
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) 
 #pragma unroll
             for (int k = 0; k < 2; ++k)
               if (k == 0 || pcol < 2) {
-                const f32x4 ta = sisr_fma4(v[r][k][0], g4a, u[r][k][0]), tb = sisr_fma4(v[r][k][1], g4b, u[r][k][1]);
+                const f32x4 ta = sisr_mul_add4(v[r][k][0], g4a, u[r][k][0]), tb = sisr_mul_add4(v[r][k][1], g4b, u[r][k][1]);
                 const int col = pcol + 32 * k;
                 if (rown && cok[k] && col >= 1 && col <= TW) {
                   *reinterpret_cast<f32x4*>(p.gate_out + ro + goff[k]) = ta;
@@ -841,8 +841,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
         tb = tb * s4b + t4b;
       }
       if (GATE) {
-        ta = sisr_fma4(ta, s4a, u.in[r][0]);
-        tb = sisr_fma4(tb, s4b, u.in[r][1]);
+        ta = sisr_mul_add4(ta, s4a, u.in[r][0]);
+        tb = sisr_mul_add4(tb, s4b, u.in[r][1]);
         if (r >= 1 && r <= TH && gh < H && cok) {  // interior columns are exactly the pixels this tile owns
           float* o = p.gate_out + (long)b * p.xv.sB + (long)gh * p.xv.sH + (long)gw * p.xv.sW + c8 * 8;
           *reinterpret_cast<f32x4*>(o) = ta;
@@ -862,8 +862,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
         tb = tb * e4b + f4b;
       }
       if (GATE) {
-        ta = sisr_fma4(ta, e4a, u.ed[0]);
-        tb = sisr_fma4(tb, e4b, u.ed[1]);
+        ta = sisr_mul_add4(ta, e4a, u.ed[0]);
+        tb = sisr_mul_add4(tb, e4b, u.ed[1]);
       }
       u32x4 pk = sisr_pack_bf16x8(ta, tb);
       const unsigned m = (ghe >= 0 && ghe < H && gwe >= 0 && gwe < W) ? 0xffffffffu : 0u;

@@ -31,12 +31,15 @@ __device__ __forceinline__ f32x4 sisr_keep_if(f32x4 t, bool ok) {
   return __builtin_bit_cast(f32x4, b);
 }
 
-// a * b + c with ONE rounding per component, spelled out: the gated skip t * g + x is formed by the stand-alone gate
-// kernel and by the GATE prologues of the conv kernels, and the two must agree to the bit (the ReLU masks of the next
-// block are taken from it; a one-ulp difference flips a mask element now and then, which moves gradients by 1e-3).
-__device__ __forceinline__ f32x4 sisr_fma4(f32x4 a, f32x4 b, f32x4 c) {
-  return (f32x4){__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1]), __builtin_fmaf(a[2], b[2], c[2]),
-                 __builtin_fmaf(a[3], b[3], c[3])};
+// The gated skip t * g + x, with the product rounded BEFORE the sum (no fma contraction) -- the arithmetic of the
+// reference's `x * y` followed by `res += x` on fp32 tensors.  It is formed by the stand-alone gate kernel and by the
+// GATE prologues of the conv kernels, and all of them must agree to the bit, with each other and with the reference:
+// the next block's ReLU mask is taken from this map, an element of it that differs by one ulp flips a mask bit now
+// and then, and one flipped bit moves that block's weight gradient by ~3e-3 (found with a float64 run of the oracle).
+__device__ __forceinline__ f32x4 sisr_mul_add4(f32x4 a, f32x4 b, f32x4 c) {
+#pragma clang fp contract(off)
+  const f32x4 p = a * b;
+  return p + c;
 }
 
 #define SISR_OK 0

@@ -145,8 +145,8 @@ def test_fused_group_node_matches_per_block_nodes(meta):
             res[fused] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
     finally:
         ops.FUSED_GROUPS = True
-    # the gated skip is formed by one explicit fma in both paths, so the forward pass -- and with it every ReLU mask --
-    # is bit-identical; the gradients then differ only by how the gate sums are partitioned
+    # the gated skip is formed with the same two roundings (product, then sum) in both paths, so the forward pass -- and
+    # with it every ReLU mask -- is bit-identical; the gradients then differ only by how the gate sums are partitioned
     assert torch.equal(res[True][0], res[False][0])
     for k in res[True][1]:
         a, b = res[True][1][k].double(), res[False][1][k].double()
@@ -352,6 +352,35 @@ def test_edsr_paper_width_vs_oracle():
     torch.manual_seed(8)
     net = A.EDSR(net_features=256, num_blocks=2, scale=4, res_scale=0.1)
     net_vs_oracle(net, "edsr", dict(num_blocks=2, scale=4, res_scale=0.1), rnd(1, 3, 18, 35, seed=37, scale=0.5))
+
+
+@pytest.mark.parametrize("kind", ["rcan", "qrcan"])
+def test_reduced_net_gradients_against_float64_oracle(kind):
+    """Tighter than the elementwise fp32 comparisons above: every parameter gradient of a reduced net within 2e-5 of a
+    FLOAT64 evaluation of the oracle, by norm.  (Deterministic kernels and fixed seeds: no ReLU-mask element sits
+    within fp32 noise of zero for these inputs; a single flipped element would show as ~3e-3.)"""
+    torch.manual_seed(8)
+    if kind == "qrcan":
+        net = A.QRCAN(n_resblocks=3, n_resgroups=2, n_feats=64, scale=2, style="standard", num_metadata=10,
+                      include_q_layer=True, num_q_layers_inner_residual=2)
+        cfg = dict(n_resgroups=2, n_resblocks=3, scale=2, style="standard", include_q_layer=True,
+                   num_q_layers_inner_residual=2)
+    else:
+        net = A.RCAN(n_resblocks=3, n_resgroups=2, n_feats=64, scale=2)
+        cfg = dict(n_resgroups=2, n_resblocks=3, scale=2)
+    x, md = rnd(2, 3, 21, 30, seed=70, scale=0.5), rnd(2, 10, 1, 1, seed=71, scale=0.3)
+    sd = {k: v.detach().double().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    ref = O.forward(kind, sd, x.double(), md.double() if kind == "qrcan" else None, **cfg)
+    cot = rnd(*ref.shape, seed=72)
+    ref.backward(cot.double())
+    net.to(DEV)
+    out = net(x.to(DEV), md.to(DEV)) if kind == "qrcan" else net(x.to(DEV))
+    out.backward(cot.to(DEV))
+    assert float((out.detach().double().cpu() - ref.detach()).norm()) < 2e-6 * float(ref.detach().norm())
+    for k, p in net.named_parameters():
+        want = sd[k].grad
+        err = float((p.grad.double().cpu() - want).norm())
+        assert err <= 2e-5 * float(want.norm()) + 1e-9, (k, err, float(want.norm()))
 
 
 def test_qrcan_reduced_vs_oracle():
