@@ -617,6 +617,42 @@ def test_set5_training_psnr_parity_at_equal_steps():
     assert max(abs(d) for d in diffs) < 0.02, diffs
 
 
+def test_set5_training_psnr_parity_meta_rcan():
+    """The same for north_star's target family -- RCAN + meta-attention (QRCAN, style 'standard', q-layers on, reduced
+    to 2 groups x 3 blocks so that the CPU oracle keeps up): 20 Adam steps through the group-level fused node with the
+    blur-kernel metadata of the Set5 example data, then Set5 Y-PSNR within 0.02 dB."""
+    import random
+    torch.manual_seed(8)
+    kw = dict(metadata=["blur_kernel"], style="standard", include_q_layer=True, n_resgroups=2, n_resblocks=3)
+    h = sisr_amd.handlers.available_models["qrcan"](device=0, model_save_dir="/tmp", eval_mode=False, scale=4, lr=1e-4, **kw)
+    cfg = dict(n_resgroups=2, n_resblocks=3, scale=4, style="standard", include_q_layer=True)
+    tr = O.Trainer("qrcan", {k: v.detach().cpu() for k, v in h.net.state_dict().items()}, lr=1e-4, **cfg)
+    data = [(x[0], y[0], md[0]) for _, x, y, md in set5()]
+    rng = random.Random(4)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    keys = [("blur_kernel",) * 4] * 10
+    for step in range(20):
+        xs, ys, ms = [], [], []
+        for _ in range(4):
+            x, y, m = data[rng.randrange(5)]
+            i, j = rng.randrange(x.shape[1] - 31), rng.randrange(x.shape[2] - 31)
+            xs.append(x[:, i:i + 32, j:j + 32])
+            ys.append(y[:, 4 * i:4 * i + 128, 4 * j:4 * j + 128])
+            ms.append(m)
+        xb, yb, mb = torch.stack(xs), torch.stack(ys), torch.stack(ms)
+        loss_hip, _ = h.run_train(xb, yb, metadata=mb, metadata_keys=keys)
+        loss_ref, _, _ = tr.step(xb, yb, mb.float().view(4, 10, 1, 1))
+        assert abs(float(loss_hip) - loss_ref) < 2e-3, (step, float(loss_hip), loss_ref)
+    diffs = []
+    with torch.no_grad():
+        for x, y, m in data:
+            out, _, _ = h.run_eval(x[None], metadata=m[None], metadata_keys=[("blur_kernel",)] * 10)
+            ref = O.qrcan(tr.sd, x[None], m.float().view(1, 10, 1, 1), 2, 3, 4, "standard", False, True)
+            diffs.append(sisr_amd.metrics.y_psnr(out[0].numpy(), y.numpy()) - O.y_psnr(ref[0].numpy(), y.numpy()))
+    print("Set5 Y-PSNR (HIP - oracle), meta-RCAN after 20 steps:", diffs)
+    assert max(abs(d) for d in diffs) < 0.02, diffs
+
+
 # ----------------------------------------------------------------------------- size-independent properties, edge cases
 def test_adjoint_identities_at_bench_size():
     """<conv(x), dy> = <x, dgrad(dy)> = <w, wgrad(x, dy)> + <b, sum dy> on a full 8x64x128x128 map: the three
