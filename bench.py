@@ -7,14 +7,24 @@
 
 A step is BaseModel.train_step on the full-depth network: forward + L1 + backward + Adam + scheduler step
 (the reference's run_train, Code/SISR/models/__init__.py:466-489, minus its per-step D2H copies), on
-synthetic inputs already resident in HBM (SURVEY.md §8d).  Per-GPU batch is fixed, so scaling is weak;
-value = all patches of all ranks / max-over-ranks wall time of exactly K steps.
+synthetic inputs already resident in HBM.  value = all patches of all ranks / max-over-ranks wall
+time of exactly K steps.
+
+Default workloads (BASELINE.json configs):
+  N = 1   configs[1]: RCAN x4, 32 tiles on the GPU.  The line also carries "meta_rcan": the same measurement for
+          RCAN + meta-attention (QRCAN, north_star's target family), taken right after the timed region.
+  N > 1   configs[3]: Meta-RCAN (QRCAN) data-parallel, GLOBAL batch 32 -> 32/N tiles per GPU, gradients all-reduced
+          over RCCL ("scaling": "strong"); per-GPU batches <= 8 replay forward+backward from a hipGraph.  The line also
+          carries "weak_scaling": QRCAN at 32 tiles PER GPU (global batch 32 N), measured after the timed region.
+  --batch B (tiles per GPU, weak scaling) or --global-batch G (strong scaling) override either default.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (conv3x3_c64_kernel, 64->64 body shape): algorithmic FLOPs per launch
-                divided by its mean launch duration, measured with HIP events around every launch of that
-                shape in the forward pass of the last timed step (backward convs overlap the side-stream weight
-                gradients, so only forward launches run alone), against the 157.3 TFLOP/s fp32 matrix/vector peak.
+  roofline      bound "mfma" (fp32 path; SURVEY.md 8d: the step is bound by the fp32 matrix rate, not HBM).  Primary
+                achieved / frac = the WHOLE STEP's algorithmic TFLOP/s per GPU against the 157.3 TFLOP/s fp32 MFMA peak.
+                "families": each 64->64 conv kernel family of the step (forward plain, forward GATE, dgrad with ReLU mask,
+                dgrad with DOT epilogue, weight gradient + slab reduce) timed ALONE with HIP events on its launch stream
+                in one extra, untimed step with the weight-gradient side stream off: algorithmic FLOPs per launch /
+                mean launch duration.  "kernel" names the family with the largest share of the step.
   cpu_baseline  rank 0, N=1 only: the CPU oracle (a restatement of the reference proven equal to it by the
                 golden vectors) doing the same step at batch 1 on the host cores -- a bounded sample.
 """
@@ -33,10 +43,10 @@ import torch.distributed as dist  # noqa: E402
 CONV_BODY_FLOP_PER_PIXEL = 2 * 64 * 64 * 9
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
 HBM_PEAK_GBS = 8000.0          # same guide: HBM3E ~8 TB/s
-# algorithmic HBM bytes per LR patch, fwd + bwd, fp32 maps, layer at a time with the legal fusions (SURVEY.md §8d)
+# algorithmic HBM bytes per LR patch, fwd + bwd, fp32 maps, layer at a time with the legal fusions (SURVEY.md 8d)
 HBM_GB_PER_PATCH = {"rcan": 16.5, "qrcan": 16.5, "edsr": 1.4, "qedsr": 1.4}
 WORKLOADS = {
-    # name: (registry name, handler kwargs, fwd+bwd algorithmic TFLOP per LR patch (SURVEY.md §8d))
+    # name: (registry name, handler kwargs, fwd+bwd algorithmic TFLOP per LR patch (SURVEY.md 8d))
     "rcan": ("rcan", {}, 1.565),
     "qrcan": ("qrcan", {"metadata": ["blur_kernel"], "style": "standard", "include_q_layer": True}, 1.565),
     "edsr": ("edsr", {}, 0.195),
@@ -48,38 +58,65 @@ WORKLOADS = {
     "san": ("san", {}, 1.598),
     "qsan": ("qsan", {"metadata": ["blur_kernel"]}, 1.598),
 }
+GRAPH_MAX_BATCH = 8  # --graph auto: per-GPU batches up to this replay forward+backward from a hipGraph
 
 
-class ConvTimer:
-    """HIP-event timing of every 64->64 body conv launch (recorded on the launch stream)."""
+class KernelTimer:
+    """HIP-event timing of every body-shape (width -> width, 3x3) launch, per kernel family.  Events are recorded on
+    the stream the kernel is launched on; used for ONE extra step with the weight-gradient side stream off, so every
+    kernel runs alone."""
 
     def __init__(self, ops, width=64):
-        self.ops, self.orig, self.events, self.on, self.width = ops, ops.conv_c64, [], False, width
+        self.ops, self.width, self.on = ops, width, False
+        self.orig_conv, self.orig_wgrad = ops.conv_c64, ops.wgrad_c64
+        self.events = {}
+
+    def _timed(self, family, pixels, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.events.setdefault(family, []).append((e0, e1, pixels))
 
     def install(self):
-        def timed(x, xview, packed, bias, bnq, y, yview, B, H, W, cin, cout, **kw):
-            # forward launches only: in backward the data-gradient convs share the GPU with the
-            # weight-gradient kernels of the side stream, so their individual durations say nothing about the kernel
-            # ... and only the plain instantiation: launches that also build the gated skip in their staging
-            # (GATE) do a second pass's work that the algorithmic FLOP count does not credit
-            if (self.on and cin == self.width and cout == self.width and not self.ops.IN_BACKWARD
-                    and kw.get("gate_add") is None):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                self.orig(x, xview, packed, bias, bnq, y, yview, B, H, W, cin, cout, **kw)
-                e1.record()
-                self.events.append((e0, e1, B * H * W))
+        def conv(x, xview, packed, bias, bnq, y, yview, B, H, W, cin, cout, **kw):
+            call = lambda: self.orig_conv(x, xview, packed, bias, bnq, y, yview, B, H, W, cin, cout, **kw)  # noqa: E731
+            if not (self.on and cin == self.width and cout == self.width):
+                return call()
+            if kw.get("gate_add") is not None:
+                fam = "conv fwd, GATE prologue (builds and stores the gated skip while staging)"
+            elif kw.get("dot") is not None:
+                fam = "dgrad + residual, DOT epilogue (gate-gradient partial sums)"
+            elif kw.get("mask") is not None:
+                fam = "dgrad, ReLU mask (+ per-(b,c) affine prologue)"
+            elif self.ops.IN_BACKWARD:
+                fam = "dgrad, plain / residual"
             else:
-                self.orig(x, xview, packed, bias, bnq, y, yview, B, H, W, cin, cout, **kw)
-        self.ops.conv_c64 = timed
+                fam = "conv fwd, plain (bias / ReLU / GAP partials / residual epilogue)"
+            self._timed(fam, B * H * W, call)
 
-    def summary(self):
-        if not self.events:
-            return None
-        ms = [a.elapsed_time(b) for a, b, _ in self.events]
-        flop = [p * CONV_BODY_FLOP_PER_PIXEL * (self.width // 64) ** 2 for _, _, p in self.events]
-        return {"launches": len(ms), "avg_us": 1e3 * sum(ms) / len(ms), "tflops": sum(flop) / (sum(ms) * 1e-3) / 1e12,
-                "flop_per_launch": sum(flop) / len(flop)}
+        def wgrad(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, **kw):
+            call = lambda: self.orig_wgrad(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, **kw)  # noqa: E731
+            if not (self.on and cin == self.width and cout == self.width):
+                return call()
+            self._timed("wgrad + slab reduce", B * H * W, call)
+
+        self.ops.conv_c64, self.ops.wgrad_c64 = conv, wgrad
+
+    def remove(self):
+        self.ops.conv_c64, self.ops.wgrad_c64 = self.orig_conv, self.orig_wgrad
+
+    def summary(self, peak_tflops):
+        out = []
+        for fam, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            flop = [p * CONV_BODY_FLOP_PER_PIXEL * (self.width // 64) ** 2 for _, _, p in evs]
+            tf = sum(flop) / (sum(ms) * 1e-3) / 1e12
+            out.append({"family": fam, "launches_per_step": len(ms), "avg_launch_us": 1e3 * sum(ms) / len(ms),
+                        "flop_per_launch": sum(flop) / len(flop), "achieved": tf, "frac": tf / peak_tflops,
+                        "ms_per_step": sum(ms)})
+        out.sort(key=lambda d: -d["ms_per_step"])
+        return out
 
 
 def cpu_baseline(workload, seconds_budget=30.0):
@@ -110,9 +147,75 @@ def cpu_baseline(workload, seconds_budget=30.0):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": 1.0 / med, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{name} x4 full depth, batch 1, 128x128 LR tile, fwd+L1+bwd+Adam, median of {len(times)} "
-                      f"timed steps after 1 warm-up (oracle/sisr_oracle.py on torch CPU kernels)"}
+    ref = {"rcan": 0.265, "qrcan": 0.266, "edsr": 1.75, "qedsr": 2.44, "han": 0.296, "qhan": 0.246}.get(workload)
+    out = {"value": 1.0 / med, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{name} x4 full depth, batch 1, 128x128 LR tile, fwd+L1+bwd+Adam, median of {len(times)} "
+                     f"timed steps after 1 warm-up (oracle/sisr_oracle.py on torch CPU kernels)"}
+    if ref is not None:  # the reference itself, same step, in the build container
+        out["reference_anchor"] = {"value": ref, "unit": "patches/s", "cores": 8, "kind": "reference",
+                                   "where": "build container (8 vCPU Xeon 2.1 GHz), the reference's own run_train; "
+                                            "it cannot travel to the GPU box"}
+    return out
+
+
+def measure(sisr, workload, B, steps, warmup, use_graph, rank, world, local, dev, families=False):
+    """Build the handler, run warm-up + exactly `steps` timed steps (barrier + sync on both sides, max over ranks)."""
+    name, params, tflop_per_patch = WORKLOADS[workload]
+    if name not in sisr.available_models:
+        raise SystemExit(f"workload {name} is not built yet")
+    torch.manual_seed(8)
+    h = sisr.available_models[name](device=local, model_save_dir="/tmp", eval_mode=False, scale=4, lr=1e-4,
+                                    scheduler="cosine_annealing_warm_restarts",
+                                    scheduler_params={"t_mult": 1, "restart_period": 125000, "lr_min": 1e-7}, **params)
+    if world > 1:
+        h.set_multi_gpu()
+    h.use_graph = use_graph
+    g = torch.Generator().manual_seed(8 + rank)
+    x = torch.rand(B, 3, 128, 128, generator=g).to(dev)
+    y = torch.rand(B, 3, 512, 512, generator=g).to(dev)
+    kw = {}
+    if "metadata" in params:
+        kw["extra_channels"] = (torch.rand(B, 10, 1, 1, generator=g) * 0.4).to(dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        h.train_step(x, y, **kw)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = h.train_step(x, y, **kw)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    res = {"value": world * B * steps / dt, "ms_per_step": 1e3 * dt / steps, "loss": float(loss.item()),
+           "tflop_per_patch": tflop_per_patch, "width": params.get("num_features", 64), "name": name, "params": params}
+    if families:  # one extra, untimed, eager step with every kernel alone on the stream
+        timer = KernelTimer(sisr.ops, width=res["width"])
+        timer.install()
+        side, sisr.ops.WGRAD_SIDE_STREAM = sisr.ops.WGRAD_SIDE_STREAM, False
+        h.use_graph = False
+        try:
+            timer.on = True
+            h.train_step(x, y, **kw)
+            timer.on = False
+            torch.cuda.synchronize()
+        finally:
+            sisr.ops.WGRAD_SIDE_STREAM = side
+            timer.remove()
+        res["timer"] = timer
+    if h.reducer is not None:
+        h.reducer.remove()
+    del h, x, y, kw
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -120,11 +223,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="LR patches per GPU per step")
-    ap.add_argument("--workload", default="rcan", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="LR patches per GPU per step (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="LR patches per step over ALL GPUs (strong scaling); default 32 when N > 1 (BASELINE config 4)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: rcan at N = 1, qrcan at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay forward+backward as a hipGraph (small batches)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the meta_rcan / weak_scaling side measurement")
+    ap.add_argument("--graph", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                    help=f"replay forward+backward as a hipGraph (auto: per-GPU batch <= {GRAPH_MAX_BATCH})")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="arithmetic of the 64-channel convs: fp32 MFMA (reference arithmetic, the headline) or bf16 "
                          "MFMA operands with fp32 accumulate / storage (BASELINE config 'HAN x4 bf16')")
@@ -141,110 +248,83 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    name, params, tflop_per_patch = WORKLOADS[args.workload]
-    if name not in sisr.available_models:
-        raise SystemExit(f"workload {name} is not built yet")
 
-    torch.manual_seed(8)
-    h = sisr.available_models[name](device=local, model_save_dir="/tmp", eval_mode=False, scale=4, lr=1e-4,
-                                    scheduler="cosine_annealing_warm_restarts",
-                                    scheduler_params={"t_mult": 1, "restart_period": 125000, "lr_min": 1e-7}, **params)
-    if world > 1:
-        h.set_multi_gpu()
-    if args.graph:
-        h.use_graph = True
-        args.no_kernel_timing = True
-        if h.reducer is not None:
-            h.reducer.remove()
-            h.reducer.overlap = False
-    B = args.batch
-    g = torch.Generator().manual_seed(8 + rank)
-    x = torch.rand(B, 3, 128, 128, generator=g).to(dev)
-    y = torch.rand(B, 3, 512, 512, generator=g).to(dev)
-    kw = {}
-    if "metadata" in params:
-        kw["extra_channels"] = (torch.rand(B, 10, 1, 1, generator=g) * 0.4).to(dev)
+    explicit = args.workload is not None or args.batch is not None or args.global_batch is not None
+    workload = args.workload or ("rcan" if world == 1 else "qrcan")
+    if args.batch is not None and args.global_batch is not None:
+        raise SystemExit("--batch (per GPU) and --global-batch are exclusive")
+    if args.batch is not None:
+        B, scaling = args.batch, "weak"
+    else:
+        G = args.global_batch if args.global_batch is not None else 32
+        if G % world:
+            raise SystemExit(f"global batch {G} is not divisible by {world} GPUs")
+        B = G // world
+        scaling = "weak" if (world == 1 and args.global_batch is None) else "strong"
+    use_graph = args.graph == "on" or (args.graph == "auto" and B <= GRAPH_MAX_BATCH)
 
-    timer = ConvTimer(sisr.ops, width=params.get("num_features", 64))
-    if not args.no_kernel_timing:
-        timer.install()
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        h.train_step(x, y, **kw)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        timer.on = (i == args.steps - 1)
-        loss, _ = h.train_step(x, y, **kw)
-    timer.on = False
-    sync()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    loss_val = float(loss.item())
+    main_res = measure(sisr, workload, B, args.steps, args.warmup, use_graph, rank, world, local, dev,
+                       families=not args.no_kernel_timing and args.precision == "fp32")
+    secondary = None
+    if not explicit and not args.no_secondary and args.precision == "fp32":
+        # N = 1: the north_star family beside BASELINE's configs[1]; N > 1: the weak-scaling point beside config 4
+        ssteps = max(2, min(args.steps, 5))
+        s = measure(sisr, "qrcan", 32, ssteps, min(args.warmup, 2), False, rank, world, local, dev)
+        secondary = ("meta_rcan" if world == 1 else "weak_scaling", {
+            "workload": "QRCAN (RCAN + meta-attention, style 'standard', q-layers on) x4 full depth, same train step",
+            "value": s["value"], "unit": "patches/s", "ms_per_step": s["ms_per_step"], "steps": ssteps,
+            "per_gpu_batch": 32, "global_batch": 32 * world, "n_gpus": world,
+            "algorithmic_tflops_per_gpu": s["value"] / world * s["tflop_per_patch"],
+            "frac_of_fp32_mfma_peak": s["value"] / world * s["tflop_per_patch"] / FP32_MFMA_PEAK_TFLOPS})
 
     if rank == 0:
+        name, params, value = main_res["name"], main_res["params"], main_res["value"]
+        tflop_per_patch = main_res["tflop_per_patch"]
         label = name.upper() + (f" ({params['num_features']} features, {params['num_blocks']} blocks)"
                                 if "num_features" in params else "")
-        value = world * B * args.steps / dt
         line = {
             "metric": "LR-patches/sec (128x128x3, x4) fwd+bwd", "value": value, "unit": "patches/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands, f32 accumulate and storage",
             "data": "synthetic",
             "config": {"workload": f"{label} x4 full depth, 128x128 LR -> 512x512 tiles, train step = "
                                    f"fwd + L1 + bwd + Adam + scheduler", "per_gpu_batch": B, "global_batch": B * world,
-                       "parallelism": f"dp{world}", "hip_graph": bool(args.graph), "final_loss": loss_val,
+                       "parallelism": f"dp{world}", "hip_graph": bool(use_graph), "final_loss": main_res["loss"],
                        "algorithmic_tflops": value * tflop_per_patch},
         }
-        ks = timer.summary()
-        if ks and args.precision == "bf16":
-            # the bf16 conv is HBM-bound: one fp32 map in, one out (weights / bias are L2-resident)
-            nbytes = 2 * (ks["flop_per_launch"] / (CONV_BODY_FLOP_PER_PIXEL * (timer.width // 64) ** 2)) * timer.width * 4
-            gbs = nbytes / (ks["avg_us"] * 1e-6) / 1e9
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", "traffic_conv3x3_c64_bf16.json")
-            if os.path.exists(tj) and timer.width == 64:
-                with open(tj) as f:
-                    traffic = json.load(f).get(str(B))
-            line["roofline"] = {"bound": "hbm", "kernel": "conv3x3_c64_bf16_kernel (64->64 body conv, forward launches)",
-                                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                "traffic": traffic, "avg_launch_us": ks["avg_us"], "launches_timed": ks["launches"],
-                                "bytes_per_launch": nbytes, "mfma_tflops": ks["tflops"]}
-        elif ks:
-            traffic = None
+        step_tf = value / world * tflop_per_patch
+        if args.precision == "fp32":
+            fams = main_res["timer"].summary(FP32_MFMA_PEAK_TFLOPS) if "timer" in main_res else []
+            traffic, tsrc = None, None
             tj = os.path.join(ROOT, "profiles", "traffic_conv3x3_c64.json")
-            if os.path.exists(tj):
+            if os.path.exists(tj) and main_res["width"] == 64:
                 with open(tj) as f:
-                    traffic = json.load(f).get(str(B))
-            line["roofline"] = {"bound": "mfma",
-                                "kernel": f"conv3x3_c64_v4_kernel<0,0,0,2,0,0> ({timer.width}->{timer.width} body conv, "
-                                          f"forward launches without fused prologue)",
-                                "achieved": ks["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ks["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                                "avg_launch_us": ks["avg_us"], "launches_timed": ks["launches"],
-                                "flop_per_launch": ks["flop_per_launch"]}
-        if "roofline" in line and args.workload in HBM_GB_PER_PATCH:
-            # the other roof, for reference (SURVEY.md §8d asks for both): whole-step algorithmic HBM rate
-            gbs = value / world * HBM_GB_PER_PATCH[args.workload]
-            line["roofline"]["secondary"] = {"bound": "mfma" if args.precision == "bf16" else "hbm",
-                                             "what": "whole step, algorithmic bytes per patch x patches/s per GPU",
-                                             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": gbs / HBM_PEAK_GBS} if args.precision == "fp32" else {
-                "bound": "mfma", "what": "whole step, algorithmic TFLOP/s per GPU against the dense bf16 MFMA peak",
-                "achieved": value / world * tflop_per_patch, "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": value / world * tflop_per_patch / 2500.0}
+                    tdoc = json.load(f)
+                traffic, tsrc = tdoc.get(str(B)), tdoc.get("source")
+            line["roofline"] = {
+                "bound": "mfma", "what": "whole training step: algorithmic TFLOP/s per GPU (patches/s x TFLOP per patch)",
+                "achieved": step_tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_tf / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": traffic, "traffic_source": tsrc,
+                "kernel": fams[0]["family"] if fams else None, "families": fams,
+            }
+            if workload in HBM_GB_PER_PATCH:
+                gbs = value / world * HBM_GB_PER_PATCH[workload]
+                line["roofline"]["secondary"] = {"bound": "hbm", "what": "whole step, algorithmic bytes per patch x "
+                                                 "patches/s per GPU", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                                 "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        else:
+            # bf16 mode: every conv moves two fp32 maps per launch and ~15 us of MFMA: HBM-bound
+            gbs = value / world * HBM_GB_PER_PATCH.get(workload, 16.5)
+            line["roofline"] = {"bound": "hbm", "what": "whole step, algorithmic fp32-map bytes per patch x patches/s per GPU",
+                                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                "traffic": None,
+                                "secondary": {"bound": "mfma", "achieved": step_tf, "peak": 2500.0, "unit": "TFLOP/s",
+                                              "frac": step_tf / 2500.0}}
+        if secondary is not None:
+            line[secondary[0]] = secondary[1]
         if world == 1 and not args.no_cpu_baseline and args.precision == "fp32":
-            line["cpu_baseline"] = cpu_baseline(args.workload)
+            line["cpu_baseline"] = cpu_baseline(workload)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

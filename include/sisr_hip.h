@@ -48,6 +48,13 @@ int sisr_pack_conv3x3(const float* w, float* packed, int cout, int cin, int64_t 
 /* forward and input-gradient packings of one weight in one launch (shuffle_r > 1: conv feeds PixelShuffle(r)) */
 int sisr_pack_conv3x3_both(const float* w, float* packed_fwd, float* packed_dgrad, int cout, int cin, int shuffle_r,
                            void* stream);
+/* every conv weight of a network in ONE launch (a training step repacks them all after the optimiser update).
+ * jobs_device: device array of n_jobs records {const float* w; void* packed_fwd; void* packed_dgrad; int32 cout, cin,
+ * shuffle_r, first_block} (sisr_pack_job_bytes() each; the caller builds it once per network); job j owns blocks
+ * [first_block_j, first_block_j+1) of 256 packed elements each; total_blocks = their sum.  bf16 != 0: the bf16
+ * packings of sisr_pack_conv3x3_bf16_both. */
+size_t sisr_pack_job_bytes(void);
+int sisr_pack_conv3x3_many(const void* jobs_device, int n_jobs, int total_blocks, int bf16, void* stream);
 int sisr_conv3x3_c64_gap_parts(int H, int W);
 int sisr_conv3x3_c64_set_variant(int v); /* 4 issue-lean kernel, tile height by grid size, + general fallback (default);
                                              5 / 6 force its 4-row / 2-row tile; 2 general kernel only;
@@ -110,6 +117,18 @@ size_t sisr_meta_gate_bwd_workspace_bytes(int B, int hidden, int channels);
 int sisr_meta_gate_bwd(const float* dm, const float* m, const float* hid, const float* md, int B, int M, int hidden,
                        int channels, const float* v1, const float* v2, int relu, float* dv1, float* dc1, float* dv2,
                        float* dc2, float* dmd, float* workspace, void* stream);
+/* All L meta-attention layers of a network at once (the gates depend on the metadata and each layer's own weights
+ * only -- ref: attention_manipulators/architectures.py:172-180 applies q_node to the same `metadata` in every
+ * QRCAB): *_table are device arrays of L device pointers to the layers' parameters; hid [L][B][hidden], m and dm
+ * [L][B][channels]; gradients come back as [L][hidden*M], [L][hidden], [L][channels*hidden], [L][channels].
+ * No metadata gradient. */
+int sisr_meta_gate_many_fwd(const float* md, int B, int M, int hidden, int channels, int layers,
+                            const float* const* v1_table, const float* const* c1_table, const float* const* v2_table,
+                            const float* const* c2_table, int relu, float* hid, float* m, void* stream);
+size_t sisr_meta_gate_many_bwd_workspace_bytes(int B, int hidden, int channels, int layers);
+int sisr_meta_gate_many_bwd(const float* dm, const float* m, const float* hid, const float* md, int B, int M, int hidden,
+                            int channels, int layers, const float* const* v1_table, const float* const* v2_table,
+                            int relu, float* dv1, float* dc1, float* dv2, float* dc2, float* workspace, void* stream);
 
 /* ---- gated residual: y = t*g[b,c] + shift[b,c] + x  (g, shift, x nullable)
  * ref: the `x * y` / `res += x` tails of CALayer, RCAB, QRCAB, ParamResBlock; with shift it is also the

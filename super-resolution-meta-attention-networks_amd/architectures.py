@@ -34,6 +34,47 @@ def _ca_params(seq):
     return seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias
 
 
+def conv_weights(net):
+    """[(weight, shuffle)] of every 3x3 conv the MFMA kernels run (channel counts multiples of 64), for ops.pack_all:
+    shuffle = r for the Upsampler convs whose PixelShuffle is fused into the store, 1 otherwise."""
+    out, seen = [], set()
+    for m in net.modules():
+        if isinstance(m, Upsampler):
+            mods = list(m)
+            for i in range(0, len(mods), 2):
+                r, w = mods[i + 1].upscale_factor, mods[i].weight
+                if w.shape[0] == 64 * r * r and w.shape[1] % 64 == 0 and id(w) not in seen:
+                    out.append((w, r))
+                    seen.add(id(w))
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.groups == 1 and id(m.weight) not in seen:
+            w = m.weight
+            if w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
+                out.append((w, 1))
+                seen.add(id(w))
+    return out
+
+
+def meta_gates(layers, attributes):
+    """Gates of a list of ParaCALayers: one batched launch when they are uniform (the normal case: every q-layer of a
+    network has the same metadata / hidden / channel sizes), else one launch per layer."""
+    if not layers:
+        return []
+    first = layers[0]
+    def sig(lay):
+        a, b = (lay.attribute_integrator[i] for i in lay.fc_index)
+        return (tuple(a.weight.shape), tuple(b.weight.shape), lay.nonlinearity, a.bias is not None, b.bias is not None)
+    if (len(layers) > 1 and not attributes.requires_grad and all(sig(lay) == sig(first) for lay in layers)
+            and sig(first)[3] and sig(first)[4]):
+        params = []
+        for lay in layers:
+            a, b = (lay.attribute_integrator[i] for i in lay.fc_index)
+            params.append((a.weight, a.bias, b.weight, b.bias))
+        if all(t.is_contiguous() for lay in params for t in lay):
+            return list(ops.meta_gate_many(attributes, params, first.nonlinearity))
+    return [lay.gate(attributes) for lay in layers]
+
+
 # ----------------------------------------------------------------------------- plain blocks
 class Upsampler(nn.Sequential):
     """ref: advanced/common.py:20-45.  conv(C -> r^2 C) + PixelShuffle(r); for n_feat = 64 the shuffle is fused
@@ -308,18 +349,20 @@ class QRCAB(nn.Module):
         self.body = nn.Sequential(*body)
         self.res_scale = res_scale
 
-    def forward(self, x):
+    def forward(self, x, m=None):
+        """m: this block's meta gate when the network computed all of them up front (meta_gates)."""
         feat, md = x
         b = self.body
+        if self.q_layer and m is None:
+            m = self.q_node.gate(md)
         if self.pa:
             # per-pixel gate between the channel and meta gates: the per-(b,c) fusion does not apply
             t = ops.res_block_convs(feat, b[0].weight, b[0].bias, b[2].weight, b[2].bias)
             t = self.pa_node(self.final_body(t, md))
             if self.q_layer:
-                return ops.gate_mul(t, self.q_node.gate(md), feat), md
+                return ops.gate_mul(t, m, feat), md
             return ops.add_residual(t, feat), md
         if self.final_body.style == 'standard':
-            m = self.q_node.gate(md) if self.q_layer else None
             y = ops.res_block(feat, b[0].weight, b[0].bias, b[2].weight, b[2].bias,
                               ca=_ca_params(self.final_body.conv_du), m=m)
             return y, md
@@ -327,7 +370,7 @@ class QRCAB(nn.Module):
         t = ops.res_block_convs(feat, b[0].weight, b[0].bias, b[2].weight, b[2].bias)
         g = self.final_body.gate_from_pool(ops.global_avg_pool(t), md)
         if self.q_layer:
-            g = g * self.q_node.gate(md).reshape(g.shape)
+            g = g * m.reshape(g.shape)
         return ops.gate_mul(t, g, feat), md
 
 
@@ -345,16 +388,19 @@ class QResidualGroup(nn.Module):
         self.final_body = conv(n_feat, n_feat, kernel_size)
         self.body = nn.Sequential(*body)
 
-    def forward(self, x):
+    def forward(self, x, gates=None):
+        """gates: {id(block): meta gate} computed by the network for all its q-layers at once, or None."""
         feat, md = x
+        ms = [(gates.get(id(b)) if gates else None) for b in self.body]
         if (ops.fused_groups_enabled() and feat.shape[1] == 64
                 and all(not b.pa and b.final_body.style == 'standard' for b in self.body)):
             blocks = [(b.body[0].weight, b.body[0].bias, b.body[2].weight, b.body[2].bias,
-                       _ca_params(b.final_body.conv_du), b.q_node.gate(md) if b.q_layer else None) for b in self.body]
+                       _ca_params(b.final_body.conv_du),
+                       (m if m is not None else b.q_node.gate(md)) if b.q_layer else None) for b, m in zip(self.body, ms)]
             return ops.gated_group(feat, blocks, self.final_body.weight, self.final_body.bias), md
         res = feat
-        for blk in self.body:
-            res, _ = blk((res, md))
+        for blk, m in zip(self.body, ms):
+            res, _ = blk((res, md), m)
         return _conv(self.final_body, res, residual=feat), md
 
 
@@ -384,8 +430,10 @@ class QRCAN(nn.Module):
         _check_rgb(x, "QRCAN")
         x = _conv(self.head[0], x)
         res = x
+        qblocks = [b for g in self.body for b in g.body if b.q_layer]
+        gates = dict(zip(map(id, qblocks), meta_gates([b.q_node for b in qblocks], metadata)))
         for g in self.body:
-            res, _ = g((res, metadata))
+            res, _ = g((res, metadata), gates)
         res = _conv(self.final_body, res, residual=x)
         return _conv(self.tail[1], self.tail[0](res))
 
@@ -401,11 +449,11 @@ class ParamResBlock(nn.Module):
         self.attention_layer = ParaCALayer(n_feats, n_params, nonlinearity=q_layer_nonlinearity)
         self.res_scale = res_scale
 
-    def forward(self, x):
+    def forward(self, x, m=None):
         feat, md = x
         b = self.body
-        y = ops.res_block(feat, b[0].weight, b[0].bias, b[2].weight, b[2].bias, m=self.attention_layer.gate(md),
-                          res_scale=self.res_scale)
+        y = ops.res_block(feat, b[0].weight, b[0].bias, b[2].weight, b[2].bias,
+                          m=m if m is not None else self.attention_layer.gate(md), res_scale=self.res_scale)
         return y, md
 
 
@@ -427,7 +475,7 @@ class QEDSR(nn.Module):
         _check_rgb(x, "QEDSR")
         x = _conv(self.head, x)
         res = x
-        for blk in self.body:
-            res, _ = blk((res, metadata))
+        for blk, m in zip(self.body, meta_gates([b.attention_layer for b in self.body], metadata)):
+            res, _ = blk((res, metadata), m)
         res = _conv(self.final_body, res, residual=x)
         return _conv(self.tail[1], self.tail[0](res))

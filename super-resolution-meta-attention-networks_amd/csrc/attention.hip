@@ -142,10 +142,10 @@ __global__ __launch_bounds__(256) void ca_gate_bwd_kernel(const float* __restric
 
 // ---------------------------------------------------------------- meta gate (ParaCALayer) forward / backward
 // md [B][M]; v1 [Hd][M]; c1 [Hd]; v2 [C][Hd]; c2 [C].  One block per sample, blockDim = 256.
-__global__ __launch_bounds__(256) void meta_gate_fwd_kernel(const float* __restrict__ md, int M, int Hd, int C,
-                                                            const float* __restrict__ v1, const float* __restrict__ c1,
-                                                            const float* __restrict__ v2, const float* __restrict__ c2,
-                                                            int relu, float* __restrict__ hid, float* __restrict__ m) {
+__device__ __forceinline__ void meta_gate_fwd_body(const float* __restrict__ md, int M, int Hd, int C,
+                                                   const float* __restrict__ v1, const float* __restrict__ c1,
+                                                   const float* __restrict__ v2, const float* __restrict__ c2,
+                                                   int relu, float* __restrict__ hid, float* __restrict__ m) {
   extern __shared__ float sm[];  // Hd floats
   const int b = blockIdx.x;
   for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
@@ -163,16 +163,40 @@ __global__ __launch_bounds__(256) void meta_gate_fwd_kernel(const float* __restr
   }
 }
 
+__global__ __launch_bounds__(256) void meta_gate_fwd_kernel(const float* __restrict__ md, int M, int Hd, int C,
+                                                            const float* __restrict__ v1, const float* __restrict__ c1,
+                                                            const float* __restrict__ v2, const float* __restrict__ c2,
+                                                            int relu, float* __restrict__ hid, float* __restrict__ m) {
+  meta_gate_fwd_body(md, M, Hd, C, v1, c1, v2, c2, relu, hid, m);
+}
+
+// All L meta-attention layers of a network in one launch (blockIdx.y = layer): the gates depend on the metadata and
+// on the layers' own weights only, never on features, so the 200 ParaCALayers of a QRCAN need not be 200 launches.
+// Weight pointers come from device tables (the layers' parameters live wherever nn.Module put them); hid and m are
+// [L][B][Hd] and [L][B][C].
+struct MetaTables {
+  const float* const* v1;
+  const float* const* c1;
+  const float* const* v2;
+  const float* const* c2;
+};
+
+__global__ __launch_bounds__(256) void meta_gate_many_fwd_kernel(const float* __restrict__ md, int B, int M, int Hd, int C,
+                                                                 MetaTables t, int relu, float* __restrict__ hid,
+                                                                 float* __restrict__ m) {
+  const int l = blockIdx.y;
+  meta_gate_fwd_body(md, M, Hd, C, t.v1[l], t.c1[l], t.v2[l], t.c2[l], relu, hid + (long)l * B * Hd, m + (long)l * B * C);
+}
+
 // Backward in two stages (the single-block batch loop it replaces took ~0.5 ms per layer at B = 32):
 //  sample stage (one block per sample): dz2 = dm*m*(1-m); dz1 = act'(hid) * V2^T dz2; dmd = V1^T dz1
 //  param stage  (one thread per parameter element): dV2 = sum_b dz2 (x) hid, dc2 = sum_b dz2,
 //                                                   dV1 = sum_b dz1 (x) md,  dc1 = sum_b dz1   (batch order)
-__global__ __launch_bounds__(256) void meta_gate_bwd_sample_kernel(const float* __restrict__ dm, const float* __restrict__ m,
-                                                                   const float* __restrict__ hid, int M, int Hd, int C,
-                                                                   const float* __restrict__ v1,
-                                                                   const float* __restrict__ v2, int relu,
-                                                                   float* __restrict__ dz2_out, float* __restrict__ dz1_out,
-                                                                   float* __restrict__ dmd) {
+__device__ __forceinline__ void meta_gate_bwd_sample_body(const float* __restrict__ dm, const float* __restrict__ m,
+                                                          const float* __restrict__ hid, int M, int Hd, int C,
+                                                          const float* __restrict__ v1, const float* __restrict__ v2,
+                                                          int relu, float* __restrict__ dz2_out,
+                                                          float* __restrict__ dz1_out, float* __restrict__ dmd) {
   extern __shared__ float sm[];  // dz2 [C] | dz1 [Hd] | v2 [C*Hd] | v1 [Hd*M]   (weights staged coalesced)
   float* dz2 = sm;
   float* dz1 = sm + C;
@@ -206,11 +230,32 @@ __global__ __launch_bounds__(256) void meta_gate_bwd_sample_kernel(const float* 
   }
 }
 
-__global__ __launch_bounds__(256) void meta_gate_bwd_param_kernel(const float* __restrict__ dz2, const float* __restrict__ dz1,
-                                                                  const float* __restrict__ hid, const float* __restrict__ md,
-                                                                  int B, int M, int Hd, int C, float* __restrict__ dv1,
-                                                                  float* __restrict__ dc1, float* __restrict__ dv2,
-                                                                  float* __restrict__ dc2) {
+__global__ __launch_bounds__(256) void meta_gate_bwd_sample_kernel(const float* __restrict__ dm, const float* __restrict__ m,
+                                                                   const float* __restrict__ hid, int M, int Hd, int C,
+                                                                   const float* __restrict__ v1,
+                                                                   const float* __restrict__ v2, int relu,
+                                                                   float* __restrict__ dz2_out, float* __restrict__ dz1_out,
+                                                                   float* __restrict__ dmd) {
+  meta_gate_bwd_sample_body(dm, m, hid, M, Hd, C, v1, v2, relu, dz2_out, dz1_out, dmd);
+}
+
+// blockIdx.y = layer; dm, m, dz2: [L][B][C]; hid, dz1: [L][B][Hd]; no metadata gradient (it would be a sum over layers)
+__global__ __launch_bounds__(256) void meta_gate_many_bwd_sample_kernel(const float* __restrict__ dm,
+                                                                        const float* __restrict__ m,
+                                                                        const float* __restrict__ hid, int B, int M, int Hd,
+                                                                        int C, MetaTables t, int relu,
+                                                                        float* __restrict__ dz2_out,
+                                                                        float* __restrict__ dz1_out) {
+  const long l = blockIdx.y;
+  meta_gate_bwd_sample_body(dm + l * B * C, m + l * B * C, hid + l * B * Hd, M, Hd, C, t.v1[l], t.v2[l], relu,
+                            dz2_out + l * B * C, dz1_out + l * B * Hd, nullptr);
+}
+
+__device__ __forceinline__ void meta_gate_bwd_param_body(const float* __restrict__ dz2, const float* __restrict__ dz1,
+                                                         const float* __restrict__ hid, const float* __restrict__ md,
+                                                         int B, int M, int Hd, int C, float* __restrict__ dv1,
+                                                         float* __restrict__ dc1, float* __restrict__ dv2,
+                                                         float* __restrict__ dc2) {
   const long n2 = (long)C * Hd, n1 = (long)Hd * M;
   const long total = n2 + n1 + C + Hd;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -234,6 +279,26 @@ __global__ __launch_bounds__(256) void meta_gate_bwd_param_kernel(const float* _
       dc1[j] = acc;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void meta_gate_bwd_param_kernel(const float* __restrict__ dz2, const float* __restrict__ dz1,
+                                                                  const float* __restrict__ hid, const float* __restrict__ md,
+                                                                  int B, int M, int Hd, int C, float* __restrict__ dv1,
+                                                                  float* __restrict__ dc1, float* __restrict__ dv2,
+                                                                  float* __restrict__ dc2) {
+  meta_gate_bwd_param_body(dz2, dz1, hid, md, B, M, Hd, C, dv1, dc1, dv2, dc2);
+}
+
+// blockIdx.y = layer; gradients are written as [L][Hd*M], [L][Hd], [L][C*Hd], [L][C] (the caller hands out row views)
+__global__ __launch_bounds__(256) void meta_gate_many_bwd_param_kernel(const float* __restrict__ dz2,
+                                                                       const float* __restrict__ dz1,
+                                                                       const float* __restrict__ hid,
+                                                                       const float* __restrict__ md, int B, int M, int Hd,
+                                                                       int C, float* __restrict__ dv1, float* __restrict__ dc1,
+                                                                       float* __restrict__ dv2, float* __restrict__ dc2) {
+  const long l = blockIdx.y;
+  meta_gate_bwd_param_body(dz2 + l * B * C, dz1 + l * B * Hd, hid + l * B * Hd, md, B, M, Hd, C, dv1 + l * Hd * M,
+                           dc1 + l * Hd, dv2 + l * C * Hd, dc2 + l * C);
 }
 
 // ---------------------------------------------------------------- gated residual: y = t*g[b,c] + shift[b,c] + x
@@ -475,6 +540,48 @@ extern "C" int sisr_meta_gate_bwd(const float* dm, const float* m, const float* 
   const long total = (long)channels * hidden + (long)hidden * M + channels + hidden;
   hipLaunchKernelGGL(meta_gate_bwd_param_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      dz2, dz1, hid, md, B, M, hidden, channels, dv1, dc1, dv2, dc2);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_meta_gate_many_fwd(const float* md, int B, int M, int hidden, int channels, int layers,
+                                       const float* const* v1_table, const float* const* c1_table,
+                                       const float* const* v2_table, const float* const* c2_table, int relu, float* hid,
+                                       float* m, void* stream) {
+  if (!md || !v1_table || !c1_table || !v2_table || !c2_table || !hid || !m || B <= 0 || M <= 0 || hidden <= 0 ||
+      channels <= 0 || layers <= 0)
+    return SISR_ERR_ARG;
+  if (hidden > 4096 || layers > 65535) return SISR_ERR_UNSUPPORTED;
+  const MetaTables t = {v1_table, c1_table, v2_table, c2_table};
+  hipLaunchKernelGGL(meta_gate_many_fwd_kernel, dim3(B, layers), dim3(256), hidden * sizeof(float), (hipStream_t)stream,
+                     md, B, M, hidden, channels, t, relu, hid, m);
+  return sisr_check_launch();
+}
+
+extern "C" size_t sisr_meta_gate_many_bwd_workspace_bytes(int B, int hidden, int channels, int layers) {
+  return (B > 0 && hidden > 0 && channels > 0 && layers > 0)
+             ? (size_t)layers * B * (hidden + channels) * sizeof(float)
+             : 0;
+}
+
+extern "C" int sisr_meta_gate_many_bwd(const float* dm, const float* m, const float* hid, const float* md, int B, int M,
+                                       int hidden, int channels, int layers, const float* const* v1_table,
+                                       const float* const* v2_table, int relu, float* dv1, float* dc1, float* dv2,
+                                       float* dc2, float* workspace, void* stream) {
+  if (!dm || !m || !hid || !md || !v1_table || !v2_table || !dv1 || !dc1 || !dv2 || !dc2 || !workspace || B <= 0 ||
+      layers <= 0)
+    return SISR_ERR_ARG;
+  const size_t lds = ((size_t)hidden + channels + (size_t)channels * hidden + (size_t)hidden * M) * sizeof(float);
+  if (lds > 60000 || layers > 65535) return SISR_ERR_UNSUPPORTED;
+  float* dz2 = workspace;
+  float* dz1 = workspace + (size_t)layers * B * channels;
+  const MetaTables t = {v1_table, nullptr, v2_table, nullptr};
+  hipLaunchKernelGGL(meta_gate_many_bwd_sample_kernel, dim3(B, layers), dim3(256), lds, (hipStream_t)stream, dm, m, hid, B,
+                     M, hidden, channels, t, relu, dz2, dz1);
+  int rc = sisr_check_launch();
+  if (rc) return rc;
+  const long total = (long)channels * hidden + (long)hidden * M + channels + hidden;
+  hipLaunchKernelGGL(meta_gate_many_bwd_param_kernel, dim3((unsigned)((total + 255) / 256), layers), dim3(256), 0,
+                     (hipStream_t)stream, dz2, dz1, hid, md, B, M, hidden, channels, dv1, dc1, dv2, dc2);
   return sisr_check_launch();
 }
 

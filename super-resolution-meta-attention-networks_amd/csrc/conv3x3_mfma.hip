@@ -1120,6 +1120,106 @@ extern "C" int sisr_pack_conv3x3_both(const float* w, float* packed_fwd, float* 
   return sisr_check_launch();
 }
 
+// Every conv weight of a network packed by ONE launch (a training step repacks all of them after the optimiser
+// moved them: 413 launches of ~5 us each for RCAN).  jobs[] lives in device memory (built once per network by the
+// caller): job j owns blocks [first_block, first_block of j+1); a block packs 256 consecutive packed elements in
+// both orders, element maps as in pack_conv3x3_both_kernel / pack_conv3x3_bf16_both_kernel.
+struct PackJob {
+  const float* w;
+  void* pf;
+  void* pd;
+  int cout, cin, r, first_block;
+};
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void pack_conv3x3_many_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
+  __shared__ int job_s;
+  if (threadIdx.x == 0) {  // largest j with first_block <= blockIdx.x
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    job_s = lo;
+  }
+  __syncthreads();
+  const PackJob jb = jobs[job_s];
+  const float* __restrict__ w = jb.w;
+  const int cout = jb.cout, cin = jb.cin, r = jb.r;
+  const long total = (long)cout * cin * 9;
+  const long idx = (long)(blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int rr = r * r;
+  const int oc = cout >> 6, ic = cin >> 6;
+  if (!BF16) {
+    float* pf = static_cast<float*>(jb.pf);
+    float* pd = static_cast<float*>(jb.pd);
+    long t_ = idx;
+    const int e = t_ & 3;
+    t_ >>= 2;
+    const int n = t_ & 63;
+    t_ >>= 6;
+    const int h = t_ & 1;
+    t_ >>= 1;
+    const int j = t_ & 7;
+    t_ >>= 3;
+    const int t = t_ % 9;
+    t_ /= 9;
+    const int k8 = 8 * j + 4 * h + e;
+    {
+      const int c = t_ % ic, q = t_ / ic;
+      const long o = r > 1 ? (long)n * rr + q : (long)q * 64 + n;
+      const long i = (long)c * 64 + k8;
+      pf[idx] = w[(o * cin + i) * 9 + t];
+    }
+    {
+      const int c = t_ % oc, q = t_ / oc;
+      const long i = (long)q * 64 + n;
+      const long o = r > 1 ? (long)k8 * rr + c : (long)c * 64 + k8;
+      pd[idx] = w[(o * cin + i) * 9 + (8 - t)];
+    }
+  } else {
+    __bf16* pf = static_cast<__bf16*>(jb.pf);
+    __bf16* pd = static_cast<__bf16*>(jb.pd);
+    long t_ = idx;
+    const int j = t_ & 7;
+    t_ >>= 3;
+    const int n = t_ & 63;
+    t_ >>= 6;
+    const int h = t_ & 1;
+    t_ >>= 1;
+    const int s = t_ % 36;
+    t_ /= 36;
+    const int t = s >> 2;
+    const int k = 16 * (s & 3) + 8 * h + j;
+    {
+      const int c = t_ % ic, q = t_ / ic;
+      const long o = r > 1 ? (long)n * rr + q : (long)q * 64 + n;
+      const long i = (long)c * 64 + k;
+      pf[idx] = (__bf16)w[(o * cin + i) * 9 + t];
+    }
+    {
+      const int c = t_ % oc, q = t_ / oc;
+      const long i = (long)q * 64 + n;
+      const long o = r > 1 ? (long)k * rr + c : (long)c * 64 + k;
+      pd[idx] = (__bf16)w[(o * cin + i) * 9 + (8 - t)];
+    }
+  }
+}
+
+extern "C" size_t sisr_pack_job_bytes() { return sizeof(PackJob); }
+
+extern "C" int sisr_pack_conv3x3_many(const void* jobs_device, int n_jobs, int total_blocks, int bf16, void* stream) {
+  if (!jobs_device || n_jobs <= 0 || total_blocks <= 0) return SISR_ERR_ARG;
+  if (bf16)
+    hipLaunchKernelGGL(pack_conv3x3_many_kernel<true>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const PackJob*>(jobs_device), n_jobs);
+  else
+    hipLaunchKernelGGL(pack_conv3x3_many_kernel<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const PackJob*>(jobs_device), n_jobs);
+  return sisr_check_launch();
+}
+
 // Kernel selection (process-wide, read-only during launches): 4 = issue-lean kernel (2-row tiles on small grids,
 // 4-row tiles otherwise) with the general kernel as fallback (default); 5 / 6 = the same with the 4-row / 2-row
 // tile forced; 2 = general kernel only; 13 / 16 = diagnostic builds of the general kernel (see above).

@@ -124,8 +124,10 @@ class QHAN(nn.Module):
         x = A._conv(self.head[0], x)
         res, maps = x, []
         mods = list(self.body)
+        qblocks = [b for g in mods[:-1] for b in g.body if b.q_layer]
+        gates = dict(zip(map(id, qblocks), A.meta_gates([b.q_node for b in qblocks], metadata)))
         for g in mods[:-1]:
-            res, _ = g((res, metadata))
+            res, _ = g((res, metadata), gates)
             maps.append(res)
         res = A._conv(mods[-1], res)
         maps.append(res)

@@ -162,47 +162,70 @@ class BaseModel(nn.Module):
             raise RuntimeError('Model initialized in eval mode, training not possible.')
         self.net.train()
         x, y = x.to(device=self.device), y.to(device=self.device)
-        if self.use_graph and x.is_cuda and (self.reducer is None or not self.reducer.overlap):
+        if self.use_graph and x.is_cuda:
             return self._graphed_step(x, y, kwargs)
-        out = self.run_model(x, image_names=tag, **kwargs)
-        loss = self.criterion(out, y)
-        self.standard_update(loss)
+        try:
+            ops.pack_all(self.net, A.conv_weights)  # every conv weight repacked by one launch
+            out = self.run_model(x, image_names=tag, **kwargs)
+            loss = self.criterion(out, y)
+            self.standard_update(loss)
+        finally:
+            ops.invalidate_packs()  # the optimiser moved the weights
         return loss.detach(), out.detach()
 
     def _graphed_step(self, x, y, kwargs):
         """Forward + loss + backward captured once per batch shape into a hipGraph and replayed; the reducer,
-        gradient clipping, Adam and the scheduler stay eager (they are a handful of launches)."""
+        gradient clipping, Adam and the scheduler stay eager (they are a handful of launches).
+
+        A replay writes gradients into the tensors that were the parameters' .grad at capture time, so every
+        entry keeps those tensors and re-binds p.grad to them after each replay: the data-parallel join (which
+        hands out bucket views as .grad) and a capture for another batch shape both re-point p.grad in between.
+        With a GradReducer the captured weight-gradient kernels write straight into its buckets (ops.GRAD_SINK),
+        its hooks stay off while capturing / replaying and all buckets are all-reduced at the join."""
         extra = kwargs.get('extra_channels')
         key = (tuple(x.shape), tuple(y.shape), None if extra is None else tuple(extra.shape))
         entry = self._graphs.get(key)
-        if entry is None:
-            sx, sy = x.clone(), y.clone()
-            se = None if extra is None else extra.to(self.device).clone()
-            kw = dict(kwargs)
-            if se is not None:
-                kw['extra_channels'] = se
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):  # one eager pass off the default stream: allocator + lazy-init warm-up
+        red = self.reducer
+        if red is not None:
+            red.hooks_enabled = False
+        try:
+            if entry is None:
+                sx, sy = x.clone(), y.clone()
+                se = None if extra is None else extra.to(self.device).clone()
+                kw = dict(kwargs)
+                if se is not None:
+                    kw['extra_channels'] = se
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):  # one eager pass off the default stream: allocator + lazy-init warm-up
+                    self.optimizer.zero_grad(set_to_none=True)
+                    ops.pack_all(self.net, A.conv_weights)
+                    self.criterion(self.run_model(sx, **kw), sy).backward()
+                torch.cuda.current_stream().wait_stream(side)
                 self.optimizer.zero_grad(set_to_none=True)
-                self.criterion(self.run_model(sx, **kw), sy).backward()
-            torch.cuda.current_stream().wait_stream(side)
-            self.optimizer.zero_grad(set_to_none=True)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self.run_model(sx, **kw)
-                loss = self.criterion(out, sy)
-                loss.backward()
-            entry = (graph, sx, sy, se, loss, out)
-            self._graphs[key] = entry
-        graph, sx, sy, se, loss, out = entry
-        sx.copy_(x)
-        sy.copy_(y)
-        if se is not None:
-            se.copy_(extra)
-        graph.replay()  # gradients land in the .grad tensors created during capture
-        if self.reducer is not None:
-            self.reducer.reduce()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    ops.pack_all(self.net, A.conv_weights)  # first node of the graph: the replay repacks
+                    out = self.run_model(sx, **kw)
+                    loss = self.criterion(out, sy)
+                    loss.backward()
+                grads = [(p, p.grad) for p in self.net.parameters()]
+                entry = (graph, sx, sy, se, loss, out, grads)
+                self._graphs[key] = entry
+            graph, sx, sy, se, loss, out, grads = entry
+            sx.copy_(x)
+            sy.copy_(y)
+            if se is not None:
+                se.copy_(extra)
+            graph.replay()
+            for p, g in grads:  # this replay's gradients live in this entry's capture-time tensors
+                p.grad = g
+        finally:
+            ops.invalidate_packs()
+            if red is not None:
+                red.hooks_enabled = True
+        if red is not None:
+            red.reduce()
         if self.grad_clip is not None:
             nn.utils.clip_grad_norm_(self.net.parameters(), self.grad_clip)
         self.optimizer.step()
@@ -235,7 +258,12 @@ class BaseModel(nn.Module):
             if timing:
                 torch.cuda.synchronize()  # the reference times without a device sync (ref :508-512); we do sync
                 tic = time.perf_counter()
-            out = self.run_model(x, image_names=tag, **kwargs)
+            try:
+                if x.is_cuda:
+                    ops.pack_all(self.net, A.conv_weights)
+                out = self.run_model(x, image_names=tag, **kwargs)
+            finally:
+                ops.invalidate_packs()
             if timing:
                 torch.cuda.synchronize()
                 toc = time.perf_counter()

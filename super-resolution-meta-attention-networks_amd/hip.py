@@ -68,6 +68,13 @@ _SIGS.update({  # bf16 matrix-core variants (csrc/conv3x3_mfma.hip, csrc/wgrad3x
     "sisr_wgrad3x3_c64_bf16": (c_int, [P, P, P, P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
                                   c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
 })
+_SIGS.update({  # step-level launches (round 2): all conv weights / all meta gates of a network at once
+    "sisr_pack_job_bytes": (c_size_t, []),
+    "sisr_pack_conv3x3_many": (c_int, [P, c_int, c_int, c_int, P]),
+    "sisr_meta_gate_many_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P]),
+    "sisr_meta_gate_many_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sisr_meta_gate_many_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P]),
+})
 _SIGS.update({  # SAN attention (csrc/san.hip)
     "sisr_covpool_workspace_bytes": (c_size_t, [c_int, c_long]),
     "sisr_covpool_fwd": (c_int, [P, P, P, P, c_int, c_long, c_int, P]),

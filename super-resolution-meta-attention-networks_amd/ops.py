@@ -31,6 +31,7 @@ CL = torch.channels_last
 # stream once, at the end of the backward pass (autograd engine callback), before anything reads the grads.
 # (Measured +5 % at 16 tiles per GPU when introduced; neutral at 32 with the current kernels -- see DESIGN.md §3.)
 WGRAD_SIDE_STREAM = os.environ.get("SISR_WGRAD_SIDE_STREAM", "1") != "0"
+GRAPH_FORK = os.environ.get("SISR_GRAPH_FORK", "1") != "0"
 IN_BACKWARD = False  # set while a conv operator's backward runs (bench.py times forward launches only)
 _side_streams = {}
 _join_pending = set()
@@ -82,9 +83,22 @@ GRAD_SINK = {}
 
 def _grad_buf(w):
     sink = GRAD_SINK.get(w.data_ptr())
-    if sink is not None and sink.shape == w.shape:
+    # only when this backward creates the gradient: with a pre-existing .grad (zero_grad(set_to_none=False),
+    # micro-batch accumulation) autograd adds the result to it, and .grad may itself be the bucket view
+    if sink is not None and sink.shape == w.shape and w.grad is None:
         return sink.view(sink.shape)  # a fresh alias: autograd adopts a gradient it holds the only reference to
     return torch.empty_like(w)
+
+
+def _side_ok(*weights):
+    """Weight gradients may be produced on the side stream (which re-joins the main stream only at the end of the
+    backward pass) iff autograd will merely ADOPT them: with an existing .grad AccumulateGrad would run
+    `p.grad += dw` on the main stream before the side-stream kernel has written dw."""
+    if not (WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False and all(w.grad is None for w in weights)):
+        return False
+    # under hipGraph capture the fork / join become graph edges (parallel branches the GPU may overlap);
+    # SISR_GRAPH_FORK=0 keeps a captured backward on one stream
+    return GRAPH_FORK or not torch.cuda.is_current_stream_capturing()
 
 
 _gate_ws_cache = {}
@@ -127,8 +141,78 @@ def _wptr(packed):
     return hip.ptr_bf16(packed) if packed.dtype == torch.bfloat16 else hip.ptr(packed)
 
 
+# Step-level packing: BaseModel.train_step / run_eval call pack_all(net) once, which repacks EVERY conv weight of the
+# network with one launch into persistent buffers and publishes them here; pack_pair / pack_weight then find their
+# weight (by object identity) and launch nothing.  The entries are dropped as soon as the optimiser has moved the
+# weights (invalidate_packs), so a stale packing can never be used; code that calls a network outside the handlers
+# simply packs per conv as before.
+_STEP_PACKS = {}
+
+
+class _PackPlan:
+    def __init__(self, weights, device):
+        import numpy as np
+        self.precision = PRECISION
+        self.items = [(w, int(r)) for w, r in weights]
+        self.ptrs = [w.data_ptr() for w, _ in self.items]
+        total = sum(w.numel() for w, _ in self.items)
+        dt = torch.bfloat16 if PRECISION == "bf16" else torch.float32
+        self.fwd = torch.empty(total, device=device, dtype=dt)
+        self.dgrad = torch.empty(total, device=device, dtype=dt)
+        esz = self.fwd.element_size()
+        jobs = np.zeros(len(self.items), dtype=[("w", "<u8"), ("pf", "<u8"), ("pd", "<u8"), ("cout", "<i4"),
+                                                ("cin", "<i4"), ("r", "<i4"), ("first", "<i4")])
+        assert jobs.dtype.itemsize == hip.lib().sisr_pack_job_bytes()
+        off = blocks = 0
+        self.slices = []
+        for k, (w, r) in enumerate(self.items):
+            n = w.numel()
+            jobs[k] = (w.data_ptr(), self.fwd.data_ptr() + off * esz, self.dgrad.data_ptr() + off * esz, w.shape[0],
+                       w.shape[1], r, blocks)
+            self.slices.append((self.fwd[off:off + n], self.dgrad[off:off + n]))
+            off += n
+            blocks += (n + 255) // 256
+        self.blocks = blocks
+        self.jobs = torch.from_numpy(jobs.view(np.uint8)).to(device)
+
+    def valid(self):
+        return self.precision == PRECISION and all(w.data_ptr() == p for (w, _), p in zip(self.items, self.ptrs))
+
+    def run(self):
+        hip.check(hip.lib().sisr_pack_conv3x3_many(self.jobs.data_ptr(), len(self.items), self.blocks,
+                                                   int(PRECISION == "bf16"), hip.stream()), "sisr_pack_conv3x3_many")
+        for (w, r), (pf, pd) in zip(self.items, self.slices):
+            _STEP_PACKS[id(w)] = (w, r, PRECISION, pf, pd)
+
+
+def pack_all(net, weights_fn):
+    """Repack every 64-multiple 3x3 conv weight of `net` in one launch; weights_fn(net) -> [(weight, shuffle)]."""
+    plan = getattr(net, "_sisr_pack_plan", None)
+    if plan is None or not plan.valid():
+        ws = [(w, r) for w, r in weights_fn(net) if w.is_cuda and w.is_contiguous()]
+        if not ws:
+            return
+        plan = _PackPlan(ws, ws[0][0].device)
+        net._sisr_pack_plan = plan
+    plan.run()
+
+
+def invalidate_packs():
+    _STEP_PACKS.clear()
+
+
+def _step_pack(w, shuffle):
+    e = _STEP_PACKS.get(id(w))
+    if e is not None and e[0] is w and e[1] == shuffle and e[2] == PRECISION:
+        return e[3], e[4]
+    return None
+
+
 def pack_weight(w, mode, shuffle=1):
     """OIHW fp32 weight -> B-fragment order of the MFMA conv ('fwd') or of its input gradient ('dgrad')."""
+    hit = _step_pack(w, shuffle)
+    if hit is not None:
+        return hit[0] if mode == "fwd" else hit[1]
     if PRECISION == "bf16":
         pf, pd = pack_pair(w, shuffle)
         return pf if mode == "fwd" else pd
@@ -149,6 +233,9 @@ def pack_weight(w, mode, shuffle=1):
 
 def pack_pair(w, shuffle=1):
     """(forward packing, input-gradient packing) of one weight, one launch."""
+    hit = _step_pack(w, shuffle)
+    if hit is not None:
+        return hit
     cout, cin = w.shape[0], w.shape[1]
     if PRECISION == "bf16":
         buf = torch.empty(2, cout * cin * 9, device=w.device, dtype=torch.bfloat16)
@@ -353,6 +440,80 @@ def meta_gate(md, v1, c1, v2, c2, relu):
     return _MetaGate.apply(md, v1, c1, v2, c2, bool(relu))
 
 
+_meta_tables = {}
+
+
+def _meta_table(params, device):
+    """Device table [4][L] of the layers' (v1, c1, v2, c2) addresses, rebuilt when a parameter moved."""
+    ptrs = tuple(t.data_ptr() for t in params)
+    key = (device.index, len(ptrs))
+    hit = _meta_tables.get(key)
+    if hit is None or hit[0] != ptrs:
+        L = len(ptrs) // 4
+        tab = torch.tensor([[ptrs[4 * l + k] for l in range(L)] for k in range(4)], dtype=torch.int64).to(device)
+        hit = (ptrs, tab)
+        _meta_tables[key] = hit
+    return hit[1]
+
+
+class _MetaGateMany(Function):
+    """The gates of L ParaCALayers (same M, hidden size, channel count, nonlinearity) in one launch each way:
+    m[l] = sigmoid(V2_l act(V1_l md + c1_l) + c2_l)  ->  (L, B, C).  They depend on the metadata and the layers'
+    own weights only, so a network computes all of them before its first block."""
+
+    @staticmethod
+    def forward(ctx, md, relu, *params):
+        L = len(params) // 4
+        B, M = md.shape[0], md.shape[1]
+        if md.requires_grad:
+            raise NotImplementedError("batched meta gates do not return a metadata gradient")
+        for t in params:
+            if not t.is_contiguous():
+                raise NotImplementedError("batched meta gates need contiguous layer parameters")
+        md2 = md.reshape(B, M).contiguous()
+        Hd, C = params[0].shape[0], params[2].shape[0]
+        dev = md.device
+        tab = _meta_table(params, dev)
+        hid = torch.empty((L, B, Hd), device=dev, dtype=torch.float32)
+        m = torch.empty((L, B, C), device=dev, dtype=torch.float32)
+        es = tab.element_size() * L
+        base = tab.data_ptr()
+        hip.check(hip.lib().sisr_meta_gate_many_fwd(hip.ptr(md2), B, M, Hd, C, L, base, base + es, base + 2 * es,
+                                                    base + 3 * es, int(relu), hip.ptr(hid), hip.ptr(m), hip.stream()),
+                  "sisr_meta_gate_many_fwd")
+        ctx.save_for_backward(md2, hid, m, tab)
+        ctx.cfg = (relu, L, B, M, Hd, C, [tuple(t.shape) for t in params[:4]])
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        md2, hid, m, tab = ctx.saved_tensors
+        relu, L, B, M, Hd, C, shapes = ctx.cfg
+        dev = md2.device
+        dmc = dm.contiguous()
+        dv1 = torch.empty((L,) + shapes[0], device=dev)
+        dc1 = torch.empty((L,) + shapes[1], device=dev)
+        dv2 = torch.empty((L,) + shapes[2], device=dev)
+        dc2 = torch.empty((L,) + shapes[3], device=dev)
+        ws = torch.empty(L * B * (Hd + C), device=dev)
+        es = tab.element_size() * L
+        base = tab.data_ptr()
+        hip.check(hip.lib().sisr_meta_gate_many_bwd(hip.ptr(dmc), hip.ptr(m), hip.ptr(hid), hip.ptr(md2), B, M, Hd, C, L,
+                                                    base, base + 2 * es, int(relu), hip.ptr(dv1), hip.ptr(dc1),
+                                                    hip.ptr(dv2), hip.ptr(dc2), hip.ptr(ws), hip.stream()),
+                  "sisr_meta_gate_many_bwd")
+        grads = []
+        for l in range(L):  # row views: each is the only reference to its tensor object, so autograd adopts it
+            grads += [dv1[l], dc1[l], dv2[l], dc2[l]]
+        return (None, None, *grads)
+
+
+def meta_gate_many(md, layers, relu):
+    """layers: [(v1, c1, v2, c2)] of L uniform ParaCALayers -> tuple of L (B, C) gates (views of one tensor)."""
+    flat = [t for lay in layers for t in lay]
+    return _MetaGateMany.apply(md, bool(relu), *flat).unbind(0)
+
+
 # ----------------------------------------------------------------------------- fused residual block
 class _ResBlock(Function):
     """y = x + gate * res_scale * conv2(relu(conv1(x)));  gate = CA(GAP(.)) [* m] | m | 1."""
@@ -456,9 +617,8 @@ class _ResBlock(Function):
             # conv2 backward: dt2 = dy*scale + shift is rebuilt on load, never stored
             dw2, db2 = _grad_buf(w2), torch.empty(C, device=dev)
             dw1, db1 = _grad_buf(w1), torch.empty(C, device=dev)
-                # plain first-order backward only; not under hipGraph capture (record_stream + private pools)
-            side = (WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False
-                    and not torch.cuda.is_current_stream_capturing())
+            # plain first-order backward only; not under hipGraph capture (record_stream + private pools)
+            side = _side_ok(w1, w2)
 
             def wgrad2():
                 wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, C, C, alpha=rs, dy_scale=scale, dy_shift=shift)
@@ -574,8 +734,6 @@ class _GatedGroup(Function):
             v = hip.view_plain(H, W, 64)
             hw = H * W
             dout = _cl(dout)
-            side = (WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False
-                    and not torch.cuda.is_current_stream_capturing())
 
             def run(fn, keep):
                 if side:
@@ -589,6 +747,7 @@ class _GatedGroup(Function):
             for cnt, has_m, s1, s2 in meta:
                 blocks.append((sv_all[pos:pos + cnt], has_m, s1, s2))
                 pos += cnt
+            side = _side_ok(wt, *(t for blk in blocks for t in blk[0][1:3]))
             # tail conv: weight gradient from (u_n, dout); dU_n = convT(dout), with sum(dU_n * t2_n) on the side
             dwt, dbt = _grad_buf(wt), torch.empty(64, device=dev)
             run(lambda: wgrad_c64(un, v, dout, v, dwt, dbt, B, H, W, 64, 64), (un, dout, dwt, dbt))

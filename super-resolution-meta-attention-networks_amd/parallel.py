@@ -105,7 +105,10 @@ class GradReducer:
         self.works = [None] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
-        self.overlap = overlap  # False: no hooks, everything is reduced at the join (needed under hipGraph replay)
+        self.overlap = overlap  # False: no hooks, everything is reduced at the join
+        # hooks_enabled is switched off by BaseModel._graphed_step while it captures / replays a hipGraph: a captured
+        # backward must not launch collectives, and a replay fires no hooks, so every bucket is reduced at the join
+        self.hooks_enabled = True
         self.handles = []
         if overlap:
             for p in self.params:
@@ -117,6 +120,8 @@ class GradReducer:
             dist.broadcast(b.data, src=0, group=process_group)
 
     def _on_grad(self, p):
+        if not self.hooks_enabled:
+            return
         bi = self.bucket_of[p]
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
@@ -124,7 +129,10 @@ class GradReducer:
 
     def _launch(self, bi):
         bucket, flat = self.buckets[bi], self.flat[bi]
-        # gradients the kernels already wrote into the bucket (ops.GRAD_SINK) need no copy
+        # Gradients the kernels of THIS step wrote straight into the bucket (ops.GRAD_SINK) need no copy.  The test is
+        # "p.grad aliases the bucket", which is only sound because p.grad always names this step's gradient when we
+        # get here: eager steps start from zero_grad() (grads None, or accumulated in place into the view), and a
+        # hipGraph replay rebinds p.grad to the tensors its kernels write (BaseModel._graphed_step).
         todo = [p for p in bucket if p.grad is None or p.grad.data_ptr() != self.views[p].data_ptr()]
         dst = [self.views[p] for p in todo]
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in todo]
