@@ -158,7 +158,7 @@ def cpu_baseline(workload, seconds_budget=30.0):
     return out
 
 
-def measure(sisr, workload, B, steps, warmup, use_graph, rank, world, local, dev, families=False):
+def measure(sisr, workload, B, steps, warmup, use_graph, rank, world, local, dev, families=False, dp=False):
     """Build the handler, run warm-up + exactly `steps` timed steps (barrier + sync on both sides, max over ranks)."""
     name, params, tflop_per_patch = WORKLOADS[workload]
     if name not in sisr.available_models:
@@ -167,7 +167,7 @@ def measure(sisr, workload, B, steps, warmup, use_graph, rank, world, local, dev
     h = sisr.available_models[name](device=local, model_save_dir="/tmp", eval_mode=False, scale=4, lr=1e-4,
                                     scheduler="cosine_annealing_warm_restarts",
                                     scheduler_params={"t_mult": 1, "restart_period": 125000, "lr_min": 1e-7}, **params)
-    if world > 1:
+    if world > 1 or dp:
         h.set_multi_gpu()
     h.use_graph = use_graph
     g = torch.Generator().manual_seed(8 + rank)
@@ -232,6 +232,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the meta_rcan / weak_scaling side measurement")
     ap.add_argument("--graph", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
                     help=f"replay forward+backward as a hipGraph (auto: per-GPU batch <= {GRAPH_MAX_BATCH})")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="N = 1 only: run through a one-rank RCCL world (GradReducer buckets, all_reduce, join)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="arithmetic of the 64-channel convs: fp32 MFMA (reference arithmetic, the headline) or bf16 "
                          "MFMA operands with fp32 accumulate / storage (BASELINE config 'HAN x4 bf16')")
@@ -248,6 +250,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.force_dp and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
 
     explicit = args.workload is not None or args.batch is not None or args.global_batch is not None
     workload = args.workload or ("rcan" if world == 1 else "qrcan")
@@ -264,7 +270,7 @@ def main():
     use_graph = args.graph == "on" or (args.graph == "auto" and B <= GRAPH_MAX_BATCH)
 
     main_res = measure(sisr, workload, B, args.steps, args.warmup, use_graph, rank, world, local, dev,
-                       families=not args.no_kernel_timing and args.precision == "fp32")
+                       families=not args.no_kernel_timing and args.precision == "fp32", dp=args.force_dp)
     secondary = None
     if not explicit and not args.no_secondary and args.precision == "fp32":
         # N = 1: the north_star family beside BASELINE's configs[1]; N > 1: the weak-scaling point beside config 4
@@ -290,7 +296,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{label} x4 full depth, 128x128 LR -> 512x512 tiles, train step = "
                                    f"fwd + L1 + bwd + Adam + scheduler", "per_gpu_batch": B, "global_batch": B * world,
-                       "parallelism": f"dp{world}", "hip_graph": bool(use_graph), "final_loss": main_res["loss"],
+                       "parallelism": f"dp{world}" + (" (one-rank RCCL world)" if args.force_dp and world == 1 else ""),
+                       "hip_graph": bool(use_graph), "final_loss": main_res["loss"],
                        "algorithmic_tflops": value * tflop_per_patch},
         }
         step_tf = value / world * tflop_per_patch
@@ -326,7 +333,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.precision == "fp32":
             line["cpu_baseline"] = cpu_baseline(workload)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

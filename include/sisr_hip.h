@@ -130,6 +130,29 @@ int sisr_meta_gate_many_bwd(const float* dm, const float* m, const float* hid, c
                             int channels, int layers, const float* const* v1_table, const float* const* v2_table,
                             int relu, float* dv1, float* dc1, float* dv2, float* dc2, float* workspace, void* stream);
 
+/* ---- generic gate MLP: the metadata-mixing QCALayer styles ---------------------------------------------
+ * ref: attention_manipulators/architectures.py:105-127 (QCALayer.forward after avg_pool: 'modulate', 'max_concat',
+ * 'softmax', 'mini_concat', 'extended_attention').  Layer k: z = W_k in_k + b_k with in_k = cat(v_k, metadata if cat[k]),
+ * ReLU'd first if relu_in[k]; v_{k+1} = act[k](z), act 0 none / 1 ReLU / 2 sigmoid; final_mode 0 none / 1 softmax over
+ * channels / 2 multiply by the metadata (M == C); then an optional per-(b,c) factor `mul` (the meta-attention gate).
+ * desc: HOST pointer, copied into the launch; w/b device pointers (Conv2d 1x1 weights, [nout][nin + cat*M]).
+ * acts [B][nin[0] + sum nout], yfin [B][C] are kept for the backward; workspace [B][sum nout]; dw/db HOST arrays of L
+ * device pointers; dmd, dmul nullable. */
+#define SISR_GATE_MLP_MAX_LAYERS 4
+typedef struct {
+  const float* w[SISR_GATE_MLP_MAX_LAYERS];
+  const float* b[SISR_GATE_MLP_MAX_LAYERS];
+  int nin[SISR_GATE_MLP_MAX_LAYERS], nout[SISR_GATE_MLP_MAX_LAYERS], cat[SISR_GATE_MLP_MAX_LAYERS],
+      relu_in[SISR_GATE_MLP_MAX_LAYERS], act[SISR_GATE_MLP_MAX_LAYERS];
+  int L, M, C, final_mode;
+} sisr_gate_mlp;
+size_t sisr_gate_mlp_desc_bytes(void);
+int sisr_gate_mlp_fwd(const float* pool, const float* md, const float* mul, int B, const void* desc, float* acts,
+                      float* yfin, float* y, void* stream);
+int sisr_gate_mlp_bwd(const float* dy, const float* md, const float* mul, int B, const void* desc, const float* acts,
+                      const float* yfin, float* workspace, float* dpool, float* dmd, float* dmul, float* const* dw,
+                      float* const* db, void* stream);
+
 /* ---- gated residual: y = t*g[b,c] + shift[b,c] + x  (g, shift, x nullable)
  * ref: the `x * y` / `res += x` tails of CALayer, RCAB, QRCAB, ParamResBlock; with shift it is also the
  * CALayer input gradient dy*g + dL/ds/HW.  gate_dg_partial: per-slice sums of dy*t (t NULL: of dy = GAP). */

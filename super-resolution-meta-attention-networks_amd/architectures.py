@@ -279,8 +279,9 @@ class PALayer(nn.Module):
 
 class QCALayer(nn.Module):
     """ref: attention_manipulators/architectures.py:34-127.  'standard' (the paper's configuration) runs the
-    fused CA kernels; the five metadata-mixing styles finish the HIP global-average-pool with their few-element
-    FC stack in stock torch ops on the device (B x <=74 values) before the HIP gate multiply."""
+    fused CA kernels; the five metadata-mixing styles run the HIP global-average-pool, their whole FC stack as one
+    generic gate-MLP launch (ops.qca_gate) and the HIP gate multiply.  The nn.Conv2d / Softmax children only hold
+    parameters and keep the reference's state-dict keys."""
 
     def __init__(self, channel, style, reduction=16, num_metadata=1):
         super().__init__()
@@ -308,21 +309,19 @@ class QCALayer(nn.Module):
             self.softmax = nn.Softmax(dim=1)
         self.style = style
 
-    def gate_from_pool(self, y, attributes):
+    def gate_convs(self):
         s = self.style
-        if s == 'modulate':
-            return self.conv_du(y) * attributes
-        if s == 'max_concat':
-            return self.conv_du(torch.cat((y, attributes), dim=1))
+        if s in ('modulate', 'max_concat', 'softmax'):
+            return [self.conv_du[0], self.conv_du[2]]
         if s == 'mini_concat':
-            return self.conv_du(torch.cat((self.pre_concat(y), attributes), dim=1))
+            return [self.pre_concat, self.conv_du[1]]
         if s == 'extended_attention':
-            for sec in self.feature_convs:
-                y = sec(torch.cat((y, attributes), dim=1))
-            return self.final_conv(y)
-        if s == 'softmax':
-            return self.softmax(self.conv_du(torch.cat((y, attributes), dim=1)))
+            return [sec[0] for sec in self.feature_convs] + [self.final_conv[0]]
         raise NotImplementedError(s)
+
+    def gate_from_pool(self, y, attributes, mul=None):
+        """pooled vector (B,C,1,1) -> gate (B,C,1,1) [x mul]: the style's whole FC stack in one HIP launch."""
+        return ops.qca_gate(y, attributes, self.style, self.gate_convs(), mul)
 
     def forward(self, x, attributes):
         if self.style == 'standard':
@@ -368,9 +367,7 @@ class QRCAB(nn.Module):
             return y, md
         # metadata-mixing CA styles: conv pair fused, gates composed
         t = ops.res_block_convs(feat, b[0].weight, b[0].bias, b[2].weight, b[2].bias)
-        g = self.final_body.gate_from_pool(ops.global_avg_pool(t), md)
-        if self.q_layer:
-            g = g * m.reshape(g.shape)
+        g = self.final_body.gate_from_pool(ops.global_avg_pool(t), md, m if self.q_layer else None)
         return ops.gate_mul(t, g, feat), md
 
 

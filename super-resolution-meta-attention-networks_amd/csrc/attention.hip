@@ -10,6 +10,7 @@
 // it.  All reductions run in a fixed order (no atomics), so results are run-to-run reproducible.
 // These are M = batch sized contractions (64x4, 10x32x64): VALU + wave shuffles, not MFMA.
 #include "sisr_common.h"
+#include <string.h>
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -301,6 +302,197 @@ __global__ __launch_bounds__(256) void meta_gate_many_bwd_param_kernel(const flo
                            dc1 + l * Hd, dv2 + l * C * Hd, dc2 + l * C);
 }
 
+// ---------------------------------------------------------------- generic gate MLP (the metadata-mixing QCALayer styles)
+// ref: attention_manipulators/architectures.py:105-127.  After the global average pool every style is a 2..4 layer MLP
+// on a <= 74-element vector per sample, with the metadata vector concatenated to some layers' inputs:
+//   modulate            [64 -> 4 relu][4 -> 64 sigmoid]                       then y *= metadata (M == C)
+//   max_concat / softmax [64+M -> 4 relu][4 -> 64 sigmoid]                    (softmax: then softmax over channels)
+//   mini_concat         [64 -> 4][relu(cat(., md)) -> 64 sigmoid]             (the ReLU also hits the metadata)
+//   extended_attention  [64+M -> 32 relu][32+M -> 16 relu][16+M -> 4 relu][4 -> 64 sigmoid]
+// One workgroup per sample, everything in LDS, sums in index order.  An optional per-(b,c) factor `mul` (the block's
+// meta-attention gate) is applied last.  The forward keeps every layer's output (acts) for the backward, which
+// returns d pool, d metadata, d mul and, summed over the batch in batch order, the parameter gradients.
+#define GM_MAXL 4
+#define GM_MAXW 160
+struct GateMlp {
+  const float* w[GM_MAXL];
+  const float* b[GM_MAXL];
+  int nin[GM_MAXL], nout[GM_MAXL], cat[GM_MAXL], relu_in[GM_MAXL], act[GM_MAXL];
+  int L, M, C, final_mode;  // final_mode: 0 none, 1 softmax over channels, 2 multiply by the metadata
+};
+
+__device__ __forceinline__ int gm_acts_width(const GateMlp& d) {
+  int w = d.nin[0];
+  for (int k = 0; k < d.L; ++k) w += d.nout[k];
+  return w;
+}
+
+__global__ __launch_bounds__(256) void gate_mlp_fwd_kernel(const float* __restrict__ pool, const float* __restrict__ md,
+                                                           const float* __restrict__ mul, GateMlp d,
+                                                           float* __restrict__ acts, float* __restrict__ yfin,
+                                                           float* __restrict__ y) {
+  __shared__ float cur[GM_MAXW], nxt[GM_MAXW], mdv[GM_MAXW];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int AW = gm_acts_width(d);
+  float* ab = acts + (long)b * AW;
+  for (int j = t; j < d.nin[0]; j += 256) {
+    const float v = pool[(long)b * d.nin[0] + j];
+    cur[j] = v;
+    ab[j] = v;
+  }
+  for (int j = t; j < d.M; j += 256) mdv[j] = md[(long)b * d.M + j];
+  __syncthreads();
+  int off = d.nin[0];
+  for (int k = 0; k < d.L; ++k) {
+    const int nin = d.nin[k], inw = nin + (d.cat[k] ? d.M : 0), nout = d.nout[k];
+    for (int o = t; o < nout; o += 256) {
+      float z = d.b[k] ? d.b[k][o] : 0.f;
+      const float* wr = d.w[k] + (long)o * inw;
+      for (int j = 0; j < inw; ++j) {
+        float v = j < nin ? cur[j] : mdv[j - nin];
+        if (d.relu_in[k]) v = fmaxf(v, 0.f);
+        z += wr[j] * v;
+      }
+      if (d.act[k] == 1) z = fmaxf(z, 0.f);
+      else if (d.act[k] == 2) z = sigmoidf(z);
+      nxt[o] = z;
+      ab[off + o] = z;
+    }
+    __syncthreads();
+    for (int o = t; o < nout; o += 256) cur[o] = nxt[o];
+    __syncthreads();
+    off += nout;
+  }
+  const int C = d.C;
+  if (d.final_mode == 1) {
+    float mx = -3.402823466e38f;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, cur[c]);
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += expf(cur[c] - mx);
+    for (int c = t; c < C; c += 256) nxt[c] = expf(cur[c] - mx) / sum;
+  } else if (d.final_mode == 2) {
+    for (int c = t; c < C; c += 256) nxt[c] = cur[c] * mdv[c];
+  } else {
+    for (int c = t; c < C; c += 256) nxt[c] = cur[c];
+  }
+  for (int c = t; c < C; c += 256) {
+    const float v = nxt[c];
+    yfin[(long)b * C + c] = v;
+    y[(long)b * C + c] = mul ? v * mul[(long)b * C + c] : v;
+  }
+}
+
+// per sample: dz of every layer into ws [B][ZW] (ZW = sum of nout), d pool, d metadata, d mul
+__global__ __launch_bounds__(256) void gate_mlp_bwd_sample_kernel(const float* __restrict__ dy, const float* __restrict__ md,
+                                                                  const float* __restrict__ mul, GateMlp d,
+                                                                  const float* __restrict__ acts,
+                                                                  const float* __restrict__ yfin, float* __restrict__ ws,
+                                                                  float* __restrict__ dpool, float* __restrict__ dmd,
+                                                                  float* __restrict__ dmul) {
+  __shared__ float dv[GM_MAXW], dz[GM_MAXW], mdv[GM_MAXW], dmda[GM_MAXW], red[2];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int AW = gm_acts_width(d), C = d.C;
+  const int ZW = AW - d.nin[0];
+  const float* ab = acts + (long)b * AW;
+  for (int j = t; j < d.M; j += 256) {
+    mdv[j] = md[(long)b * d.M + j];
+    dmda[j] = 0.f;
+  }
+  for (int c = t; c < C; c += 256) {
+    float g = dy[(long)b * C + c];
+    if (mul) {
+      if (dmul) dmul[(long)b * C + c] = g * yfin[(long)b * C + c];
+      g *= mul[(long)b * C + c];
+    }
+    dv[c] = g;
+  }
+  __syncthreads();
+  const int vL = AW - d.nout[d.L - 1];  // offset of the last layer's output in acts
+  if (d.final_mode == 1) {
+    if (t == 0) {
+      float s = 0.f;
+      for (int c = 0; c < C; ++c) s += dv[c] * yfin[(long)b * C + c];
+      red[0] = s;
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += 256) dz[c] = yfin[(long)b * C + c] * (dv[c] - red[0]);
+    __syncthreads();
+    for (int c = t; c < C; c += 256) dv[c] = dz[c];
+  } else if (d.final_mode == 2) {
+    for (int c = t; c < C; c += 256) {
+      dmda[c] += dv[c] * ab[vL + c];
+      dv[c] = dv[c] * mdv[c];
+    }
+  }
+  __syncthreads();
+  int voff = vL, zoff = ZW;
+  for (int k = d.L - 1; k >= 0; --k) {
+    const int nin = d.nin[k], inw = nin + (d.cat[k] ? d.M : 0), nout = d.nout[k];
+    zoff -= nout;
+    const int inoff = voff - nin;  // offset of this layer's (previous layer's output) input in acts
+    for (int o = t; o < nout; o += 256) {
+      const float v = ab[voff + o];
+      float g = dv[o];
+      if (d.act[k] == 1) g = v > 0.f ? g : 0.f;
+      else if (d.act[k] == 2) g = g * v * (1.f - v);
+      dz[o] = g;
+      ws[(long)b * ZW + zoff + o] = g;
+    }
+    __syncthreads();
+    for (int j = t; j < inw; j += 256) {
+      float g = 0.f;
+      for (int o = 0; o < nout; ++o) g += d.w[k][(long)o * inw + j] * dz[o];
+      const float raw = j < nin ? ab[inoff + j] : mdv[j - nin];
+      if (d.relu_in[k] && !(raw > 0.f)) g = 0.f;
+      if (j < nin) dv[j] = g;
+      else dmda[j - nin] += g;
+    }
+    __syncthreads();
+    voff = inoff;
+  }
+  for (int j = t; j < d.nin[0]; j += 256) dpool[(long)b * d.nin[0] + j] = dv[j];
+  if (dmd)
+    for (int j = t; j < d.M; j += 256) dmd[(long)b * d.M + j] = dmda[j];
+}
+
+// one thread per parameter element of every layer: sum over the batch (batch order) of dz (x) layer input
+struct GateMlpGrads {
+  float* dw[GM_MAXL];
+  float* db[GM_MAXL];
+};
+__global__ __launch_bounds__(256) void gate_mlp_bwd_param_kernel(const float* __restrict__ md, GateMlp d,
+                                                                 const float* __restrict__ acts,
+                                                                 const float* __restrict__ ws, GateMlpGrads g, int B) {
+  const int AW = gm_acts_width(d);
+  const int ZW = AW - d.nin[0];
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  int voff = 0, zoff = 0;
+  for (int k = 0; k < d.L; ++k) {
+    const int nin = d.nin[k], inw = nin + (d.cat[k] ? d.M : 0), nout = d.nout[k];
+    const long nw = (long)nout * inw;
+    if (i < nw + nout) {
+      float acc = 0.f;
+      if (i < nw) {
+        const int o = (int)(i / inw), j = (int)(i - (long)o * inw);
+        for (int b = 0; b < B; ++b) {
+          float v = j < nin ? acts[(long)b * AW + voff + j] : md[(long)b * d.M + (j - nin)];
+          if (d.relu_in[k]) v = fmaxf(v, 0.f);
+          acc += ws[(long)b * ZW + zoff + o] * v;
+        }
+        g.dw[k][i] = acc;
+      } else {
+        const int o = (int)(i - nw);
+        for (int b = 0; b < B; ++b) acc += ws[(long)b * ZW + zoff + o];
+        if (g.db[k]) g.db[k][o] = acc;
+      }
+      return;
+    }
+    i -= nw + nout;
+    voff += nin;
+    zoff += nout;
+  }
+}
+
 // ---------------------------------------------------------------- gated residual: y = t*g[b,c] + shift[b,c] + x
 // t, x, y: contiguous [B][HW][C]; g, shift: [B][C] (nullable -> 1, 0); x nullable.  C % 4 == 0.
 __global__ __launch_bounds__(256) void gate_residual_fwd_kernel(const float* __restrict__ t, const float* __restrict__ g,
@@ -582,6 +774,62 @@ extern "C" int sisr_meta_gate_many_bwd(const float* dm, const float* m, const fl
   const long total = (long)channels * hidden + (long)hidden * M + channels + hidden;
   hipLaunchKernelGGL(meta_gate_many_bwd_param_kernel, dim3((unsigned)((total + 255) / 256), layers), dim3(256), 0,
                      (hipStream_t)stream, dz2, dz1, hid, md, B, M, hidden, channels, dv1, dc1, dv2, dc2);
+  return sisr_check_launch();
+}
+
+// ---- generic gate MLP.  `desc` is a HOST pointer to the struct below (copied into the launch); all arrays device.
+struct sisr_gate_mlp_host {
+  const float* w[GM_MAXL];
+  const float* b[GM_MAXL];
+  int nin[GM_MAXL], nout[GM_MAXL], cat[GM_MAXL], relu_in[GM_MAXL], act[GM_MAXL];
+  int L, M, C, final_mode;
+};
+static int gate_mlp_check(const sisr_gate_mlp_host* h, GateMlp* d) {
+  if (!h || h->L < 1 || h->L > GM_MAXL || h->M < 0 || h->C < 1) return SISR_ERR_ARG;
+  memcpy(d, h, sizeof(GateMlp));
+  int prev = h->nin[0];
+  for (int k = 0; k < h->L; ++k) {
+    if (!h->w[k] || h->nin[k] != prev || h->nout[k] < 1) return SISR_ERR_ARG;
+    if (h->nin[k] + (h->cat[k] ? h->M : 0) > GM_MAXW || h->nout[k] > GM_MAXW) return SISR_ERR_UNSUPPORTED;
+    prev = h->nout[k];
+  }
+  if (prev != h->C || h->M > GM_MAXW) return SISR_ERR_UNSUPPORTED;
+  if (h->final_mode == 2 && h->M != h->C) return SISR_ERR_UNSUPPORTED;
+  return SISR_OK;
+}
+extern "C" size_t sisr_gate_mlp_desc_bytes() { return sizeof(sisr_gate_mlp_host); }
+extern "C" int sisr_gate_mlp_fwd(const float* pool, const float* md, const float* mul, int B, const void* desc,
+                                 float* acts, float* yfin, float* y, void* stream) {
+  GateMlp d;
+  int rc = gate_mlp_check(static_cast<const sisr_gate_mlp_host*>(desc), &d);
+  if (rc) return rc;
+  if (!pool || !acts || !yfin || !y || B <= 0 || (d.M > 0 && !md)) return SISR_ERR_ARG;
+  hipLaunchKernelGGL(gate_mlp_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pool, md, mul, d, acts, yfin, y);
+  return sisr_check_launch();
+}
+extern "C" int sisr_gate_mlp_bwd(const float* dy, const float* md, const float* mul, int B, const void* desc,
+                                 const float* acts, const float* yfin, float* workspace, float* dpool, float* dmd,
+                                 float* dmul, float* const* dw, float* const* db, void* stream) {
+  GateMlp d;
+  int rc = gate_mlp_check(static_cast<const sisr_gate_mlp_host*>(desc), &d);
+  if (rc) return rc;
+  if (!dy || !acts || !yfin || !workspace || !dpool || !dw || !db || B <= 0) return SISR_ERR_ARG;
+  hipLaunchKernelGGL(gate_mlp_bwd_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dy, md, mul, d, acts, yfin,
+                     workspace, dpool, dmd, dmul);
+  rc = sisr_check_launch();
+  if (rc) return rc;
+  GateMlpGrads g;
+  long total = 0;
+  for (int k = 0; k < GM_MAXL; ++k) {
+    g.dw[k] = k < d.L ? dw[k] : nullptr;
+    g.db[k] = k < d.L ? db[k] : nullptr;
+    if (k < d.L) {
+      if (!dw[k]) return SISR_ERR_ARG;
+      total += (long)d.nout[k] * (d.nin[k] + (d.cat[k] ? d.M : 0)) + d.nout[k];
+    }
+  }
+  hipLaunchKernelGGL(gate_mlp_bwd_param_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     md, d, acts, workspace, g, B);
   return sisr_check_launch();
 }
 

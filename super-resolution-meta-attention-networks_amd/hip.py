@@ -75,6 +75,11 @@ _SIGS.update({  # step-level launches (round 2): all conv weights / all meta gat
     "sisr_meta_gate_many_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "sisr_meta_gate_many_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P]),
 })
+_SIGS.update({  # generic gate MLP: the metadata-mixing QCALayer styles (csrc/attention.hip)
+    "sisr_gate_mlp_desc_bytes": (c_size_t, []),
+    "sisr_gate_mlp_fwd": (c_int, [P, P, P, c_int, P, P, P, P, P]),
+    "sisr_gate_mlp_bwd": (c_int, [P, P, P, c_int, P, P, P, P, P, P, P, P, P, P]),
+})
 _SIGS.update({  # SAN attention (csrc/san.hip)
     "sisr_covpool_workspace_bytes": (c_size_t, [c_int, c_long]),
     "sisr_covpool_fwd": (c_int, [P, P, P, P, c_int, c_long, c_int, P]),
@@ -85,6 +90,16 @@ _SIGS.update({  # SAN attention (csrc/san.hip)
     "sisr_nl_attn_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "sisr_nl_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
 })
+
+
+GM_MAXL = 4
+
+
+class GateMlpDesc(ctypes.Structure):
+    """Host mirror of sisr_gate_mlp (include/sisr_hip.h)."""
+    _fields_ = [("w", c_void_p * GM_MAXL), ("b", c_void_p * GM_MAXL), ("nin", c_int * GM_MAXL), ("nout", c_int * GM_MAXL),
+                ("cat", c_int * GM_MAXL), ("relu_in", c_int * GM_MAXL), ("act", c_int * GM_MAXL), ("L", c_int),
+                ("M", c_int), ("C", c_int), ("final_mode", c_int)]
 
 
 class HipLibraryMissing(ImportError):

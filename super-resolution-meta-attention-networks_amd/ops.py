@@ -514,6 +514,101 @@ def meta_gate_many(md, layers, relu):
     return _MetaGateMany.apply(md, bool(relu), *flat).unbind(0)
 
 
+class _GateMlp(Function):
+    """The FC stack of a metadata-mixing QCALayer style on the pooled vector (csrc/attention.hip gate_mlp_*):
+    (pool (B,C,1,1), metadata (B,M,1,1), optional meta gate (B,C)) -> gate (B,C,1,1)."""
+
+    @staticmethod
+    def forward(ctx, pool, md, mul, spec, *params):
+        import ctypes
+        layers, final_mode = spec  # layers: [(cat, relu_in, act)], params: w0, b0, w1, b1, ...
+        B, C0 = pool.shape[0], pool.shape[1]
+        M = md.shape[1]
+        dev = pool.device
+        L = len(layers)
+        d = hip.GateMlpDesc()
+        ws = [params[2 * k].reshape(params[2 * k].shape[0], -1).contiguous() for k in range(L)]
+        bs = [params[2 * k + 1].contiguous() if params[2 * k + 1] is not None else None for k in range(L)]
+        prev = C0
+        for k, (cat, relu_in, act) in enumerate(layers):
+            nout, inw = ws[k].shape
+            if inw != prev + (M if cat else 0):
+                raise RuntimeError(f"gate MLP layer {k}: weight expects {inw} inputs, got {prev + (M if cat else 0)}")
+            d.w[k], d.b[k] = hip.ptr(ws[k]), hip.ptr(bs[k])
+            d.nin[k], d.nout[k], d.cat[k], d.relu_in[k], d.act[k] = prev, nout, int(cat), int(relu_in), int(act)
+            prev = nout
+        d.L, d.M, d.C, d.final_mode = L, M, prev, final_mode
+        p2, md2 = pool.reshape(B, C0).contiguous(), md.reshape(B, M).contiguous()
+        mul2 = mul.reshape(B, prev).contiguous() if mul is not None else None
+        aw = C0 + sum(w.shape[0] for w in ws)
+        acts = torch.empty((B, aw), device=dev, dtype=torch.float32)
+        yfin, y = _vec(B, prev, dev), _vec(B, prev, dev)
+        hip.check(hip.lib().sisr_gate_mlp_fwd(hip.ptr(p2), hip.ptr(md2), hip.ptr(mul2), B, ctypes.addressof(d),
+                                              hip.ptr(acts), hip.ptr(yfin), hip.ptr(y), hip.stream()), "sisr_gate_mlp_fwd")
+        ctx.save_for_backward(md2, mul2, acts, yfin, *ws, *[b for b in bs if b is not None])
+        ctx.cfg = (layers, final_mode, B, C0, M, prev, [tuple(params[2 * k].shape) for k in range(L)],
+                   [b is not None for b in bs], tuple(pool.shape), tuple(md.shape),
+                   tuple(mul.shape) if mul is not None else None)
+        return y.reshape(B, prev, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes
+        layers, final_mode, B, C0, M, C, wshapes, has_b, s_pool, s_md, s_mul = ctx.cfg
+        sv = list(ctx.saved_tensors)
+        md2, mul2, acts, yfin = sv[:4]
+        L = len(layers)
+        ws = sv[4:4 + L]
+        bs_present = sv[4 + L:]
+        dev = acts.device
+        d = hip.GateMlpDesc()
+        prev, bi = C0, 0
+        for k, (cat, relu_in, act) in enumerate(layers):
+            d.w[k] = hip.ptr(ws[k])
+            d.b[k] = hip.ptr(bs_present[bi]) if has_b[k] else None
+            bi += int(has_b[k])
+            d.nin[k], d.nout[k], d.cat[k], d.relu_in[k], d.act[k] = prev, ws[k].shape[0], int(cat), int(relu_in), int(act)
+            prev = ws[k].shape[0]
+        d.L, d.M, d.C, d.final_mode = L, M, C, final_mode
+        dyc = dy.reshape(B, C).contiguous()
+        zw = sum(w.shape[0] for w in ws)
+        wsp = torch.empty((B, zw), device=dev, dtype=torch.float32)
+        dpool = _vec(B, C0, dev)
+        dmd = _vec(B, M, dev) if ctx.needs_input_grad[1] else None
+        dmul = _vec(B, C, dev) if (mul2 is not None and ctx.needs_input_grad[2]) else None
+        dws = [torch.empty(wshapes[k], device=dev, dtype=torch.float32) for k in range(L)]
+        dbs = [torch.empty(ws[k].shape[0], device=dev, dtype=torch.float32) if has_b[k] else None for k in range(L)]
+        PA = ctypes.c_void_p * hip.GM_MAXL
+        dwa = PA(*[hip.ptr(t) for t in dws])
+        dba = PA(*[hip.ptr(t) for t in dbs])
+        hip.check(hip.lib().sisr_gate_mlp_bwd(hip.ptr(dyc), hip.ptr(md2), hip.ptr(mul2), B, ctypes.addressof(d),
+                                              hip.ptr(acts), hip.ptr(yfin), hip.ptr(wsp), hip.ptr(dpool), hip.ptr(dmd),
+                                              hip.ptr(dmul), dwa, dba, hip.stream()), "sisr_gate_mlp_bwd")
+        grads = []
+        for k in range(L):
+            grads += [dws[k], dbs[k]]
+        return (dpool.reshape(s_pool), dmd.reshape(s_md) if dmd is not None else None,
+                dmul.reshape(s_mul) if dmul is not None else None, None, *grads)
+
+
+# (cat metadata, ReLU on the concatenated input, activation 0 none / 1 relu / 2 sigmoid) per layer, final mode
+QCA_STYLES = {
+    "modulate": ([(0, 0, 1), (0, 0, 2)], 2),
+    "max_concat": ([(1, 0, 1), (0, 0, 2)], 0),
+    "softmax": ([(1, 0, 1), (0, 0, 2)], 1),
+    "mini_concat": ([(0, 0, 0), (1, 1, 2)], 0),
+    "extended_attention": ([(1, 0, 1), (1, 0, 1), (1, 0, 1), (0, 0, 2)], 0),
+}
+
+
+def qca_gate(pool, md, style, convs, mul=None):
+    """convs: the style's nn.Conv2d 1x1 layers in order; mul: optional (B,C) meta-attention gate folded in."""
+    params = []
+    for c in convs:
+        params += [c.weight, c.bias]
+    return _GateMlp.apply(pool, md, mul, QCA_STYLES[style], *params)
+
+
 # ----------------------------------------------------------------------------- fused residual block
 class _ResBlock(Function):
     """y = x + gate * res_scale * conv2(relu(conv1(x)));  gate = CA(GAP(.)) [* m] | m | 1."""

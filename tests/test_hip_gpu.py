@@ -4,6 +4,8 @@ Tolerances (fp32 everywhere): the MFMA conv sums K = 576 products in a different
 CPU reference, so outputs agree to ~1e-5 relative; gradients that reduce over all pixels to ~1e-4.
 north_star's bar is 1e-3 dB PSNR on full images; the whole-net tests below assert that too.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -17,6 +19,7 @@ pytestmark = pytest.mark.gpu
 A = sisr_amd.architectures
 ops = sisr_amd.ops
 DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def close(got, want, rtol, atol, msg=""):
@@ -492,9 +495,17 @@ def test_run_train_trajectory_matches_reference(name):
     h = build_gpu(name, eval_mode=False, lr=1e-4, grad_clip=ref["grad_clip"], scheduler=ref["scheduler"],
                   scheduler_params=ref["scheduler_params"])
     g = torch.Generator().manual_seed(77)
-    # Tolerances widen with the step index: Adam's first updates are ~lr*sign(g), so fp32 rounding noise in
-    # near-zero gradients flips individual updates and the trajectories drift apart chaotically (the
-    # reference itself drifts by as much between thread counts).  Step 0 is a pure fwd+bwd comparison.
+    # Flat per-step tolerances (2e-5 loss, 1e-3 gradient norm, 1e-4 output mean) plus, per model and step, four times
+    # what the REFERENCE drifts from ITSELF between torch thread counts (fixtures g4_train_steps_t{1,3}.json, generated
+    # by tools/make_fixtures.py g4t at 1 and 3 threads against the 8-thread G4): EDSR / QEDSR / QRCAN reproduce
+    # themselves to 1e-5, full-depth RCAN at this tile size is chaotic -- its own step-4 loss / gradient norm / output
+    # mean move by 2.9e-5 / 3.4e-4 / 2.7e-4 -- so that is the resolution its trajectory can be compared at.
+    alt = [golden_json(f"g4_train_steps_t{t}")[name]["steps"] for t in (1, 3)]
+
+    def ref_drift(i, key, rel=False):
+        base = ref["steps"][i][key]
+        return max(abs(a[i][key] / base - 1) if rel else abs(a[i][key] - base) for a in alt)
+
     rows = []
     for i, step in enumerate(ref["steps"]):
         x = torch.rand(2, 3, 16, 16, generator=g)
@@ -507,11 +518,18 @@ def test_run_train_trajectory_matches_reference(name):
         assert abs(h.get_learning_rate() - step["lr_after"]) < 1e-12
         rows.append((i, float(loss) - step["loss"], gn / step["grad_norm"] - 1, float(out.mean()) - step["out_mean"]))
     print(name, "trajectory (step, dloss, rel dgradnorm, dmean):", rows)
+    try:
+        import json
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", f"trajectory_{name}.json"), "w") as f:
+            json.dump({"rows": rows, "ref_drift": [(ref_drift(i, "loss"), ref_drift(i, "grad_norm", True),
+                                                    ref_drift(i, "out_mean")) for i in range(len(rows))]}, f)
+    except OSError:
+        pass
     for i, dl, dg, dm in rows:
-        k = 1 + 4 * i
-        assert abs(dl) < 2e-5 * k, rows
-        assert abs(dg) < 1e-3 * k, rows
-        assert abs(dm) < 1e-4 * k, rows
+        assert abs(dl) < 2e-5 + 4 * ref_drift(i, "loss"), rows
+        assert abs(dg) < 1e-3 + 4 * ref_drift(i, "grad_norm", rel=True), rows
+        assert abs(dm) < 1e-4 + 4 * ref_drift(i, "out_mean"), rows
     psum = float(sum(v.double().sum() for v in h.net.state_dict().values()))
     assert abs(psum - ref["final_param_sum"]) < 5e-2
 
@@ -654,15 +672,17 @@ def test_set5_training_psnr_parity_at_equal_steps():
     assert max(abs(d) for d in diffs) < 0.02, diffs
 
 
-def test_set5_training_psnr_parity_meta_rcan():
-    """The same for north_star's target family -- RCAN + meta-attention (QRCAN, style 'standard', q-layers on, reduced
-    to 2 groups x 3 blocks so that the CPU oracle keeps up): 20 Adam steps through the group-level fused node with the
-    blur-kernel metadata of the Set5 example data, then Set5 Y-PSNR within 0.02 dB."""
+@pytest.mark.parametrize("groups,blocks", [(2, 3), (10, 20)])
+def test_set5_training_psnr_parity_meta_rcan(groups, blocks):
+    """The same for north_star's target family -- RCAN + meta-attention (QRCAN, style 'standard', q-layers on), at a
+    reduced depth (2 groups x 3 blocks) and at FULL depth (10 x 20, the BASELINE config): 20 Adam steps through the
+    group-level fused node with the blur-kernel metadata of the Set5 example data, the CPU oracle taking the same steps,
+    then Set5 Y-PSNR within 0.02 dB."""
     import random
     torch.manual_seed(8)
-    kw = dict(metadata=["blur_kernel"], style="standard", include_q_layer=True, n_resgroups=2, n_resblocks=3)
+    kw = dict(metadata=["blur_kernel"], style="standard", include_q_layer=True, n_resgroups=groups, n_resblocks=blocks)
     h = sisr_amd.handlers.available_models["qrcan"](device=0, model_save_dir="/tmp", eval_mode=False, scale=4, lr=1e-4, **kw)
-    cfg = dict(n_resgroups=2, n_resblocks=3, scale=4, style="standard", include_q_layer=True)
+    cfg = dict(n_resgroups=groups, n_resblocks=blocks, scale=4, style="standard", include_q_layer=True)
     tr = O.Trainer("qrcan", {k: v.detach().cpu() for k, v in h.net.state_dict().items()}, lr=1e-4, **cfg)
     data = [(x[0], y[0], md[0]) for _, x, y, md in set5()]
     rng = random.Random(4)
@@ -684,9 +704,9 @@ def test_set5_training_psnr_parity_meta_rcan():
     with torch.no_grad():
         for x, y, m in data:
             out, _, _ = h.run_eval(x[None], metadata=m[None], metadata_keys=[("blur_kernel",)] * 10)
-            ref = O.qrcan(tr.sd, x[None], m.float().view(1, 10, 1, 1), 2, 3, 4, "standard", False, True)
+            ref = O.qrcan(tr.sd, x[None], m.float().view(1, 10, 1, 1), groups, blocks, 4, "standard", False, True)
             diffs.append(sisr_amd.metrics.y_psnr(out[0].numpy(), y.numpy()) - O.y_psnr(ref[0].numpy(), y.numpy()))
-    print("Set5 Y-PSNR (HIP - oracle), meta-RCAN after 20 steps:", diffs)
+    print(f"Set5 Y-PSNR (HIP - oracle), meta-RCAN {groups}x{blocks} after 20 steps:", diffs)
     assert max(abs(d) for d in diffs) < 0.02, diffs
 
 

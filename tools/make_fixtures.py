@@ -246,8 +246,11 @@ def make_g3():
         json.dump(summary, f, indent=1)
 
 
-def make_g4():
-    """run_train trajectories through the reference handlers (full-depth nets, small tiles)."""
+def make_g4(threads=None, fname="g4_train_steps.json"):
+    """run_train trajectories through the reference handlers (full-depth nets, small tiles).
+    threads: run the reference at that torch thread count (G4T: how far the reference drifts from ITSELF)."""
+    if threads is not None:
+        torch.set_num_threads(threads)
     out = {}
     sched = {"scheduler": "cosine_annealing_warm_restarts",
              "scheduler_params": {"t_mult": 1, "restart_period": 3, "lr_min": 1e-7}}
@@ -280,7 +283,11 @@ def make_g4():
         st = model.save_model("x", 0, extract_state_only=True)
         out[name]["ckpt_keys"] = sorted(st.keys())
         out[name]["optimizer_group_keys"] = sorted(st["optimizer"]["param_groups"][0].keys())
-    with open(os.path.join(OUT, "g4_train_steps.json"), "w") as f:
+    if threads is not None:
+        for v in out.values():
+            v["threads"] = threads
+        torch.set_num_threads(8)
+    with open(os.path.join(OUT, fname), "w") as f:
         json.dump(out, f, indent=1)
 
 
@@ -345,6 +352,9 @@ if __name__ == "__main__":
                     ("g7", make_g7)):
         if tag in which:
             fn()
+    if "g4t" in which:  # the same trajectories from the reference at other thread counts (reference-vs-reference drift)
+        make_g4(threads=1, fname="g4_train_steps_t1.json")
+        make_g4(threads=3, fname="g4_train_steps_t3.json")
 
 
 def make_g5():
