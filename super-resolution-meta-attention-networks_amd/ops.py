@@ -31,7 +31,9 @@ CL = torch.channels_last
 # stream once, at the end of the backward pass (autograd engine callback), before anything reads the grads.
 # (Measured +5 % at 16 tiles per GPU when introduced; neutral at 32 with the current kernels -- see DESIGN.md §3.)
 WGRAD_SIDE_STREAM = os.environ.get("SISR_WGRAD_SIDE_STREAM", "1") != "0"
-GRAPH_FORK = os.environ.get("SISR_GRAPH_FORK", "1") != "0"
+# weight gradients as parallel branches of a captured backward: measured SLOWER than one serial stream at 4 tiles per
+# GPU (QRCAN, one-rank RCCL world: 48.0 vs 51.5 patches/s -- every cross-branch edge costs a barrier packet), so off
+GRAPH_FORK = os.environ.get("SISR_GRAPH_FORK", "0") != "0"
 IN_BACKWARD = False  # set while a conv operator's backward runs (bench.py times forward launches only)
 _side_streams = {}
 _join_pending = set()
@@ -96,8 +98,7 @@ def _side_ok(*weights):
     `p.grad += dw` on the main stream before the side-stream kernel has written dw."""
     if not (WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False and all(w.grad is None for w in weights)):
         return False
-    # under hipGraph capture the fork / join become graph edges (parallel branches the GPU may overlap);
-    # SISR_GRAPH_FORK=0 keeps a captured backward on one stream
+    # under hipGraph capture the fork / join would become graph edges (SISR_GRAPH_FORK=1); default: one stream
     return GRAPH_FORK or not torch.cuda.is_current_stream_capturing()
 
 

@@ -495,11 +495,13 @@ def test_run_train_trajectory_matches_reference(name):
     h = build_gpu(name, eval_mode=False, lr=1e-4, grad_clip=ref["grad_clip"], scheduler=ref["scheduler"],
                   scheduler_params=ref["scheduler_params"])
     g = torch.Generator().manual_seed(77)
-    # Flat per-step tolerances (2e-5 loss, 1e-3 gradient norm, 1e-4 output mean) plus, per model and step, four times
-    # what the REFERENCE drifts from ITSELF between torch thread counts (fixtures g4_train_steps_t{1,3}.json, generated
-    # by tools/make_fixtures.py g4t at 1 and 3 threads against the 8-thread G4): EDSR / QEDSR / QRCAN reproduce
-    # themselves to 1e-5, full-depth RCAN at this tile size is chaotic -- its own step-4 loss / gradient norm / output
-    # mean move by 2.9e-5 / 3.4e-4 / 2.7e-4 -- so that is the resolution its trajectory can be compared at.
+    # Flat per-step tolerances -- 5e-6 loss, 1e-4 gradient norm, 5e-5 output mean, the same at every step (measured on
+    # MI355X once the gated skip was made fma-free: <= 9e-7 / 1.9e-5 / 1.1e-5 over all four models and five steps) --
+    # plus, per model and step, what the REFERENCE drifts from ITSELF between torch thread counts (fixtures
+    # g4_train_steps_t{1,3}.json, generated by tools/make_fixtures.py g4t at 1 and 3 threads against the 8-thread G4):
+    # EDSR / QEDSR / QRCAN reproduce themselves to 1e-5, full-depth RCAN at this tile size is chaotic -- its own step-4
+    # loss / gradient norm / output mean move by 2.9e-5 / 3.4e-4 / 2.7e-4 -- and a trajectory cannot be pinned tighter
+    # than the reference pins itself.
     alt = [golden_json(f"g4_train_steps_t{t}")[name]["steps"] for t in (1, 3)]
 
     def ref_drift(i, key, rel=False):
@@ -527,9 +529,9 @@ def test_run_train_trajectory_matches_reference(name):
     except OSError:
         pass
     for i, dl, dg, dm in rows:
-        assert abs(dl) < 2e-5 + 4 * ref_drift(i, "loss"), rows
-        assert abs(dg) < 1e-3 + 4 * ref_drift(i, "grad_norm", rel=True), rows
-        assert abs(dm) < 1e-4 + 4 * ref_drift(i, "out_mean"), rows
+        assert abs(dl) < 5e-6 + ref_drift(i, "loss"), rows
+        assert abs(dg) < 1e-4 + ref_drift(i, "grad_norm", rel=True), rows
+        assert abs(dm) < 5e-5 + ref_drift(i, "out_mean"), rows
     psum = float(sum(v.double().sum() for v in h.net.state_dict().values()))
     assert abs(psum - ref["final_param_sum"]) < 5e-2
 
