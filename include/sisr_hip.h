@@ -251,6 +251,17 @@ int sisr_crop_augment(const float* const* src, const int* params, float* dst, in
 /* ---- diagnostics (not on the product path): sustained fp32-MFMA rate and in-kernel clock ---------- */
 int sisr_diag_mfma_peak(int blocks, int iters, float* out, unsigned long long* clk, void* stream);
 
+/* ---- channel padding and RGB pixel-shuffle (SRMD: conv(3+M -> nc) ... conv(nc -> 3 r^2) + PixelShuffle(r))
+ * ref: advanced/architectures.py:380-425, advanced/SRMD_blocks.py:33-126.  The MFMA convs work on 64-channel chunks:
+ * the (3+M)-channel NCHW input becomes a zero-padded NHWC map, head / tail weights zero-padded OIHW copies (crop != 0:
+ * the inverse, for their gradients), and the tail's NHWC result is shuffled into the NCHW image (adjoint != 0: the
+ * gradient map, padded channels zero). */
+int sisr_nchw_to_nhwc_pad(const float* x, float* y, int B, int C, int H, int W, int C_padded, void* stream);
+int sisr_pad_oihw(const float* src, float* dst, int cout, int cin, int cout_padded, int cin_padded, int taps, int crop,
+                  void* stream);
+int sisr_shuffle_rgb(const float* src, float* dst, int B, int C, int r, int H, int W, int C_padded, int adjoint,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -510,7 +510,22 @@ def chop_forward(run, x, scale, max_pixels=160000, shave=10):
     return out
 
 
-NETS = {"rcan": rcan, "edsr": edsr, "han": han, "san": san, "qrcan": qrcan, "qedsr": qedsr, "qhan": qhan, "qsan": qsan}
+def srmd(sd, x, nb=12, scale=4):
+    """ref: advanced/architectures.py:380-425 with advanced/SRMD_blocks.py:33-126: x is the (3+M)-channel input
+    (RGB + metadata maps); model = [conv, ReLU] x (nb-1), conv, PixelShuffle(scale) -- flat Sequential indices."""
+    y = x
+    for k in range(nb - 1):
+        y = F.relu(conv(sd, f"model.{2 * k}", y))
+    return F.pixel_shuffle(conv(sd, f"model.{2 * (nb - 1)}", y), scale)
+
+
+def sft_channels(x, metadata):
+    """(B, M) metadata -> (B, M, H, W) maps.  ref: attention_manipulators/__init__.py:53-80."""
+    B, _, H, W = x.shape
+    return metadata.reshape(B, -1, 1, 1).to(torch.float32).expand(B, metadata.shape[1], H, W)
+
+
+NETS = {"srmd": srmd, "rcan": rcan, "edsr": edsr, "han": han, "san": san, "qrcan": qrcan, "qedsr": qedsr, "qhan": qhan, "qsan": qsan}
 META_NETS = ("qrcan", "qedsr", "qhan", "qsan")
 
 

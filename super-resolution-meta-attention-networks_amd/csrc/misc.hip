@@ -133,3 +133,104 @@ extern "C" int sisr_crop_augment(const float* const* src, const int* params, flo
                      reinterpret_cast<const CropRec*>(params), dst, C, crop);
   return sisr_check_launch();
 }
+
+// ---------------------------------------------------------------- channel padding / RGB pixel-shuffle (SRMD widening)
+// ref: advanced/architectures.py:380-425 SRMD: conv(3+M -> nc) ... conv(nc -> 3 r^2) + PixelShuffle(r).  The MFMA conv
+// kernels work on 64-channel chunks, so the (3+M)-channel NCHW input is laid out once as a zero-padded NHWC map, the
+// head / tail weights are zero-padded copies, and the tail's 64-channel NHWC result is shuffled into the NCHW RGB image.
+
+// NCHW (B, C, H, W) -> NHWC (B, H, W, Cp), channels >= C zero.  One thread per float4 of the output.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                               long hw, int Cp, long total4) {
+  const int c4n = Cp >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long pix = i / c4n;
+    const int c0 = (int)(i - pix * c4n) * 4;
+    const long b = pix / hw, p = pix - b * hw;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c0 + e < C) v[e] = x[((long)b * C + c0 + e) * hw + p];
+    reinterpret_cast<f32x4*>(y)[i] = v;
+  }
+}
+
+// OIHW weight (co, ci, 3, 3) <-> zero-padded (cop, cip, 3, 3): dir 0 pads (dst = padded), dir 1 crops (dst = real)
+__global__ __launch_bounds__(256) void pad_oihw_kernel(const float* __restrict__ src, float* __restrict__ dst, int co, int ci,
+                                                       int cop, int cip, int taps, int dir) {
+  const long total = dir ? (long)co * ci * taps : (long)cop * cip * taps;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int t = (int)(i % taps);
+    const long r = i / taps;
+    if (dir) {
+      const int o = (int)(r / ci), c = (int)(r - (long)o * ci);
+      dst[i] = src[((long)o * cip + c) * taps + t];
+    } else {
+      const int o = (int)(r / cip), c = (int)(r - (long)o * cip);
+      dst[i] = (o < co && c < ci) ? src[((long)o * ci + c) * taps + t] : 0.f;
+    }
+  }
+}
+
+// PixelShuffle(r) of the first C*r*r channels of an NHWC (B, H, W, Cp) map into NCHW (B, C, rH, rW):
+// out[b][c][r h + i][r w + j] = y[b][h][w][c r^2 + i r + j]; dir 1 is the adjoint (gradient): padded channels <- 0.
+__global__ __launch_bounds__(256) void shuffle_rgb_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int r,
+                                                          int H, int W, int Cp, long total, int dir) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    if (!dir) {  // i indexes the NCHW output
+      const int ow = (int)(i % ((long)W * r));
+      long t = i / ((long)W * r);
+      const int oh = (int)(t % ((long)H * r));
+      t /= (long)H * r;
+      const int c = (int)(t % C);
+      const long b = t / C;
+      const int h = oh / r, ii = oh - h * r, w = ow / r, jj = ow - w * r;
+      dst[i] = src[(((long)b * H + h) * W + w) * Cp + c * r * r + ii * r + jj];
+    } else {  // i indexes the NHWC gradient
+      const int ch = (int)(i % Cp);
+      const long pix = i / Cp;
+      float v = 0.f;
+      if (ch < C * r * r) {
+        const int w = (int)(pix % W);
+        const long t = pix / W;
+        const int h = (int)(t % H);
+        const long b = t / H;
+        const int c = ch / (r * r), q = ch - c * r * r, ii = q / r, jj = q - ii * r;
+        v = src[(((long)b * C + c) * ((long)H * r) + (long)h * r + ii) * ((long)W * r) + (long)w * r + jj];
+      }
+      dst[i] = v;
+    }
+  }
+}
+
+static unsigned misc_blocks(long n) {
+  long b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 65535 ? 65535 : b));
+}
+
+extern "C" int sisr_nchw_to_nhwc_pad(const float* x, float* y, int B, int C, int H, int W, int Cp, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C || (Cp & 3)) return SISR_ERR_ARG;
+  if (!sisr_aligned16(y)) return SISR_ERR_ALIGN;
+  const long total4 = (long)B * H * W * (Cp >> 2);
+  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(misc_blocks(total4)), dim3(256), 0, (hipStream_t)stream, x, y, C,
+                     (long)H * W, Cp, total4);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_pad_oihw(const float* src, float* dst, int cout, int cin, int cout_padded, int cin_padded, int taps,
+                             int crop, void* stream) {
+  if (!src || !dst || cout <= 0 || cin <= 0 || cout_padded < cout || cin_padded < cin || taps <= 0) return SISR_ERR_ARG;
+  const long total = crop ? (long)cout * cin * taps : (long)cout_padded * cin_padded * taps;
+  hipLaunchKernelGGL(pad_oihw_kernel, dim3(misc_blocks(total)), dim3(256), 0, (hipStream_t)stream, src, dst, cout, cin,
+                     cout_padded, cin_padded, taps, crop);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_shuffle_rgb(const float* src, float* dst, int B, int C, int r, int H, int W, int Cp, int adjoint,
+                                void* stream) {
+  if (!src || !dst || B <= 0 || C <= 0 || r <= 0 || H <= 0 || W <= 0 || Cp < C * r * r) return SISR_ERR_ARG;
+  const long total = adjoint ? (long)B * H * W * Cp : (long)B * C * H * r * W * r;
+  hipLaunchKernelGGL(shuffle_rgb_kernel, dim3(misc_blocks(total)), dim3(256), 0, (hipStream_t)stream, src, dst, C, r, H, W,
+                     Cp, total, adjoint);
+  return sisr_check_launch();
+}

@@ -453,6 +453,11 @@ try:  # SAN / QSAN (san.py)
     HANDLERS += [SANHandler, QSANHandler]
 except ImportError:
     pass
+try:  # SRMD (srmd.py)
+    from .srmd import SRMDHandler
+    HANDLERS += [SRMDHandler]
+except ImportError:
+    pass
 # registry key = class name minus 'Handler', lower-cased (ref: models/__init__.py:26-30)
 available_models = {h.__name__.split('Handler')[0].lower(): h for h in HANDLERS}
 

@@ -80,6 +80,11 @@ _SIGS.update({  # generic gate MLP: the metadata-mixing QCALayer styles (csrc/at
     "sisr_gate_mlp_fwd": (c_int, [P, P, P, c_int, P, P, P, P, P]),
     "sisr_gate_mlp_bwd": (c_int, [P, P, P, c_int, P, P, P, P, P, P, P, P, P, P]),
 })
+_SIGS.update({  # channel padding / RGB shuffle for the SRMD widening (csrc/misc.hip)
+    "sisr_nchw_to_nhwc_pad": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "sisr_pad_oihw": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sisr_shuffle_rgb": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+})
 _SIGS.update({  # SAN attention (csrc/san.hip)
     "sisr_covpool_workspace_bytes": (c_size_t, [c_int, c_long]),
     "sisr_covpool_fwd": (c_int, [P, P, P, P, c_int, c_long, c_int, P]),

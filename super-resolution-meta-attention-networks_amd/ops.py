@@ -955,6 +955,176 @@ def res_block_convs(x, w1, b1, w2, b2):
     return _ConvReluConv.apply(x, w1, b1, w2, b2)
 
 
+# ----------------------------------------------------------------------------- plain conv(+ReLU) chains (SRMD)
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def _pad_oihw(w, cop, cip):
+    """(co, ci, kh, kw) -> zero-padded (cop, cip, kh, kw) copy (the weight itself when nothing is to pad)."""
+    co, ci = w.shape[0], w.shape[1]
+    if co == cop and ci == cip:
+        return w.contiguous()
+    taps = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
+    out = torch.empty((cop, cip) + tuple(w.shape[2:]), device=w.device, dtype=torch.float32)
+    hip.check(hip.lib().sisr_pad_oihw(hip.ptr(w.contiguous()), hip.ptr(out), co, ci, cop, cip, taps, 0, hip.stream()),
+              "sisr_pad_oihw")
+    return out
+
+
+def _crop_oihw(wp, shape):
+    """Inverse of _pad_oihw for gradients."""
+    if tuple(wp.shape) == tuple(shape):
+        return wp
+    co, ci = shape[0], shape[1] if len(shape) > 1 else 1
+    taps = shape[2] * shape[3] if len(shape) == 4 else 1
+    out = torch.empty(shape, device=wp.device, dtype=torch.float32)
+    hip.check(hip.lib().sisr_pad_oihw(hip.ptr(wp), hip.ptr(out), co, ci, wp.shape[0], wp.shape[1] if wp.dim() > 1 else 1,
+                                      taps, 1, hip.stream()), "sisr_pad_oihw(crop)")
+    return out
+
+
+class _ConvChain(Function):
+    """y_k = act_k(conv3x3_k(y_{k-1}) + b_k), act = ReLU or identity, as ONE autograd node (ref: the C / CR stacks of
+    advanced/SRMD_blocks.py:33-126 behind advanced/architectures.py:380-425 SRMD).  Input: channels-last map whose channel
+    count is a multiple of 64 (zero-padded); weights keep their OIHW shapes and are zero-padded to 64-multiples per step;
+    the output has the last layer's padded channel count.  Backward: the ReLU mask of layer k-1 is applied by the epilogue
+    of layer k's input-gradient conv, so no gradient map is touched by an elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x, relus, *params):
+        n = len(relus)
+        B, C0, H, W = x.shape
+        if C0 % 64:
+            raise NotImplementedError("conv chain input must be zero-padded to a multiple of 64 channels")
+        dev = x.device
+        x = _cl(x)
+        _join_pending.clear()
+        cur, cin_p = x, C0
+        maps, packs, geo = [], [], []
+        for k in range(n):
+            w, b = params[2 * k], params[2 * k + 1]
+            co, ci = w.shape[0], w.shape[1]
+            cop = _pad64(co)
+            if ci > cin_p:
+                raise RuntimeError(f"conv chain layer {k}: weight takes {ci} channels, the map has {cin_p}")
+            wp = _pad_oihw(w, cop, cin_p)
+            bp = _pad_oihw(b.reshape(co, 1), cop, 1).reshape(cop) if b is not None else None
+            pf, pd = pack_pair(wp)
+            y = _empty_cl(B, cop, H, W, dev)
+            conv_c64(cur, hip.view_plain(H, W, cin_p), pf, bp, (1, 64), y, hip.view_plain(H, W, cop), B, H, W, cin_p, cop,
+                     relu=bool(relus[k]))
+            maps.append(cur)
+            packs.append(pd)
+            geo.append((cin_p, cop, tuple(w.shape), b is not None))
+            cur, cin_p = y, cop
+        if relus[-1]:
+            raise NotImplementedError("conv chain: the last layer must be linear (its gradient arrives unmasked)")
+        ctx.save_for_backward(*maps, *[params[2 * k] for k in range(n)])
+        ctx.cfg = (n, tuple(relus), (B, H, W), geo)
+        ctx.packs = packs
+        return cur
+
+    @staticmethod
+    def backward(ctx, dy):
+        global IN_BACKWARD
+        IN_BACKWARD = True
+        try:
+            n, relus, (B, H, W), geo = ctx.cfg
+            sv = list(ctx.saved_tensors)
+            maps, ws = sv[:n], sv[n:]
+            dev = dy.device
+            g = _cl(dy)
+            side = _side_ok(*ws)
+            grads = [None] * (2 * n)
+            for k in range(n - 1, -1, -1):
+                cin_p, cop, wshape, has_b = geo[k]
+                xin = maps[k]
+                padded = (cop, cin_p) != (wshape[0], wshape[1])
+                dwp = torch.empty((cop, cin_p, 3, 3), device=dev) if padded else _grad_buf(ws[k])
+                dbp = torch.empty(cop, device=dev) if has_b else None
+
+                def wg(xin=xin, g=g, dwp=dwp, dbp=dbp, cin_p=cin_p, cop=cop):
+                    wgrad_c64(xin, hip.view_plain(H, W, cin_p), g, hip.view_plain(H, W, cop), dwp, dbp, B, H, W, cin_p, cop)
+
+                if side:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    _on_side(dev, ev, wg, (xin, g, dwp, dbp))
+                else:
+                    wg()
+                if k > 0 or ctx.needs_input_grad[0]:
+                    gin = _empty_cl(B, cin_p, H, W, dev)
+                    conv_c64(g, hip.view_plain(H, W, cop), ctx.packs[k], None, (1, 64), gin, hip.view_plain(H, W, cin_p), B, H,
+                             W, cop, cin_p, mask=(xin if (k > 0 and relus[k - 1]) else None))
+                else:
+                    gin = None
+                if padded:  # the crop reads what the (possibly side-stream) weight gradient wrote
+                    if side:
+                        def crop(dwp=dwp, dbp=dbp, k=k, wshape=wshape, has_b=has_b):
+                            grads[2 * k] = _crop_oihw(dwp, wshape)
+                            grads[2 * k + 1] = _crop_oihw(dbp.reshape(-1, 1), (wshape[0], 1)).reshape(wshape[0]) if has_b else None
+                        with torch.cuda.stream(side_stream(dev)):
+                            crop()
+                            for t in (grads[2 * k], grads[2 * k + 1]):
+                                if t is not None:
+                                    t.record_stream(torch.cuda.current_stream(dev))
+                    else:
+                        grads[2 * k] = _crop_oihw(dwp, wshape)
+                        grads[2 * k + 1] = _crop_oihw(dbp.reshape(-1, 1), (wshape[0], 1)).reshape(wshape[0]) if has_b else None
+                else:
+                    grads[2 * k], grads[2 * k + 1] = dwp, dbp
+                g = gin
+            return (g if ctx.needs_input_grad[0] else None, None, *grads)
+        finally:
+            IN_BACKWARD = False
+
+
+def conv_chain(x, layers):
+    """layers: [(weight, bias, relu)] -> channels-last map with the last layer's (64-padded) channel count."""
+    flat = []
+    for w, b, _ in layers:
+        flat += [w, b]
+    return _ConvChain.apply(x, tuple(bool(r) for _, _, r in layers), *flat)
+
+
+def nchw_to_nhwc_pad(x, cp=None):
+    """(B, C, H, W) contiguous NCHW -> channels-last (B, cp, H, W) map, channels >= C zero (no gradient: network input)."""
+    if x.requires_grad:
+        raise NotImplementedError("nchw_to_nhwc_pad is the network-input layout step and returns no gradient")
+    B, C, H, W = x.shape
+    cp = _pad64(C) if cp is None else cp
+    y = _empty_cl(B, cp, H, W, x.device)
+    hip.check(hip.lib().sisr_nchw_to_nhwc_pad(hip.ptr(x.contiguous()), hip.ptr(y), B, C, H, W, cp, hip.stream()),
+              "sisr_nchw_to_nhwc_pad")
+    return y
+
+
+class _ShuffleRGB(Function):
+    """PixelShuffle(r) of the first C r^2 channels of a channels-last map into an NCHW (B, C, rH, rW) image."""
+
+    @staticmethod
+    def forward(ctx, y, C, r):
+        B, Cp, H, W = y.shape
+        y = _cl(y)
+        out = torch.empty((B, C, H * r, W * r), device=y.device, dtype=torch.float32)
+        hip.check(hip.lib().sisr_shuffle_rgb(hip.ptr(y), hip.ptr(out), B, C, r, H, W, Cp, 0, hip.stream()), "sisr_shuffle_rgb")
+        ctx.geo = (B, C, r, H, W, Cp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C, r, H, W, Cp = ctx.geo
+        dy = _empty_cl(B, Cp, H, W, dout.device)
+        hip.check(hip.lib().sisr_shuffle_rgb(hip.ptr(dout.contiguous()), hip.ptr(dy), B, C, r, H, W, Cp, 1, hip.stream()),
+                  "sisr_shuffle_rgb(adjoint)")
+        return dy, None, None
+
+
+def shuffle_rgb(y, channels, r):
+    return _ShuffleRGB.apply(y, int(channels), int(r))
+
+
 # ----------------------------------------------------------------------------- stand-alone gates
 def _pixel_sums(t, other, B, H, W):
     """[B][parts][64] ordered partial sums of t*other (other None: of t)."""
