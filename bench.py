@@ -234,9 +234,10 @@ def main():
                     help=f"replay forward+backward as a hipGraph (auto: per-GPU batch <= {GRAPH_MAX_BATCH})")
     ap.add_argument("--force-dp", action="store_true",
                     help="N = 1 only: run through a one-rank RCCL world (GradReducer buckets, all_reduce, join)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="arithmetic of the 64-channel convs: fp32 MFMA (reference arithmetic, the headline) or bf16 "
-                         "MFMA operands with fp32 accumulate / storage (BASELINE config 'HAN x4 bf16')")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
+                    help="arithmetic of the 64-channel convs: fp32 MFMA (reference arithmetic, the headline); bf16 MFMA "
+                         "operands with fp32 accumulate / storage (BASELINE config 'HAN x4 bf16'); bf16x3 = fp32 operands "
+                         "split exactly into three bf16 numbers, six products on the bf16 MFMA (fp32-class error)")
     args = ap.parse_args()
 
     import importlib
@@ -292,7 +293,9 @@ def main():
             "metric": "LR-patches/sec (128x128x3, x4) fwd+bwd", "value": value, "unit": "patches/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands, f32 accumulate and storage",
+            "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands, f32 accumulate and storage",
+                      "bf16x3": "f32 via bf16x3 split (six bf16 MFMA products per f32 product), f32 accumulate and storage; "
+                                "weight gradients on the f32 MFMA"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{label} x4 full depth, 128x128 LR -> 512x512 tiles, train step = "
                                    f"fwd + L1 + bwd + Adam + scheduler", "per_gpu_batch": B, "global_batch": B * world,
@@ -320,6 +323,13 @@ def main():
                 line["roofline"]["secondary"] = {"bound": "hbm", "what": "whole step, algorithmic bytes per patch x "
                                                  "patches/s per GPU", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                                  "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        elif args.precision == "bf16x3":
+            peak = 2500.0 / 6.0  # dense bf16 MFMA peak / six products per fp32 product
+            line["roofline"] = {"bound": "mfma", "what": "whole step, fp32-equivalent algorithmic TFLOP/s per GPU against the "
+                                "dense bf16 MFMA peak / 6 (forward and input-gradient convs; the weight gradients still run "
+                                "on the 157.3 TFLOP/s fp32 MFMA)", "achieved": step_tf, "peak": peak, "unit": "TFLOP/s",
+                                "frac": step_tf / peak, "traffic": None,
+                                "vs_fp32_mfma_peak": step_tf / FP32_MFMA_PEAK_TFLOPS}
         else:
             # bf16 mode: every conv moves two fp32 maps per launch and ~15 us of MFMA: HBM-bound
             gbs = value / world * HBM_GB_PER_PATCH.get(workload, 16.5)

@@ -51,8 +51,8 @@ int sisr_pack_conv3x3_both(const float* w, float* packed_fwd, float* packed_dgra
 /* every conv weight of a network in ONE launch (a training step repacks them all after the optimiser update).
  * jobs_device: device array of n_jobs records {const float* w; void* packed_fwd; void* packed_dgrad; int32 cout, cin,
  * shuffle_r, first_block} (sisr_pack_job_bytes() each; the caller builds it once per network); job j owns blocks
- * [first_block_j, first_block_j+1) of 256 packed elements each; total_blocks = their sum.  bf16 != 0: the bf16
- * packings of sisr_pack_conv3x3_bf16_both. */
+ * [first_block_j, first_block_j+1) of 256 packed elements each; total_blocks = their sum.  bf16 = 1: the bf16
+ * packings of sisr_pack_conv3x3_bf16_both; 2: the three-plane packings of sisr_pack_conv3x3_x3_both. */
 size_t sisr_pack_job_bytes(void);
 int sisr_pack_conv3x3_many(const void* jobs_device, int n_jobs, int total_blocks, int bf16, void* stream);
 int sisr_conv3x3_c64_gap_parts(int H, int W);
@@ -250,6 +250,19 @@ int sisr_crop_augment(const float* const* src, const int* params, float* dst, in
 
 /* ---- diagnostics (not on the product path): sustained fp32-MFMA rate and in-kernel clock ---------- */
 int sisr_diag_mfma_peak(int blocks, int iters, float* out, unsigned long long* clk, void* stream);
+
+/* ---- fp32 through the bf16 matrix cores ("bf16x3", opt-in; the reference has no such mode) -----------------------
+ * Same contract as sisr_conv3x3_c64_bf16, but every fp32 operand is split exactly into three bf16 numbers (hi + mid +
+ * lo) and the six products of weight >= 2^-16 run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (hi*hi and the
+ * five corrections in separate accumulators): fp32-class error (the dropped products are <= 2^-24 relative each) at
+ * 6/16 of the fp32 MFMA's cycles.  Packed weights: three bf16 planes, cout*cin*9 elements apart. */
+int sisr_pack_conv3x3_x3_both(const float* w, void* packed_fwd, void* packed_dgrad, int cout, int cin, int shuffle_r,
+                              void* stream);
+int sisr_conv3x3_c64_x3(const float* x, const int64_t* xview, const void* wpacked_x3, const float* bias, int bias_n,
+                        int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,
+                        const float* in_scale, const float* in_shift, const float* out_scale, float alpha, int relu,
+                        float* gap_partial, const float* gate_add, float* gate_out, const float* dot, int B, int H,
+                        int W, int cin, int cout, void* stream);
 
 /* ---- channel padding and RGB pixel-shuffle (SRMD: conv(3+M -> nc) ... conv(nc -> 3 r^2) + PixelShuffle(r))
  * ref: advanced/architectures.py:380-425, advanced/SRMD_blocks.py:33-126.  The MFMA convs work on 64-channel chunks:

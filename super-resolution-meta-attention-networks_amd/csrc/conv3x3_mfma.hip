@@ -738,6 +738,307 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) 
   }
 }
 
+// ------------------------------------------------------------------ fp32 through the bf16 matrix cores ("bf16x3")
+// Every fp32 value is the exact sum of three bf16 numbers  x = hi + mid + lo  (24 = 3 x 8 significand bits:
+// hi = rne(x), mid = rne(x - hi), lo = x - hi - mid, each difference exact in fp32).  A product x*w is then the sum
+// of nine exact bf16 x bf16 products; the six with weight >= 2^-16 relative -- hi*hi, hi*mid, mid*hi, hi*lo, lo*hi,
+// mid*mid -- run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the three dropped ones are <= 2^-24 |x||w| each,
+// the size of fp32's own rounding of the product), at 6/16 of the fp32 MFMA's cycle count.  hi*hi accumulates into
+// its own register set and the five corrections into another, added once at the end, so the small terms are not
+// rounded against the large running sum.  Opt-in (SISR_PRECISION=bf16x3); the headline path stays exact fp32.
+// Same tile / wave geometry, staging thread map, LDS swizzle and epilogue as conv3x3_c64_bf16_kernel; the halo is
+// staged as three bf16 planes (78 KB, two workgroups per CU) and the packed weights as three planes `wplane` bytes apart.
+#define X3_PLANE (HALO_H * HALO_W * BH_PIX)
+
+__device__ __forceinline__ void sisr_split3(f32x4 a, f32x4 b, u32x4& hi, u32x4& mid, u32x4& lo) {
+  bf16x8 h, m, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = e < 4 ? a[e] : b[e - 4];
+    const __bf16 xh = (__bf16)x;
+    const float r1 = x - (float)xh;
+    const __bf16 xm = (__bf16)r1;
+    const float r2 = r1 - (float)xm;
+    h[e] = xh;
+    m[e] = xm;
+    l[e] = (__bf16)r2;
+  }
+  hi = __builtin_bit_cast(u32x4, h);
+  mid = __builtin_bit_cast(u32x4, m);
+  lo = __builtin_bit_cast(u32x4, l);
+}
+
+__device__ __forceinline__ void sisr_store_split3(unsigned char* dst, f32x4 a, f32x4 b, unsigned mask) {
+  u32x4 hi, mid, lo;
+  sisr_split3(a, b, hi, mid, lo);
+  const u32x4 mk = {mask, mask, mask, mask};
+  *reinterpret_cast<u32x4*>(dst) = hi & mk;
+  *reinterpret_cast<u32x4*>(dst + X3_PLANE) = mid & mk;
+  *reinterpret_cast<u32x4*>(dst + 2 * X3_PLANE) = lo & mk;
+}
+
+template <bool AFFINE, bool MASK, bool RES, bool GATE = false, bool DOT = false>
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, long wplane) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = blockIdx.y;
+  int bid;
+  {
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const unsigned qn = nb >> 3, rn = nb & 7;
+    bid = (int)((xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx);
+  }
+  const int tw = bid % p.tiles_w;
+  bid /= p.tiles_w;
+  const int th = bid % p.tiles_h;
+  const int b = bid / p.tiles_h;
+  const int h0 = th * TH, w0 = tw * TW;
+  const int ph = __builtin_amdgcn_readfirstlane(wave >> 1), ch = __builtin_amdgcn_readfirstlane(wave & 1);
+  const int n = lane & 31, hh = lane >> 5;
+  const int H = p.H, W = p.W;
+  const int co = ch * 32 + n;
+  const int Cout = p.cout_chunks * 64;
+
+  const float bv = p.bias ? p.bias[co * p.bias_n + q * p.bias_q] : 0.f;
+  f32x16 acc0, acc1, cor0 = {0}, cor1 = {0};  // hi*hi products / the five correction products
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = bv;
+
+  // lane constants of the A reads: byte offset of (halo row 2ph, column n+kw, chunk 2kb+hh)
+  unsigned aoff[3][4];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+      aoff[kw][kb] = ((2 * ph) * HALO_W + n + kw) * BH_PIX + (((2 * kb + hh) ^ (((n + kw) >> 1) & 7)) << 4);
+  const unsigned boff = (hh * 64 + co) * 16;  // bytes
+
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w);
+  for (int c = 0; c < p.cin_chunks; ++c) {
+    if (c) __syncthreads();
+    {  // ---- halo staging: thread = (8-channel chunk c8, column pcol [+32]); rows in two batches of three
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
+      const int c8 = tl & 7, pcol = tl >> 3;
+      const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(c);
+      f32x4 s4a = {1.f, 1.f, 1.f, 1.f}, s4b = s4a, t4a = {0.f, 0.f, 0.f, 0.f}, t4b = t4a;
+      if (AFFINE) {
+        const float* sp = p.in_scale + ((long)b * p.cin_chunks + c) * 64 + c8 * 8;
+        s4a = *reinterpret_cast<const f32x4*>(sp);
+        s4b = *reinterpret_cast<const f32x4*>(sp + 4);
+        if (p.in_shift) {
+          const float* tp = p.in_shift + ((long)b * p.cin_chunks + c) * 64 + c8 * 8;
+          t4a = *reinterpret_cast<const f32x4*>(tp);
+          t4b = *reinterpret_cast<const f32x4*>(tp + 4);
+        }
+      }
+      unsigned goff[2], loff[2];
+      bool cok[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int col = pcol + 32 * k;
+        const int gw = w0 - 1 + col;
+        cok[k] = gw >= 0 && gw < W && col < HALO_W;
+        goff[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c8 * 8);
+        loff[k] = col * BH_PIX + ((c8 ^ ((col >> 1) & 7)) << 4);
+      }
+      if (!GATE) {
+#pragma unroll
+        for (int r0 = 0; r0 < HALO_H; r0 += 3) {
+          f32x4 v[3][2][2];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int gh = h0 - 1 + r0 + r;
+            const float* xrow = xb + (long)min(max(gh, 0), H - 1) * p.xv.sH;  // scalar
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              if (k == 0 || pcol < 2) {
+                v[r][k][0] = *reinterpret_cast<const f32x4*>(xrow + goff[k]);
+                v[r][k][1] = *reinterpret_cast<const f32x4*>(xrow + goff[k] + 4);
+              }
+          }
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int gh = h0 - 1 + r0 + r;
+            const bool rok = gh >= 0 && gh < H;  // scalar
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              if (k == 0 || pcol < 2) {
+                f32x4 ta = v[r][k][0], tb = v[r][k][1];
+                if (AFFINE) {
+                  ta = ta * s4a + t4a;
+                  tb = tb * s4b + t4b;
+                }
+                const unsigned m = (rok && cok[k]) ? 0xffffffffu : 0u;
+                sisr_store_split3(ldsb + (r0 + r) * (HALO_W * BH_PIX) + loff[k], ta, tb, m);
+              }
+          }
+        }
+      } else {  // GATE: u = t * gate + skip in fp32, written out once by the owning tile, then rounded for the MFMA
+        const float* gp = p.in_scale + (long)b * 64 + c8 * 8;
+        const f32x4 g4a = *reinterpret_cast<const f32x4*>(gp), g4b = *reinterpret_cast<const f32x4*>(gp + 4);
+        const long boffs = (long)b * p.xv.sB;
+#pragma unroll
+        for (int r0 = 0; r0 < HALO_H; r0 += 2) {
+          f32x4 v[2][2][2], u[2][2][2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const long ro = boffs + (long)min(max(h0 - 1 + r0 + r, 0), H - 1) * p.xv.sH;  // scalar
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              if (k == 0 || pcol < 2) {
+                v[r][k][0] = *reinterpret_cast<const f32x4*>(p.x + ro + goff[k]);
+                v[r][k][1] = *reinterpret_cast<const f32x4*>(p.x + ro + goff[k] + 4);
+                u[r][k][0] = *reinterpret_cast<const f32x4*>(p.gate_add + ro + goff[k]);
+                u[r][k][1] = *reinterpret_cast<const f32x4*>(p.gate_add + ro + goff[k] + 4);
+              }
+          }
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int hr = r0 + r, gh = h0 - 1 + hr;
+            const bool rok = gh >= 0 && gh < H;              // scalar
+            const bool rown = hr >= 1 && hr <= TH && gh < H;  // scalar
+            const long ro = boffs + (long)min(max(gh, 0), H - 1) * p.xv.sH;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              if (k == 0 || pcol < 2) {
+                const f32x4 ta = sisr_mul_add4(v[r][k][0], g4a, u[r][k][0]), tb = sisr_mul_add4(v[r][k][1], g4b, u[r][k][1]);
+                const int col = pcol + 32 * k;
+                if (rown && cok[k] && col >= 1 && col <= TW) {
+                  *reinterpret_cast<f32x4*>(p.gate_out + ro + goff[k]) = ta;
+                  *reinterpret_cast<f32x4*>(p.gate_out + ro + goff[k] + 4) = tb;
+                }
+                const unsigned m = (rok && cok[k]) ? 0xffffffffu : 0u;
+                sisr_store_split3(ldsb + hr * (HALO_W * BH_PIX) + loff[k], ta, tb, m);
+              }
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- K loop: 36 steps (tap t = s >> 2, 16-channel block kb = s & 3); per step and M-tile six MFMAs:
+    // hi*hi into the main accumulator, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid into the correction accumulator
+    const unsigned char* wq = wbase + ((long)q * p.cin_chunks + c) * (36 * 2048);  // scalar
+#define BF_LOAD_B(s, pl) (*reinterpret_cast<const bf16x8*>(wq + (pl) * wplane + (s) * 2048 + boff))
+#define BF_LOAD_A(m, s, pl) \
+  (*reinterpret_cast<const bf16x8*>(ldsb + (pl) * X3_PLANE + ((((s) >> 2) / 3 + (m)) * (HALO_W * BH_PIX)) + aoff[((s) >> 2) % 3][(s) & 3]))
+    bf16x8 bq[4][3];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bq[s][pl] = BF_LOAD_B(s, pl);
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+      const bf16x8 bh = bq[s & 3][0], bm = bq[s & 3][1], bl = bq[s & 3][2];
+      if (s + 4 < 36) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bq[s & 3][pl] = BF_LOAD_B(s + 4, pl);
+      }
+      const bf16x8 a0h = BF_LOAD_A(0, s, 0), a1h = BF_LOAD_A(1, s, 0);
+      const bf16x8 a0m = BF_LOAD_A(0, s, 1), a1m = BF_LOAD_A(1, s, 1);
+      const bf16x8 a0l = BF_LOAD_A(0, s, 2), a1l = BF_LOAD_A(1, s, 2);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, bh, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, bh, acc1, 0, 0, 0);
+      cor0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, bm, cor0, 0, 0, 0);
+      cor1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, bm, cor1, 0, 0, 0);
+      cor0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0m, bh, cor0, 0, 0, 0);
+      cor1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1m, bh, cor1, 0, 0, 0);
+      cor0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, bl, cor0, 0, 0, 0);
+      cor1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, bl, cor1, 0, 0, 0);
+      cor0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, bh, cor0, 0, 0, 0);
+      cor1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, bh, cor1, 0, 0, 0);
+      cor0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0m, bm, cor0, 0, 0, 0);
+      cor1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1m, bm, cor1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // keep each step's fragment loads next to it (register budget)
+    }
+#undef BF_LOAD_A
+#undef BF_LOAD_B
+  }
+
+  acc0 += cor0;
+  acc1 += cor1;
+  // ---- epilogue.  The kernel is HBM-bound, so output / mask / residual traffic must move as whole 256-B pixel
+  // rows: the accumulators (column = cout on the lane, 16 pixel columns in registers) are transposed through LDS
+  // and every thread then handles float4 pieces of eight pixels, all of its loads in flight at once.
+  float os = p.alpha;
+  if (p.out_scale) os *= p.out_scale[(long)b * Cout + q * 64 + co];
+  const float lo = p.relu ? 0.f : -3.402823466e38f;
+  float* ot = reinterpret_cast<float*>(ldsb);  // [TH*TW pixels][64] fp32, row stride BE_LD
+  __syncthreads();                              // every wave is done reading the halo
+  float grow[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    float gsum = 0.f;
+    const f32x16 acc = m ? acc1 : acc0;
+    const int prow = (2 * ph + m) * TW;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pc = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float v = fmaxf(acc[r], lo) * os;
+      ot[(prow + pc) * BE_LD + co] = v;
+      if (h0 + 2 * ph + m < H && w0 + pc < W) gsum += v;
+    }
+    grow[m] = gsum + __shfl_xor(gsum, 32);
+  }
+  if (!DOT && p.gap) {  // only offered without mask / residual (host checks): v above is the final value
+    if (hh == 0) {
+      const int tile = th * p.tiles_w + tw;
+      const long parts = (long)p.tiles_w * p.tiles_h * 2;
+      p.gap[(((long)b * parts) + tile * 2 + ph) * Cout + q * 64 + co] = grow[0] + grow[1];
+    }
+  }
+  __syncthreads();
+  {
+    const int c4 = tid & 15, pr = tid >> 4;  // pixel pr + 16 i  ->  tile row i >> 1, column pr + 16 (i & 1)
+    const long tile_base = (long)b * p.yv.sB + p.yv.chunk(q) + (long)w0 * p.yv.sW + c4 * 4;
+    f32x4 rv[8], mv[8], dv[8];
+    bool ok[8];
+    long off[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = h0 + (i >> 1), col = pr + 16 * (i & 1);
+      ok[i] = row < H && w0 + col < W;
+      off[i] = tile_base + (long)min(row, H - 1) * p.yv.sH + (long)min(col, W - 1 - w0) * p.yv.sW;
+      if (RES) rv[i] = *reinterpret_cast<const f32x4*>(p.res + off[i]);
+      if (MASK) mv[i] = *reinterpret_cast<const f32x4*>(p.mask + off[i]);
+      if (DOT) dv[i] = *reinterpret_cast<const f32x4*>(p.dot + off[i]);
+    }
+    f32x4 dsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // DOT: per 2-row strip (i < 4 / i >= 4)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(ot + (pr + 16 * i) * BE_LD + c4 * 4);
+      if (MASK) {
+        v[0] = mv[i][0] > 0.f ? v[0] : 0.f;
+        v[1] = mv[i][1] > 0.f ? v[1] : 0.f;
+        v[2] = mv[i][2] > 0.f ? v[2] : 0.f;
+        v[3] = mv[i][3] > 0.f ? v[3] : 0.f;
+      }
+      if (RES) v += rv[i];
+      if (ok[i]) {
+        *reinterpret_cast<f32x4*>(p.y + off[i]) = v;
+        if (DOT) dsum[i >> 2] += v * dv[i];
+      }
+    }
+    if (DOT) {  // sum(v * dot) per strip and channel: the 16 pixel-column threads of a channel quad, in order
+      __syncthreads();  // everyone is done with the transpose buffer
+      float* red = ot;  // [2 strips][16][64]
+      *reinterpret_cast<f32x4*>(red + (0 * 16 + pr) * 64 + c4 * 4) = dsum[0];
+      *reinterpret_cast<f32x4*>(red + (1 * 16 + pr) * 64 + c4 * 4) = dsum[1];
+      __syncthreads();
+      if (tid < 128) {
+        const int strip = tid >> 6, chn = tid & 63;
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sacc += red[(strip * 16 + j) * 64 + chn];
+        const int tile = th * p.tiles_w + tw;
+        const long parts = (long)p.tiles_w * p.tiles_h * 2;
+        p.gap[(((long)b * parts) + tile * 2 + strip) * Cout + q * 64 + chn] = sacc;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ persistent bf16 kernel (64 -> 64)
 // PMC showed the kernel above to be bound by memory-level parallelism: a workgroup has its halo loads in flight
 // for ~15 % of its life, so a CU keeps ~22 KB outstanding -- enough for ~3 TB/s.  Here a workgroup walks tiles
@@ -1024,6 +1325,49 @@ __global__ void pack_conv3x3_bf16_both_kernel(const float* __restrict__ w, __bf1
   }
 }
 
+__device__ __forceinline__ void sisr_store_w3(__bf16* dst, long idx, long total, float x) {
+  const __bf16 xh = (__bf16)x;
+  const float r1 = x - (float)xh;
+  const __bf16 xm = (__bf16)r1;
+  dst[idx] = xh;
+  dst[idx + total] = xm;
+  dst[idx + 2 * total] = (__bf16)(r1 - (float)xm);
+}
+
+// bf16x3 packings: the bf16 element order of pack_conv3x3_bf16_both_kernel, three planes (hi, mid, lo) `total`
+// elements apart, for the forward and the input-gradient order.
+__global__ void pack_conv3x3_x3_both_kernel(const float* __restrict__ w, __bf16* __restrict__ pf, __bf16* __restrict__ pd,
+                                            int cout, int cin, int r) {
+  const long total = (long)cout * cin * 9;
+  const int rr = r * r;
+  const int oc = cout >> 6, ic = cin >> 6;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long t_ = idx;
+    const int j = t_ & 7;
+    t_ >>= 3;
+    const int n = t_ & 63;
+    t_ >>= 6;
+    const int h = t_ & 1;
+    t_ >>= 1;
+    const int s = t_ % 36;
+    t_ /= 36;
+    const int t = s >> 2;
+    const int k = 16 * (s & 3) + 8 * h + j;
+    {
+      const int c = t_ % ic, q = t_ / ic;
+      const long o = r > 1 ? (long)n * rr + q : (long)q * 64 + n;
+      const long i = (long)c * 64 + k;
+      sisr_store_w3(pf, idx, total, w[(o * cin + i) * 9 + t]);
+    }
+    {
+      const int c = t_ % oc, q = t_ / oc;
+      const long i = (long)q * 64 + n;
+      const long o = r > 1 ? (long)k * rr + c : (long)c * 64 + k;
+      sisr_store_w3(pd, idx, total, w[(o * cin + i) * 9 + (8 - t)]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ weight packing
 // packed[q][c][t][j][h][co][e] = w[o*so + i*si + t'],  o = co*on + q*oq,  i = (8j+4h+e)*in_ + c*iq,
 // t' = flip ? 8-t : t.  One thread per packed element.
@@ -1131,7 +1475,7 @@ struct PackJob {
   int cout, cin, r, first_block;
 };
 
-template <bool BF16>
+template <int MODE>  // 0 fp32, 1 bf16, 2 bf16x3 (three planes `total` elements apart)
 __global__ __launch_bounds__(256) void pack_conv3x3_many_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
   __shared__ int job_s;
   if (threadIdx.x == 0) {  // largest j with first_block <= blockIdx.x
@@ -1151,7 +1495,7 @@ __global__ __launch_bounds__(256) void pack_conv3x3_many_kernel(const PackJob* _
   if (idx >= total) return;
   const int rr = r * r;
   const int oc = cout >> 6, ic = cin >> 6;
-  if (!BF16) {
+  if (MODE == 0) {
     float* pf = static_cast<float*>(jb.pf);
     float* pd = static_cast<float*>(jb.pd);
     long t_ = idx;
@@ -1196,13 +1540,15 @@ __global__ __launch_bounds__(256) void pack_conv3x3_many_kernel(const PackJob* _
       const int c = t_ % ic, q = t_ / ic;
       const long o = r > 1 ? (long)n * rr + q : (long)q * 64 + n;
       const long i = (long)c * 64 + k;
-      pf[idx] = (__bf16)w[(o * cin + i) * 9 + t];
+      if (MODE == 2) sisr_store_w3(pf, idx, total, w[(o * cin + i) * 9 + t]);
+      else pf[idx] = (__bf16)w[(o * cin + i) * 9 + t];
     }
     {
       const int c = t_ % oc, q = t_ / oc;
       const long i = (long)q * 64 + n;
       const long o = r > 1 ? (long)k * rr + c : (long)c * 64 + k;
-      pd[idx] = (__bf16)w[(o * cin + i) * 9 + (8 - t)];
+      if (MODE == 2) sisr_store_w3(pd, idx, total, w[(o * cin + i) * 9 + (8 - t)]);
+      else pd[idx] = (__bf16)w[(o * cin + i) * 9 + (8 - t)];
     }
   }
 }
@@ -1211,12 +1557,17 @@ extern "C" size_t sisr_pack_job_bytes() { return sizeof(PackJob); }
 
 extern "C" int sisr_pack_conv3x3_many(const void* jobs_device, int n_jobs, int total_blocks, int bf16, void* stream) {
   if (!jobs_device || n_jobs <= 0 || total_blocks <= 0) return SISR_ERR_ARG;
-  if (bf16)
-    hipLaunchKernelGGL(pack_conv3x3_many_kernel<true>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+  if (bf16 == 2)
+    hipLaunchKernelGGL(pack_conv3x3_many_kernel<2>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const PackJob*>(jobs_device), n_jobs);
+  else if (bf16 == 1)
+    hipLaunchKernelGGL(pack_conv3x3_many_kernel<1>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const PackJob*>(jobs_device), n_jobs);
+  else if (bf16 == 0)
+    hipLaunchKernelGGL(pack_conv3x3_many_kernel<0>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                        static_cast<const PackJob*>(jobs_device), n_jobs);
   else
-    hipLaunchKernelGGL(pack_conv3x3_many_kernel<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<const PackJob*>(jobs_device), n_jobs);
+    return SISR_ERR_ARG;
   return sisr_check_launch();
 }
 
@@ -1472,5 +1823,97 @@ extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const
     BF_CASE(7, true, true, true)
 #undef BF_CASE
   }
+  return sisr_check_launch();
+}
+
+// bf16x3: fp32 through the bf16 matrix cores (three-way operand split, six products); same contract as
+// sisr_conv3x3_c64_bf16, packed weights from sisr_pack_conv3x3_x3_both (three bf16 planes).
+extern "C" int sisr_conv3x3_c64_x3(const float* x, const int64_t* xview, const void* wpacked_bf16, const float* bias,
+                                     int bias_n, int bias_q, float* y, const int64_t* yview, const float* res,
+                                     const float* mask, const float* in_scale, const float* in_shift,
+                                     const float* out_scale, float alpha, int relu, float* gap_partial,
+                                     const float* gate_add, float* gate_out, const float* dot, int B, int H, int W,
+                                     int cin, int cout, void* stream) {
+  if (!x || !wpacked_bf16 || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  const bool gate = gate_add != nullptr;
+  if (gate_add || gate_out || dot) {  // fused gated-residual chain, same contract as the fp32 entry
+    if (gate != (gate_out != nullptr) || (gate && !in_scale) || (gate && dot) || (dot && !gap_partial) ||
+        (!gate && in_scale) || in_shift || mask || out_scale || cin != 64 || cout != 64 || !sisr_aligned16(gate_add) ||
+        !sisr_aligned16(gate_out) || memcmp(xview, yview, 6 * sizeof(int64_t)) != 0)
+      return SISR_ERR_UNSUPPORTED;
+  }
+  if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
+  if (in_shift && !in_scale) return SISR_ERR_UNSUPPORTED;
+  if (!sisr_aligned16(x) || !sisr_aligned16(wpacked_bf16) || !sisr_aligned16(in_scale) || !sisr_aligned16(in_shift))
+    return SISR_ERR_ALIGN;
+  ConvParams p;
+  p.x = x;
+  p.xv = view_from(xview);
+  p.y = y;
+  p.yv = view_from(yview);
+  if ((p.xv.sB | p.xv.sH | p.xv.sW | p.xv.chi | p.xv.clo) & 3) return SISR_ERR_ALIGN;
+  p.res = res;
+  p.mask = mask;
+  p.w = reinterpret_cast<const float*>(wpacked_bf16);
+  p.bias = bias;
+  p.in_scale = in_scale;
+  p.in_shift = in_shift;
+  p.out_scale = out_scale;
+  p.gap = gap_partial;
+  p.gate_add = gate_add;
+  p.gate_out = gate_out;
+  p.dot = dot;
+  p.alpha = alpha;
+  p.bias_n = bias_n;
+  p.bias_q = bias_q;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.cin_chunks = cin / 64;
+  p.cout_chunks = cout / 64;
+  p.relu = relu;
+  p.tiles_w = (W + TW - 1) / TW;
+  p.tiles_h = (H + TH - 1) / TH;
+  const long nblk = (long)p.tiles_w * p.tiles_h * B;
+  if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
+  const dim3 grid((unsigned)nblk, p.cout_chunks);
+  if (gap_partial && !dot && (mask || res)) return SISR_ERR_UNSUPPORTED;
+  const size_t lb_halo = 3 * (size_t)X3_PLANE, lb_out = TH * TW * BE_LD * sizeof(float);
+  const size_t lb = lb_halo > lb_out ? lb_halo : lb_out;
+  hipStream_t st = (hipStream_t)stream;
+  const long wplane = (long)cin * cout * 9 * 2;  // bytes between the hi / mid / lo planes of the packed weights
+#define X3L(AF, MK, RS, GT, DT)                                                                        \
+  do {                                                                                                 \
+    SISR_ALLOW_LDS((conv3x3_c64_x3_kernel<AF, MK, RS, GT, DT>), lb);                                   \
+    hipLaunchKernelGGL((conv3x3_c64_x3_kernel<AF, MK, RS, GT, DT>), grid, dim3(256), lb, st, p, wplane); \
+  } while (0)
+  if (gate) { if (res) X3L(false, false, true, true, false); else X3L(false, false, false, true, false); }
+  else if (dot) { if (res) X3L(false, false, true, false, true); else X3L(false, false, false, false, true); }
+  else {
+    const int sel = (in_scale ? 4 : 0) | (mask ? 2 : 0) | (res ? 1 : 0);
+    switch (sel) {
+      case 0: X3L(false, false, false, false, false); break;
+      case 1: X3L(false, false, true, false, false); break;
+      case 2: X3L(false, true, false, false, false); break;
+      case 3: X3L(false, true, true, false, false); break;
+      case 4: X3L(true, false, false, false, false); break;
+      case 5: X3L(true, false, true, false, false); break;
+      case 6: X3L(true, true, false, false, false); break;
+      case 7: X3L(true, true, true, false, false); break;
+    }
+  }
+#undef X3L
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_pack_conv3x3_x3_both(const float* w, void* packed_fwd, void* packed_dgrad, int cout, int cin,
+                                         int shuffle_r, void* stream) {
+  if (!w || !packed_fwd || !packed_dgrad || cout <= 0 || cin <= 0 || (cout & 63) || (cin & 63) || shuffle_r < 1)
+    return SISR_ERR_ARG;
+  if (shuffle_r > 1 && cout != 64 * shuffle_r * shuffle_r) return SISR_ERR_UNSUPPORTED;
+  const long total = (long)cout * cin * 9;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_conv3x3_x3_both_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                     static_cast<__bf16*>(packed_fwd), static_cast<__bf16*>(packed_dgrad), cout, cin, shuffle_r);
   return sisr_check_launch();
 }

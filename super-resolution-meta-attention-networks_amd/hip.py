@@ -85,6 +85,11 @@ _SIGS.update({  # channel padding / RGB shuffle for the SRMD widening (csrc/misc
     "sisr_pad_oihw": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_shuffle_rgb": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
 })
+_SIGS.update({  # fp32 through the bf16 matrix cores: three-way operand split, six products (csrc/conv3x3_mfma.hip)
+    "sisr_pack_conv3x3_x3_both": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "sisr_conv3x3_c64_x3": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int, c_int,
+                               c_int, c_int, c_int, P]),
+})
 _SIGS.update({  # SAN attention (csrc/san.hip)
     "sisr_covpool_workspace_bytes": (c_size_t, [c_int, c_long]),
     "sisr_covpool_fwd": (c_int, [P, P, P, P, c_int, c_long, c_int, P]),

@@ -126,6 +126,9 @@ def _vec(B, C, device):
 #   "fp32"  v_mfma_f32_32x32x2_f32, exact fp32 -- the reference's arithmetic, the default
 #   "bf16"  v_mfma_f32_32x32x16_bf16: both operands rounded to bf16 (RNE) on their way into LDS, fp32 accumulate,
 #           fp32 feature maps / gradients / optimiser state in HBM (BASELINE config "HAN x4 bf16 ... MFMA")
+#   "bf16x3" forward and input-gradient convs with every fp32 operand split exactly into three bf16 numbers and the six
+#           significant products on the bf16 matrix cores (fp32-class error, 6/16 of the fp32 MFMA's cycles); weight
+#           gradients stay on the exact fp32 kernel.  Opt-in, never the headline
 # Process-wide; packed weights are rebuilt every step, so switching between steps is safe.
 PRECISION = os.environ.get("SISR_PRECISION", "fp32")
 FUSED_GROUPS = os.environ.get("SISR_FUSED_GROUPS", "1") != "0"  # group-level autograd node for CA block stacks
@@ -133,8 +136,8 @@ FUSED_GROUPS = os.environ.get("SISR_FUSED_GROUPS", "1") != "0"  # group-level au
 
 def set_precision(name):
     global PRECISION
-    if name not in ("fp32", "bf16"):
-        raise ValueError(f"precision must be 'fp32' or 'bf16', got {name!r}")
+    if name not in ("fp32", "bf16", "bf16x3"):
+        raise ValueError(f"precision must be 'fp32', 'bf16' or 'bf16x3', got {name!r}")
     PRECISION = name
 
 
@@ -156,8 +159,9 @@ class _PackPlan:
         self.precision = PRECISION
         self.items = [(w, int(r)) for w, r in weights]
         self.ptrs = [w.data_ptr() for w, _ in self.items]
-        total = sum(w.numel() for w, _ in self.items)
-        dt = torch.bfloat16 if PRECISION == "bf16" else torch.float32
+        planes = 3 if PRECISION == "bf16x3" else 1
+        total = planes * sum(w.numel() for w, _ in self.items)
+        dt = torch.float32 if PRECISION == "fp32" else torch.bfloat16
         self.fwd = torch.empty(total, device=device, dtype=dt)
         self.dgrad = torch.empty(total, device=device, dtype=dt)
         esz = self.fwd.element_size()
@@ -167,12 +171,12 @@ class _PackPlan:
         off = blocks = 0
         self.slices = []
         for k, (w, r) in enumerate(self.items):
-            n = w.numel()
+            n = planes * w.numel()
             jobs[k] = (w.data_ptr(), self.fwd.data_ptr() + off * esz, self.dgrad.data_ptr() + off * esz, w.shape[0],
                        w.shape[1], r, blocks)
             self.slices.append((self.fwd[off:off + n], self.dgrad[off:off + n]))
             off += n
-            blocks += (n + 255) // 256
+            blocks += (w.numel() + 255) // 256
         self.blocks = blocks
         self.jobs = torch.from_numpy(jobs.view(np.uint8)).to(device)
 
@@ -181,7 +185,8 @@ class _PackPlan:
 
     def run(self):
         hip.check(hip.lib().sisr_pack_conv3x3_many(self.jobs.data_ptr(), len(self.items), self.blocks,
-                                                   int(PRECISION == "bf16"), hip.stream()), "sisr_pack_conv3x3_many")
+                                                   {"fp32": 0, "bf16": 1, "bf16x3": 2}[PRECISION], hip.stream()),
+                  "sisr_pack_conv3x3_many")
         for (w, r), (pf, pd) in zip(self.items, self.slices):
             _STEP_PACKS[id(w)] = (w, r, PRECISION, pf, pd)
 
@@ -214,7 +219,7 @@ def pack_weight(w, mode, shuffle=1):
     hit = _step_pack(w, shuffle)
     if hit is not None:
         return hit[0] if mode == "fwd" else hit[1]
-    if PRECISION == "bf16":
+    if PRECISION != "fp32":
         pf, pd = pack_pair(w, shuffle)
         return pf if mode == "fwd" else pd
     cout, cin = w.shape[0], w.shape[1]
@@ -238,6 +243,11 @@ def pack_pair(w, shuffle=1):
     if hit is not None:
         return hit
     cout, cin = w.shape[0], w.shape[1]
+    if PRECISION == "bf16x3":
+        buf = torch.empty(2, 3 * cout * cin * 9, device=w.device, dtype=torch.bfloat16)
+        hip.check(hip.lib().sisr_pack_conv3x3_x3_both(hip.ptr(w), hip.ptr_bf16(buf[0]), hip.ptr_bf16(buf[1]), cout, cin,
+                                                      shuffle, hip.stream()), "sisr_pack_conv3x3_x3_both")
+        return buf[0], buf[1]
     if PRECISION == "bf16":
         buf = torch.empty(2, cout * cin * 9, device=w.device, dtype=torch.bfloat16)
         hip.check(hip.lib().sisr_pack_conv3x3_bf16_both(hip.ptr(w), hip.ptr_bf16(buf[0]), hip.ptr_bf16(buf[1]), cout,
@@ -252,8 +262,13 @@ def pack_pair(w, shuffle=1):
 def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=None, mask=None, in_scale=None,
              in_shift=None, out_scale=None, alpha=1.0, relu=False, gap=None, gate_add=None, gate_out=None, dot=None):
     L = hip.lib()
-    bf16 = packed.dtype == torch.bfloat16  # the packing decides: a weight packed under one mode runs under it
-    fn, name = (L.sisr_conv3x3_c64_bf16, "sisr_conv3x3_c64_bf16") if bf16 else (L.sisr_conv3x3_c64, "sisr_conv3x3_c64")
+    # the packing decides: a weight packed under one mode runs under it (three bf16 planes = the bf16x3 split)
+    if packed.dtype != torch.bfloat16:
+        fn, name = L.sisr_conv3x3_c64, "sisr_conv3x3_c64"
+    elif packed.numel() == 3 * cin * cout * 9:
+        fn, name = L.sisr_conv3x3_c64_x3, "sisr_conv3x3_c64_x3"
+    else:
+        fn, name = L.sisr_conv3x3_c64_bf16, "sisr_conv3x3_c64_bf16"
     rc = fn(hip.ptr(x), xview, _wptr(packed), hip.ptr(bias), bias_nq[0], bias_nq[1], hip.ptr(y), yview, hip.ptr(res),
             hip.ptr(mask), hip.ptr(in_scale), hip.ptr(in_shift), hip.ptr(out_scale), float(alpha), int(relu),
             hip.ptr(gap), hip.ptr(gate_add), hip.ptr(gate_out), hip.ptr(dot), B, H, W, cin, cout, hip.stream())

@@ -39,10 +39,10 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--variants", default="4,2", help="conv kernel selections to time: 4 auto, 5 / 6 forced 4-row / 2-row tile, 2 general")
     ap.add_argument("--rounds", type=int, default=0, help="interleaved A/B rounds over --variants (conv only)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"])
     a = ap.parse_args()
     ops.set_precision(a.precision)
-    if a.precision == "bf16":
+    if a.precision != "fp32":
         a.variants = "4"  # one bf16 conv kernel; report GB/s of the two fp32 maps beside TFLOP/s
     only = set(a.only.split(",")) if a.only else None
     B, H, W = a.batch, a.hw, a.hw
