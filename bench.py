@@ -294,8 +294,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands, f32 accumulate and storage",
-                      "bf16x3": "f32 via bf16x3 split (six bf16 MFMA products per f32 product), f32 accumulate and storage; "
-                                "weight gradients on the f32 MFMA"}[args.precision],
+                      "bf16x3": "f32 via bf16x3 split (six bf16 MFMA products per f32 product), f32 accumulate and storage"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{label} x4 full depth, 128x128 LR -> 512x512 tiles, train step = "
                                    f"fwd + L1 + bwd + Adam + scheduler", "per_gpu_batch": B, "global_batch": B * world,
@@ -326,8 +325,7 @@ def main():
         elif args.precision == "bf16x3":
             peak = 2500.0 / 6.0  # dense bf16 MFMA peak / six products per fp32 product
             line["roofline"] = {"bound": "mfma", "what": "whole step, fp32-equivalent algorithmic TFLOP/s per GPU against the "
-                                "dense bf16 MFMA peak / 6 (forward and input-gradient convs; the weight gradients still run "
-                                "on the 157.3 TFLOP/s fp32 MFMA)", "achieved": step_tf, "peak": peak, "unit": "TFLOP/s",
+                                "dense bf16 MFMA peak / 6", "achieved": step_tf, "peak": peak, "unit": "TFLOP/s",
                                 "frac": step_tf / peak, "traffic": None,
                                 "vs_fp32_mfma_peak": step_tf / FP32_MFMA_PEAK_TFLOPS}
         else:

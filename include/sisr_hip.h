@@ -264,6 +264,14 @@ int sisr_conv3x3_c64_x3(const float* x, const int64_t* xview, const void* wpacke
                         float* gap_partial, const float* gate_add, float* gate_out, const float* dot, int B, int H,
                         int W, int cin, int cout, void* stream);
 
+/* weight / bias gradient in the same arithmetic (contract of sisr_wgrad3x3_c64) */
+size_t sisr_wgrad3x3_c64_x3_workspace_bytes(int B, int H, int W, int cin, int cout);
+int sisr_wgrad3x3_c64_x3(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
+                         const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so, int64_t si,
+                         int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n, int in_perm_q, float* dbias,
+                         int bias_n, int bias_q, float* workspace, size_t workspace_bytes, int B, int H, int W, int cin,
+                         int cout, void* stream);
+
 /* ---- channel padding and RGB pixel-shuffle (SRMD: conv(3+M -> nc) ... conv(nc -> 3 r^2) + PixelShuffle(r))
  * ref: advanced/architectures.py:380-425, advanced/SRMD_blocks.py:33-126.  The MFMA convs work on 64-channel chunks:
  * the (3+M)-channel NCHW input becomes a zero-padded NHWC map, head / tail weights zero-padded OIHW copies (crop != 0:

@@ -400,6 +400,234 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_kernel(WgradParams p
   }
 }
 
+// ------------------------------------------------------------------ bf16x3 weight gradient
+// The bf16 kernel above with every fp32 operand split exactly into three bf16 numbers (conv3x3_mfma.hip, "bf16x3") and six
+// products per tap and 16-pixel block; 4 x 32 pixel tiles so that the three planes of the x halo (78 KB) and of dY (49 KB)
+// fit the 160 KB of LDS with one persistent workgroup per CU.  The six products of a tap go into ONE accumulator: its
+// chain is K / 16 x 6 accumulations long against K / 2 in the fp32 kernel, so the rounding of the small terms against the
+// running sum stays below the fp32 kernel's own accumulation error.
+#define XW_TH 4
+#define XW_HH (XW_TH + 2)
+#define XW_X (XW_HH * WH_W * BW_PIX)
+#define XW_Y (XW_TH * WT_W * BW_PIX)
+
+__device__ __forceinline__ void wg_store_split3(unsigned char* dst, int plane, f32x4 a, f32x4 b, unsigned mask) {
+  bf16x8 h, m, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = e < 4 ? a[e] : b[e - 4];
+    const __bf16 vh = (__bf16)v;
+    const float r1 = v - (float)vh;
+    const __bf16 vm = (__bf16)r1;
+    h[e] = vh;
+    m[e] = vm;
+    l[e] = (__bf16)(r1 - (float)vm);
+  }
+  const u32x4 mk = {mask, mask, mask, mask};
+  *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, h) & mk;
+  *reinterpret_cast<u32x4*>(dst + plane) = __builtin_bit_cast(u32x4, m) & mk;
+  *reinterpret_cast<u32x4*>(dst + 2 * plane) = __builtin_bit_cast(u32x4, l) & mk;
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad3x3_c64_x3_kernel(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  unsigned char* ldx = ldsb;                 // three planes (hi, mid, lo) of XW_X bytes
+  unsigned char* ldy = ldsb + 3 * XW_X;      // three planes of XW_Y bytes
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pair = blockIdx.y;
+  const int cq = pair % p.cout_chunks, cc = pair / p.cout_chunks;
+  const int cih = __builtin_amdgcn_readfirstlane(wave >> 1), coh = __builtin_amdgcn_readfirstlane(wave & 1);
+  const int H = p.H, W = p.W;
+  const bool do_bias = p.bias_slabs && cc == 0;
+  const int Cout = p.cout_chunks * 64;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x16){0};
+  f32x4 bsa = {0.f, 0.f, 0.f, 0.f}, bsb = bsa;
+
+  // transposed-read lane constants: lane = 16g + 4qq + pp supplies the address of block row (pixel) qq,
+  // channels 4pp..4pp+3 of the 16-channel block (g & 1); K half (g >> 1) covers pixels 8(g>>1) .. +7
+  unsigned aoff[3][2], yoff[2];
+  {
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int chunk = (g & 1) * 2 + (pp >> 1), sub = (pp & 1) * 8;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int pix = 8 * (g >> 1) + 4 * rd + qq;
+      yoff[rd] = pix * BW_PIX + (((coh * 4 + chunk) ^ (((pix >> 1) & 1) << 2)) << 4) + sub;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+        aoff[kw][rd] = (pix + kw) * BW_PIX + (((cih * 4 + chunk) ^ ((((pix + kw) >> 1) & 1) << 2)) << 4) + sub;
+    }
+  }
+
+  const int tiles_per_img = p.tiles_w * p.tiles_h;
+  const int total = tiles_per_img * p.B;
+  // Tile walk.  Workgroup s lands on XCD s % 8; give every XCD a contiguous eighth of the tiles and let its S / 8
+  // workgroups sweep it together, so that vertically adjacent tiles (whose 10-row halos share two rows) are read
+  // through the same L2 at about the same time.  (HBM-bound kernel: measured 316 MB read per launch with the
+  // strided walk against 268 MB algorithmic.)  Falls back to the strided walk when S is not a multiple of 8.
+  int t_begin = blockIdx.x, t_end = total, t_step = p.S;
+  if ((p.S & 7) == 0) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = (total + 7) >> 3;
+    t_begin = xcd * per + idx;
+    t_end = min(total, (xcd + 1) * per);
+    t_step = p.S >> 3;
+  }
+  // ---- staging split into "issue the loads" and "convert + write LDS": one workgroup per CU (512 VGPRs per wave),
+  // the loads of tile i+1 (38 float4 per thread) are in flight while tile i is in its K loop.  Thread (c8, pcol)
+  // owns channels 8 c8 .. +7 of x halo column pcol + 1 (ten rows) and of dY column pcol (eight rows); the two edge
+  // columns of the halo (10 x 2 x 8 = 160 items) go one per thread to tid < 160 -- every load is unconditional.
+  struct Stage {
+    f32x4 x[XW_HH][2];
+    f32x4 xe[2];
+    f32x4 y[XW_TH][2];
+  };
+  Stage st;
+  const int c8 = tid & 7, pcol = tid >> 3;
+  const int eidx = tid % (XW_HH * 16), er = eidx >> 4, eside = (eidx >> 3) & 1, ec8 = eidx & 7;
+  auto decode = [&](int tile, int& b, int& h0, int& w0) {
+    b = tile / tiles_per_img;
+    const int tr = tile - b * tiles_per_img;
+    const int th = tr / p.tiles_w;
+    h0 = th * XW_TH;
+    w0 = (tr - th * p.tiles_w) * WT_W;
+  };
+  auto issue = [&](int tile) {
+    int b, h0, w0;
+    decode(tile, b, h0, w0);
+    const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(cc);
+    const int gxi = min(w0 + pcol, W - 1) * (int)p.xv.sW + c8 * 8;
+#pragma unroll
+    for (int r = 0; r < XW_HH; ++r) {
+      const float* a = xb + (long)min(max(h0 - 1 + r, 0), H - 1) * p.xv.sH + gxi;
+      st.x[r][0] = *reinterpret_cast<const f32x4*>(a);
+      st.x[r][1] = *reinterpret_cast<const f32x4*>(a + 4);
+    }
+    {
+      const int gwe = min(max(eside ? w0 + WT_W : w0 - 1, 0), W - 1);
+      const float* e = xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8;
+      st.xe[0] = *reinterpret_cast<const f32x4*>(e);
+      st.xe[1] = *reinterpret_cast<const f32x4*>(e + 4);
+    }
+    const float* yb = p.dy + (long)b * p.yv.sB + p.yv.chunk(cq);
+    const int gyi = min(w0 + pcol, W - 1) * (int)p.yv.sW + c8 * 8;
+#pragma unroll
+    for (int r = 0; r < XW_TH; ++r) {
+      const float* a = yb + (long)min(h0 + r, H - 1) * p.yv.sH + gyi;
+      st.y[r][0] = *reinterpret_cast<const f32x4*>(a);
+      st.y[r][1] = *reinterpret_cast<const f32x4*>(a + 4);
+    }
+  };
+  auto commit = [&](int tile) {
+    int b, h0, w0;
+    decode(tile, b, h0, w0);
+    const int col = pcol + 1;
+    const bool cokx = w0 + pcol < W;
+    const unsigned lx = col * BW_PIX + ((c8 ^ (((col >> 1) & 1) << 2)) << 4);
+#pragma unroll
+    for (int r = 0; r < XW_HH; ++r) {
+      const int gh = h0 - 1 + r;
+      const unsigned m = (gh >= 0 && gh < H && cokx) ? 0xffffffffu : 0u;
+      wg_store_split3(ldx + r * (WH_W * BW_PIX) + lx, XW_X, st.x[r][0], st.x[r][1], m);
+    }
+    {
+      const int ecol = eside ? WH_W - 1 : 0, gwe = eside ? w0 + WT_W : w0 - 1, ghe = h0 - 1 + er;
+      const unsigned m = (ghe >= 0 && ghe < H && gwe >= 0 && gwe < W) ? 0xffffffffu : 0u;
+      if (tid < XW_HH * 16)
+        wg_store_split3(ldx + er * (WH_W * BW_PIX) + ecol * BW_PIX + ((ec8 ^ (((ecol >> 1) & 1) << 2)) << 4), XW_X, st.xe[0], st.xe[1], m);
+    }
+    f32x4 s4a = {1.f, 1.f, 1.f, 1.f}, s4b = s4a, t4a = {0.f, 0.f, 0.f, 0.f}, t4b = t4a;
+    if (p.dy_scale) {
+      const float* sp = p.dy_scale + (long)b * Cout + cq * 64 + c8 * 8;
+      s4a = *reinterpret_cast<const f32x4*>(sp);
+      s4b = *reinterpret_cast<const f32x4*>(sp + 4);
+    }
+    if (p.dy_shift) {
+      const float* tp = p.dy_shift + (long)b * Cout + cq * 64 + c8 * 8;
+      t4a = *reinterpret_cast<const f32x4*>(tp);
+      t4b = *reinterpret_cast<const f32x4*>(tp + 4);
+    }
+    const bool coky = w0 + pcol < W;
+    const unsigned ly = pcol * BW_PIX + ((c8 ^ (((pcol >> 1) & 1) << 2)) << 4);
+#pragma unroll
+    for (int r = 0; r < XW_TH; ++r) {
+      const bool ok = coky && (h0 + r < H);
+      const f32x4 ta = sisr_keep_if(st.y[r][0] * s4a + t4a, ok), tb = sisr_keep_if(st.y[r][1] * s4b + t4b, ok);
+      bsa += ta;
+      bsb += tb;
+      wg_store_split3(ldy + r * (WT_W * BW_PIX) + ly, XW_Y, ta, tb, 0xffffffffu);
+    }
+  };
+
+  if (t_begin < t_end) {
+    issue(t_begin);
+    commit(t_begin);
+  }
+  __syncthreads();
+  for (int tile = t_begin; tile < t_end; tile += t_step) {
+    const bool has_next = tile + t_step < t_end;  // uniform
+    if (has_next) issue(tile + t_step);
+
+    // ---- 8 K-steps of 16 pixels (tile row r, half hf), nine taps each, six products per tap:
+    // hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid (A = x planes, B = dY planes)
+#pragma unroll 1
+    for (int r = 0; r < XW_TH; ++r) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const unsigned char* yb = ldy + (r * WT_W + 16 * hf) * BW_PIX;
+        const bf16x8 bh = wg_tr_frag(yb, yoff[0], yoff[1]);
+        const bf16x8 bm = wg_tr_frag(yb + XW_Y, yoff[0], yoff[1]);
+        const bf16x8 bl = wg_tr_frag(yb + 2 * XW_Y, yoff[0], yoff[1]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const unsigned char* xa = ldx + ((r + t / 3) * WH_W + 16 * hf) * BW_PIX;
+          const bf16x8 ah = wg_tr_frag(xa, aoff[t % 3][0], aoff[t % 3][1]);
+          const bf16x8 am = wg_tr_frag(xa + XW_X, aoff[t % 3][0], aoff[t % 3][1]);
+          const bf16x8 al = wg_tr_frag(xa + 2 * XW_X, aoff[t % 3][0], aoff[t % 3][1]);
+          f32x16 c = acc[t];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);  // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+          acc[t] = c;
+          __builtin_amdgcn_sched_barrier(0);  // one tap's fragments in flight at a time
+        }
+      }
+    }
+    __syncthreads();  // every wave is done with this tile's LDS image
+    if (has_next) {
+      commit(tile + t_step);
+      __syncthreads();
+    }
+  }
+
+  // ---- slabs: unit = pair*4 + (ci half, co half), the fp32 kernel's layout
+  {
+    float* out = p.slabs + ((long)blockIdx.x * ((long)gridDim.y * 4) + pair * 4 + cih * 2 + coh) * SLAB;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64 + lane] = acc[t][r];
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(ldsb);
+    *reinterpret_cast<f32x4*>(red + tid * 8) = bsa;
+    *reinterpret_cast<f32x4*>(red + tid * 8 + 4) = bsb;
+    __syncthreads();
+    if (tid < 64) {  // channel tid = c8*8 + e lives in threads with (tid & 7) == c8
+      const int c8 = tid >> 3, e = tid & 7;
+      float s = 0.f;
+      for (int k = 0; k < 32; ++k) s += red[(k * 8 + c8) * 8 + e];
+      p.bias_slabs[((long)blockIdx.x * p.cout_chunks + cq) * 64 + tid] = s;
+    }
+  }
+}
+
 // Sum S slabs per output element in slab order and scatter to dW (generic strides / channel maps):
 // element (unit, tap t, reg r, lane l): ci_local = (r&3) + 8*(r>>2) + 4*(l>>5), co_local = l&31.
 struct ReduceParams {
@@ -598,6 +826,82 @@ extern "C" int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, cons
   const size_t lds_bytes = BW_X_BYTES + BW_Y_BYTES;
   SISR_ALLOW_LDS(wgrad3x3_c64_bf16_kernel, lds_bytes);
   hipLaunchKernelGGL(wgrad3x3_c64_bf16_kernel, dim3(p.S, pairs), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  int rc = sisr_check_launch();
+  if (rc) return rc;
+  ReduceParams r;
+  r.slabs = p.slabs;
+  r.bias_slabs = p.bias_slabs;
+  r.dw = dw;
+  r.db = dbias;
+  r.so = so;
+  r.si = si;
+  r.alpha = alpha;
+  r.S = p.S;
+  r.units = units;
+  r.cin_chunks = p.cin_chunks;
+  r.cout_chunks = p.cout_chunks;
+  r.flip = flip_taps;
+  r.on = out_perm_n;
+  r.oq = out_perm_q;
+  r.in_ = in_perm_n;
+  r.iq = in_perm_q;
+  r.bias_n = bias_n;
+  r.bias_q = bias_q;
+  const long total = (long)units * SLAB + (dbias ? cout : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, RG), 0, (hipStream_t)stream, r);
+  return sisr_check_launch();
+}
+
+static int wgrad_x3_split(int B, int H, int W, int pairs) {
+  const long tiles = (long)B * ((H + XW_TH - 1) / XW_TH) * ((W + WT_W - 1) / WT_W);
+  long S = 256 / pairs;  // one persistent workgroup per CU
+  if (S < 1) S = 1;
+  if (S > tiles) S = tiles;
+  return (int)S;
+}
+
+extern "C" size_t sisr_wgrad3x3_c64_x3_workspace_bytes(int B, int H, int W, int cin, int cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
+  const int pairs = (cin / 64) * (cout / 64);
+  const int S = wgrad_x3_split(B, H, W, pairs);
+  return ((size_t)S * pairs * 4 * SLAB + (size_t)S * cout) * sizeof(float);
+}
+
+extern "C" int sisr_wgrad3x3_c64_x3(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
+                                    const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so,
+                                    int64_t si, int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n,
+                                    int in_perm_q, float* dbias, int bias_n, int bias_q, float* workspace,
+                                    size_t workspace_bytes, int B, int H, int W, int cin, int cout, void* stream) {
+  if (!x || !dy || !dw || !xview || !dyview || !workspace || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
+  if (workspace_bytes < sisr_wgrad3x3_c64_x3_workspace_bytes(B, H, W, cin, cout)) return SISR_ERR_ARG;
+  if (!sisr_aligned16(x) || !sisr_aligned16(dy) || !sisr_aligned16(workspace) || !sisr_aligned16(dy_scale) ||
+      !sisr_aligned16(dy_shift))
+    return SISR_ERR_ALIGN;
+  WgradParams p;
+  p.x = x;
+  p.xv = view_from(xview);
+  p.dy = dy;
+  p.yv = view_from(dyview);
+  if ((p.xv.sB | p.xv.sH | p.xv.sW | p.xv.chi | p.xv.clo | p.yv.sB | p.yv.sH | p.yv.sW | p.yv.chi | p.yv.clo) & 3)
+    return SISR_ERR_ALIGN;
+  p.dy_scale = dy_scale;
+  p.dy_shift = dy_shift;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.cin_chunks = cin / 64;
+  p.cout_chunks = cout / 64;
+  p.tiles_w = (W + WT_W - 1) / WT_W;
+  p.tiles_h = (H + XW_TH - 1) / XW_TH;
+  const int pairs = p.cin_chunks * p.cout_chunks;
+  const int units = pairs * 4;
+  p.S = wgrad_x3_split(B, H, W, pairs);
+  p.slabs = workspace;
+  p.bias_slabs = dbias ? workspace + (size_t)p.S * units * SLAB : nullptr;
+  const size_t lds_bytes = 3 * (size_t)(XW_X + XW_Y);
+  SISR_ALLOW_LDS(wgrad3x3_c64_x3_kernel, lds_bytes);
+  hipLaunchKernelGGL(wgrad3x3_c64_x3_kernel, dim3(p.S, pairs), dim3(256), lds_bytes, (hipStream_t)stream, p);
   int rc = sisr_check_launch();
   if (rc) return rc;
   ReduceParams r;

@@ -87,6 +87,9 @@ _SIGS.update({  # channel padding / RGB shuffle for the SRMD widening (csrc/misc
 })
 _SIGS.update({  # fp32 through the bf16 matrix cores: three-way operand split, six products (csrc/conv3x3_mfma.hip)
     "sisr_pack_conv3x3_x3_both": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "sisr_wgrad3x3_c64_x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "sisr_wgrad3x3_c64_x3": (c_int, [P, P, P, P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
+                                c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_conv3x3_c64_x3": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int, c_int,
                                c_int, c_int, c_int, P]),
 })

@@ -127,10 +127,11 @@ def _vec(B, C, device):
 #   "bf16"  v_mfma_f32_32x32x16_bf16: both operands rounded to bf16 (RNE) on their way into LDS, fp32 accumulate,
 #           fp32 feature maps / gradients / optimiser state in HBM (BASELINE config "HAN x4 bf16 ... MFMA")
 #   "bf16x3" forward and input-gradient convs with every fp32 operand split exactly into three bf16 numbers and the six
-#           significant products on the bf16 matrix cores (fp32-class error, 6/16 of the fp32 MFMA's cycles); weight
-#           gradients stay on the exact fp32 kernel.  Opt-in, never the headline
+#           significant products on the bf16 matrix cores (fp32-class error, 6/16 of the fp32 MFMA's cycles), weight
+#           gradients likewise.  Opt-in, never the headline
 # Process-wide; packed weights are rebuilt every step, so switching between steps is safe.
 PRECISION = os.environ.get("SISR_PRECISION", "fp32")
+X3_WGRAD = os.environ.get("SISR_X3_WGRAD", "1") != "0"  # bf16x3 mode: weight gradients split too (0: exact fp32 kernel)
 FUSED_GROUPS = os.environ.get("SISR_FUSED_GROUPS", "1") != "0"  # group-level autograd node for CA block stacks
 
 
@@ -277,7 +278,9 @@ def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=
 
 def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_scale=None, dy_shift=None, shuffle=1):
     L = hip.lib()
-    if PRECISION == "bf16":
+    if PRECISION == "bf16x3" and X3_WGRAD:
+        size_fn, fn, name = L.sisr_wgrad3x3_c64_x3_workspace_bytes, L.sisr_wgrad3x3_c64_x3, "sisr_wgrad3x3_c64_x3"
+    elif PRECISION == "bf16":
         size_fn, fn, name = L.sisr_wgrad3x3_c64_bf16_workspace_bytes, L.sisr_wgrad3x3_c64_bf16, "sisr_wgrad3x3_c64_bf16"
     else:
         size_fn, fn, name = L.sisr_wgrad3x3_c64_workspace_bytes, L.sisr_wgrad3x3_c64, "sisr_wgrad3x3_c64"
