@@ -283,6 +283,18 @@ int sisr_pad_oihw(const float* src, float* dst, int cout, int cin, int cout_padd
 int sisr_shuffle_rgb(const float* src, float* dst, int B, int C, int r, int H, int W, int C_padded, int adjoint,
                      void* stream);
 
+/* ---- on-the-fly LR synthesis (online_degradations) -----------------------------------------------------------
+ * ref: sr_tools/gaussian_utils.py:346-368 BatchBlur (reflection pad + per-channel l x l correlation), :52-53
+ * ToPILImage quantisation `mul(255).byte()`, sr_tools/image_manipulation.py:32-53 downsample (PIL BICUBIC resize).
+ * sisr_blur_quant: planar [C][H][W] fp32, one [l][l] kernel (l <= 21) -> uint8 (and / or the unquantised fp32 blur).
+ * sisr_pil_resample: ONE pass of libImaging/Resample.c's 8-bit resampler over a planar uint8 image (vertical = 0:
+ * taps along x; 1: along y, optionally written as fp32 / 255 = ToTensor): out = clip8((2^21 + sum in*coef) >> 22);
+ * bounds [out][2] (first tap, taps) and coef [out][ksize] int32 are device copies of the host tables. */
+int sisr_blur_quant(const float* x, const float* kernel, unsigned char* y_u8, float* y_f32, int C, int H, int W, int l,
+                    void* stream);
+int sisr_pil_resample(const unsigned char* in, void* out, const int* bounds, const int* coef, int ksize, int C, int Hin,
+                      int Win, int Hout, int Wout, int vertical, int to_float, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,7 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=../libsisr_hip.so
-SRCS=(conv3x3_mfma.hip wgrad3x3_mfma.hip conv3x3_small.hip attention.hip misc.hip han.hip san.hip diag.hip)
+SRCS=(conv3x3_mfma.hip wgrad3x3_mfma.hip conv3x3_small.hip attention.hip misc.hip han.hip san.hip degrade.hip diag.hip)
 newest=$(ls -t "${SRCS[@]}" sisr_common.h build.sh | head -1)
 if [ -f "$OUT" ] && [ "$OUT" -nt "$newest" ]; then exit 0; fi
 mkdir -p ../_build

@@ -93,6 +93,10 @@ _SIGS.update({  # fp32 through the bf16 matrix cores: three-way operand split, s
     "sisr_conv3x3_c64_x3": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int, c_int,
                                c_int, c_int, c_int, P]),
 })
+_SIGS.update({  # on-the-fly degradation (csrc/degrade.hip)
+    "sisr_blur_quant": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "sisr_pil_resample": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+})
 _SIGS.update({  # SAN attention (csrc/san.hip)
     "sisr_covpool_workspace_bytes": (c_size_t, [c_int, c_long]),
     "sisr_covpool_fwd": (c_int, [P, P, P, P, c_int, c_long, c_int, P]),

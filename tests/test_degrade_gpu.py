@@ -1,0 +1,59 @@
+"""On-the-fly degradation kernels (csrc/degrade.hip) on a real MI355X (pytest -m gpu)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sisr_amd
+from conftest import GOLDEN
+from oracle import degrade_oracle as DO
+
+pytestmark = pytest.mark.gpu
+D = sisr_amd.degrade
+
+
+@pytest.mark.parametrize("hw,scale", [((64, 96), 4), ((50, 34), 2), ((93, 61), 3), ((512, 384), 4), ((37, 45), 4)])
+def test_pil_bicubic_downsample_is_bit_identical_to_pillow(hw, scale):
+    rng = np.random.RandomState(hw[0] + scale)
+    img = DO.center_crop_u8(rng.randint(0, 256, size=hw + (3,)).astype(np.uint8), scale)
+    u8 = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1))).cuda()
+    got = D.pil_bicubic_downsample(u8, scale, to_float=False).cpu().numpy().transpose(1, 2, 0)
+    want = DO.pil_downsample(img, scale)
+    np.testing.assert_array_equal(got, want)
+    gotf = D.pil_bicubic_downsample(u8, scale).cpu().numpy().transpose(1, 2, 0)
+    np.testing.assert_array_equal(gotf, want.astype(np.float32) / np.float32(255))
+
+
+@pytest.mark.parametrize("hw,l", [((40, 52), 21), ((33, 47), 21), ((64, 64), 15), ((30, 30), 8)])
+def test_blur_matches_batchblur(hw, l):
+    g = torch.Generator().manual_seed(l + hw[0])
+    x = torch.rand(3, *hw, generator=g)
+    k = torch.rand(l, l, generator=g)
+    k = k / k.sum()
+    want = DO.batch_blur(x[None], k)[0]
+    u8, yf = D.blur_quant(x.cuda(), k, want_float=True)
+    np.testing.assert_allclose(yf.cpu().numpy(), want.numpy(), rtol=0, atol=2e-6)
+    diff = np.abs(u8.cpu().numpy().astype(int) - want.mul(255).byte().numpy().astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3  # truncation ties only (summation order)
+
+
+def test_online_degrader_reproduces_the_reference_lr_images():
+    """Same seed, same Set5 HR images as tools/make_fixtures_degrade.py: kernels and codes equal, LR images equal to the
+    reference's except where the fp32 blur lands within rounding of a byte boundary (<= 1 LSB on < 0.2 % of pixels)."""
+    z = np.load(os.path.join(GOLDEN, "d_degrade.npz"))
+    np.random.seed(int(z["seed"]))
+    pca = D.pca_matrix(batch=int(z["pca_batch"]))
+    deg = D.OnlineDegrader(scale=4, pca=pca)
+    from PIL import Image
+    for i, name in enumerate(str(z["names"]).split(",")):
+        hr = np.asarray(Image.open(os.path.join(GOLDEN, "set5", "hr", name)).convert("RGB"))
+        x = torch.from_numpy(hr.transpose(2, 0, 1).copy()).float().div(255).cuda()
+        lr, code, kernel, box = deg(x)
+        np.testing.assert_array_equal(kernel.numpy(), z[f"kernel{i}"])
+        np.testing.assert_allclose(code.numpy(), z[f"code{i}"], rtol=0, atol=1e-7)
+        want = z[f"lr{i}"].transpose(2, 0, 1).astype(int)
+        got = (lr.cpu() * 255).round().numpy().astype(int)
+        assert got.shape == want.shape and box[2:] == (want.shape[1] * 4, want.shape[2] * 4)
+        d = np.abs(got - want)
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3, (name, d.max(), (d > 0).mean())
