@@ -21,6 +21,7 @@
 // address map, and per-wave partial sums for the global average pool.
 #include "sisr_common.h"
 #include <string.h>
+#include <stdlib.h>
 
 #define TH 4
 #define TW 32
@@ -777,7 +778,9 @@ __device__ __forceinline__ void sisr_store_split3(unsigned char* dst, f32x4 a, f
   *reinterpret_cast<u32x4*>(dst + 2 * X3_PLANE) = lo & mk;
 }
 
-template <bool AFFINE, bool MASK, bool RES, bool GATE = false, bool DOT = false>
+// BD = B-fragment prefetch distance in K-steps (ring of BD + 1 slots); the A fragments of step s + 1 are requested before
+// the MFMAs of step s (double buffer).
+template <bool AFFINE, bool MASK, bool RES, bool GATE = false, bool DOT = false, int BD = 4>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, long wplane) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -923,21 +926,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, lo
 #define BF_LOAD_B(s, pl) (*reinterpret_cast<const bf16x8*>(wq + (pl) * wplane + (s) * 2048 + boff))
 #define BF_LOAD_A(m, s, pl) \
   (*reinterpret_cast<const bf16x8*>(ldsb + (pl) * X3_PLANE + ((((s) >> 2) / 3 + (m)) * (HALO_W * BH_PIX)) + aoff[((s) >> 2) % 3][(s) & 3]))
-    bf16x8 bq[4][3];
+    constexpr int RING = BD + 1;
+    bf16x8 bq[RING][3];
+    bf16x8 aq[2][2][3];  // [step parity][M-tile][plane]
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < BD; ++s)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) bq[s][pl] = BF_LOAD_B(s, pl);
 #pragma unroll
-    for (int s = 0; s < 36; ++s) {
-      const bf16x8 bh = bq[s & 3][0], bm = bq[s & 3][1], bl = bq[s & 3][2];
-      if (s + 4 < 36) {
+    for (int pl = 0; pl < 3; ++pl) {
+      aq[0][0][pl] = BF_LOAD_A(0, 0, pl);
+      aq[0][1][pl] = BF_LOAD_A(1, 0, pl);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bq[s & 3][pl] = BF_LOAD_B(s + 4, pl);
+    for (int s = 0; s < 36; ++s) {
+      if (s + BD < 36) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bq[(s + BD) % RING][pl] = BF_LOAD_B(s + BD, pl);
       }
-      const bf16x8 a0h = BF_LOAD_A(0, s, 0), a1h = BF_LOAD_A(1, s, 0);
-      const bf16x8 a0m = BF_LOAD_A(0, s, 1), a1m = BF_LOAD_A(1, s, 1);
-      const bf16x8 a0l = BF_LOAD_A(0, s, 2), a1l = BF_LOAD_A(1, s, 2);
+      if (s + 1 < 36) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          aq[(s + 1) & 1][0][pl] = BF_LOAD_A(0, s + 1, pl);
+          aq[(s + 1) & 1][1][pl] = BF_LOAD_A(1, s + 1, pl);
+        }
+      }
+      const bf16x8 bh = bq[s % RING][0], bm = bq[s % RING][1], bl = bq[s % RING][2];
+      const bf16x8 a0h = aq[s & 1][0][0], a0m = aq[s & 1][0][1], a0l = aq[s & 1][0][2];
+      const bf16x8 a1h = aq[s & 1][1][0], a1m = aq[s & 1][1][1], a1l = aq[s & 1][1][2];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, bh, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, bh, acc1, 0, 0, 0);
       cor0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, bm, cor0, 0, 0, 0);
@@ -1887,6 +1904,12 @@ extern "C" int sisr_conv3x3_c64_x3(const float* x, const int64_t* xview, const v
     SISR_ALLOW_LDS((conv3x3_c64_x3_kernel<AF, MK, RS, GT, DT>), lb);                                   \
     hipLaunchKernelGGL((conv3x3_c64_x3_kernel<AF, MK, RS, GT, DT>), grid, dim3(256), lb, st, p, wplane); \
   } while (0)
+  static const int x3_bd = getenv("SISR_X3_BD") ? atoi(getenv("SISR_X3_BD")) : 4;  // diagnostic A/B of the plain form
+  if (x3_bd == 6 && !gate && !dot && !in_scale && !mask && !res) {
+    SISR_ALLOW_LDS((conv3x3_c64_x3_kernel<false, false, false, false, false, 6>), lb);
+    hipLaunchKernelGGL((conv3x3_c64_x3_kernel<false, false, false, false, false, 6>), grid, dim3(256), lb, st, p, wplane);
+    return sisr_check_launch();
+  }
   if (gate) { if (res) X3L(false, false, true, true, false); else X3L(false, false, false, true, false); }
   else if (dot) { if (res) X3L(false, false, true, false, true); else X3L(false, false, false, false, true); }
   else {
