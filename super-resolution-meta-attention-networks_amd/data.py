@@ -4,8 +4,10 @@ ref: Code/sr_tools/data_handler.py:147-528 (SuperResImages; __getitem__ :433-525
      Code/sr_tools/image_manipulation.py:233-257 (matched random crop, flip/rotate),
      Code/SISR/training/data_setup.py:9-125 (sisr_data_setup).
 This is the caller side of the hot path: it is reproduced (same file ordering, same Python `random` call
-order, same dict keys), not accelerated.  Options outside the in-scope configs (online degradations, masks,
-CelebA attribute files, QPI group filters, Y-only inputs) raise NotImplementedError.
+order, same dict keys), not accelerated -- except `online_degradations`, whose blur + bicubic down-sampling of the HR
+image runs on the device (degrade.py / csrc/degrade.hip; the random draws stay here, on numpy's global stream, in the
+reference's order).  Options outside the in-scope configs (masks, CelebA attribute files, QPI group filters, Y-only
+inputs) raise NotImplementedError.
 """
 import glob
 import json
@@ -239,18 +241,30 @@ def read_degradation_metadata(metadata_file, filenames):
 class SuperResImages(Dataset):
     def __init__(self, lr_dir=None, hr_dir=None, dataset=None, split=None, custom_split=None, recursive_search=False,
                  input='unmodified', colorspace='rgb', scale=4, degradation_metadata_file=None, metadata=None,
-                 random_augments=None, random_crop=None, **unsupported):
+                 random_augments=None, random_crop=None, online_degradations=None, online_degradation_params=None,
+                 **unsupported):
         super().__init__()
         if split not in ['train', 'eval', 'test', 'all', None]:
             raise RuntimeError('"Split" must be one of: train | eval | test | all | None')
         if input != 'unmodified' or 'rgb' not in colorspace:
             raise NotImplementedError('only unmodified RGB inputs are in scope (EDSR/RCAN/HAN families)')
-        for k in ('online_degradations', 'mask_data', 'halfway_data', 'blacklist', 'data_attributes', 'image_shortlist',
+        for k in ('mask_data', 'halfway_data', 'blacklist', 'data_attributes', 'image_shortlist',
                   'legacy_blur_kernels', 'request_crops', 'group_select', 'attribute_amplification'):
             if unsupported.get(k):
                 raise NotImplementedError(f'data option {k!r} is outside the HIP hot-path scope')
         self.scale, self.patch_crop, self.random_augment = scale, random_crop, random_augments
         self.lr_base, self.hr_base = lr_dir, hr_dir
+        self.online_degradations = bool(online_degradations)
+        if self.online_degradations:
+            # ref: data_handler.py:222-238 -- LR images are synthesised from the HR ones; the degrader's PCA basis is
+            # built here, from 30 000 random kernels of numpy's global stream, before any file is listed
+            if hr_dir is None:
+                raise RuntimeError('Cannot synthesize LR images without specifying HR images.')
+            if degradation_metadata_file is not None:
+                raise NotImplementedError('online degradations together with a metadata file are not built')
+            from . import degrade
+            self.degrader = degrade.OnlineDegrader(scale=scale, **(online_degradation_params or {}))
+            self.lr_base, lr_dir = None, hr_dir
         groups = {}
         for f in image_names(lr_dir, recursive_search):
             rel = os.path.relpath(f, lr_dir)
@@ -269,6 +283,8 @@ class SuperResImages(Dataset):
         if degradation_metadata_file is not None:
             table, self.metadata_keys = read_degradation_metadata(degradation_metadata_file, self.lr_filenames)
             self.metadata = [table[n] for n in self.lr_filenames]
+        if self.online_degradations:
+            self.metadata_keys = ['blur_kernel'] * self.degrader.para_in  # ref :293-297
         self.image_count = len(self.lr_filenames)
         print('Initialized %s data with %d image%s.' % (dataset if dataset is not None else 'image', self.image_count,
                                                         's' if self.image_count > 1 else ''))
@@ -278,6 +294,8 @@ class SuperResImages(Dataset):
 
     def __getitem__(self, index):
         base_name, image_name = self.base_filenames[index], self.lr_filenames[index]
+        if self.online_degradations:
+            return self._degraded_item(base_name)
         lr_im = read_image(os.path.join(self.lr_base, image_name))
         metadata = self.metadata[index] if self.metadata is not None else np.array(0)
         if self.hr_base is not None:
@@ -296,6 +314,23 @@ class SuperResImages(Dataset):
         return {'lr': lr_im, 'hr': hr_im, 'tag': image_name, 'hr_tag': base_name, 'mask': np.array(0),
                 'halfway_data': np.array(0), 'metadata': metadata, 'metadata_keys': self.metadata_keys,
                 'blur_kernels': np.array(0)}
+
+    def _degraded_item(self, base_name):
+        """ref: data_handler.py:446-456 + the common tail of __getitem__: blur kernel drawn on the host (np.random), blur +
+        quantisation + PIL bicubic on the device, kernel code as the sample's metadata, full kernel as 'blur_kernels'."""
+        if not torch.cuda.is_available():
+            raise RuntimeError('online degradations run on a HIP device (no CPU path in this package)')
+        hr_im = to_tensor(read_image(os.path.join(self.hr_base, base_name)))
+        lr_dev, code, kernel, (top, left, rh, rw) = self.degrader(hr_im.cuda())
+        lr_im = lr_dev.cpu()
+        hr_im = hr_im[:, top:top + rh, left:left + rw]  # center_crop to LR size x scale (ref :470-476)
+        if self.random_augment is not None:
+            lr_im, hr_im = random_flip_rotate(lr_im, hr_im)
+        if self.patch_crop is not None:
+            lr_im, hr_im = random_matched_crop(lr_im, hr_im, crop_size=self.patch_crop, scale=self.scale)
+        return {'lr': lr_im, 'hr': hr_im, 'tag': base_name, 'hr_tag': base_name, 'mask': np.array(0),
+                'halfway_data': np.array(0), 'metadata': code.numpy(), 'metadata_keys': self.metadata_keys,
+                'blur_kernels': kernel.numpy().squeeze()}
 
 
 def sisr_data_setup(training_sets, eval_sets, batch_size=16, eval_batch_size=1, dataloader_threads=8,
@@ -316,8 +351,8 @@ def sisr_data_setup(training_sets, eval_sets, batch_size=16, eval_batch_size=1, 
             meta_file = os.path.join(ds['lr'], 'degradation_metadata.csv')
             if not os.path.isfile(meta_file):
                 meta_file = os.path.join(ds['lr'], 'qpi_slices.csv')
-        extra = {k: ds.get(k) for k in ('online_degradations', 'image_shortlist', 'legacy_blur_kernels', 'request_crops',
-                                        'attribute_amplification')}
+        extra = {k: ds.get(k) for k in ('online_degradations', 'online_degradation_params', 'image_shortlist',
+                                        'legacy_blur_kernels', 'request_crops', 'attribute_amplification')}
         return SuperResImages(lr_dir=ds['lr'], hr_dir=ds.get('hr'), dataset=ds.get('name'), split=split,
                               custom_split=custom, degradation_metadata_file=meta_file, metadata=ds.get('metadata'),
                               random_crop=ds.get('crop'), random_augments=ds.get('random_augment'),
@@ -331,6 +366,8 @@ def sisr_data_setup(training_sets, eval_sets, batch_size=16, eval_batch_size=1, 
             raise RuntimeError("device_tiles needs a HIP device")
         return (DeviceTileLoader(train, batch_size, device, drop_last=drop_last_training_batch),
                 DataLoader(dataset=val, batch_size=eval_batch_size))
+    if any(getattr(d, 'online_degradations', False) for d in train):
+        dataloader_threads = 0  # the degrader launches HIP kernels: it cannot run in forked DataLoader workers
     train = train[0] if len(train) == 1 else ConcatDataset(train)
     train_loader = DataLoader(dataset=train, batch_size=batch_size, shuffle=True, num_workers=dataloader_threads,
                               pin_memory=torch.cuda.is_available(), drop_last=drop_last_training_batch)

@@ -57,3 +57,27 @@ def test_online_degrader_reproduces_the_reference_lr_images():
         assert got.shape == want.shape and box[2:] == (want.shape[1] * 4, want.shape[2] * 4)
         d = np.abs(got - want)
         assert d.max() <= 1 and (d > 0).mean() < 2e-3, (name, d.max(), (d > 0).mean())
+
+
+def test_dataset_with_online_degradations_yields_the_reference_batch_schema(monkeypatch):
+    """SuperResImages(online_degradations=True) over the Set5 HR images: same np.random stream as a hand-driven degrader
+    (PCA basis at construction, one kernel per item), LR = degraded HR, metadata = the kernel code, keys = 10 x
+    'blur_kernel', 'blur_kernels' = the 21 x 21 kernel (ref: data_handler.py:222-238, :293-297, :446-456)."""
+    real = D.pca_matrix
+    monkeypatch.setattr(D, "pca_matrix", lambda batch=2000, k=10: real(batch=2000, k=k))
+    hr_dir = os.path.join(GOLDEN, "set5", "hr")
+    np.random.seed(5)
+    ds = sisr_amd.data.SuperResImages(hr_dir=hr_dir, online_degradations=True, split="all", scale=4)
+    items = [ds[i] for i in range(2)]
+    np.random.seed(5)
+    deg = D.OnlineDegrader(scale=4)
+    from PIL import Image
+    for i, it in enumerate(items):
+        hr = np.asarray(Image.open(os.path.join(hr_dir, ds.base_filenames[i])).convert("RGB"))
+        x = torch.from_numpy(hr.transpose(2, 0, 1).copy()).float().div(255)
+        lr, code, kernel, (top, left, rh, rw) = deg(x.cuda())
+        assert torch.equal(it["lr"], lr.cpu()) and torch.equal(it["hr"], x[:, top:top + rh, left:left + rw])
+        np.testing.assert_array_equal(it["metadata"], code.numpy())
+        np.testing.assert_array_equal(it["blur_kernels"], kernel.numpy())
+        assert it["metadata_keys"] == ["blur_kernel"] * 10 and it["tag"] == it["hr_tag"] == ds.base_filenames[i]
+        assert it["hr"].shape[1] == 4 * it["lr"].shape[1] and it["hr"].shape[2] == 4 * it["lr"].shape[2]

@@ -74,9 +74,9 @@ def test_batch_dict_schema():
     assert b["metadata"].dtype == torch.float64 and b["metadata"].shape == (2, 10)
     assert len(b["metadata_keys"]) == 10 and b["metadata_keys"][0] == ("blur_kernel", "blur_kernel")
     assert b["tag"] == ["baby.png", "bird.png"]
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):  # options that stay outside the HIP hot-path scope fail loudly
         sisr_amd.data.SuperResImages(os.path.join(d, "lr_random_blur"), os.path.join(d, "hr"), split="all",
-                                     online_degradations=True)
+                                     mask_data="somewhere")
 
 
 @pytest.mark.gpu
