@@ -284,6 +284,20 @@ def main():
             "algorithmic_tflops_per_gpu": s["value"] / world * s["tflop_per_patch"],
             "frac_of_fp32_mfma_peak": s["value"] / world * s["tflop_per_patch"] / FP32_MFMA_PEAK_TFLOPS})
 
+    x3 = None
+    if not explicit and not args.no_secondary and args.precision == "fp32" and world == 1:
+        # second line asked for by the round-1 review: the same step with the convs as bf16x3 splits
+        sisr.ops.set_precision("bf16x3")
+        try:
+            s3 = measure(sisr, workload, B, max(2, min(args.steps, 5)), min(args.warmup, 2), False, rank, world, local, dev)
+        finally:
+            sisr.ops.set_precision("fp32")
+        x3 = {"dtype": "f32 via bf16x3 split (six bf16 MFMA products per f32 product), f32 accumulate and storage",
+              "what": "same workload and step as the headline line, opt-in arithmetic: NOT the headline (DESIGN.md section 7b)",
+              "value": s3["value"], "unit": "patches/s", "ms_per_step": s3["ms_per_step"], "final_loss": s3["loss"],
+              "speedup_vs_headline": s3["value"] / main_res["value"],
+              "algorithmic_tflops": s3["value"] * s3["tflop_per_patch"]}
+
     if rank == 0:
         name, params, value = main_res["name"], main_res["params"], main_res["value"]
         tflop_per_patch = main_res["tflop_per_patch"]
@@ -338,6 +352,8 @@ def main():
                                               "frac": step_tf / 2500.0}}
         if secondary is not None:
             line[secondary[0]] = secondary[1]
+        if x3 is not None:
+            line["bf16x3"] = x3
         if world == 1 and not args.no_cpu_baseline and args.precision == "fp32":
             line["cpu_baseline"] = cpu_baseline(workload)
         print(json.dumps(line), flush=True)
