@@ -250,6 +250,8 @@ int sisr_crop_augment(const float* const* src, const int* params, float* dst, in
 
 /* ---- diagnostics (not on the product path): sustained fp32-MFMA rate and in-kernel clock ---------- */
 int sisr_diag_mfma_peak(int blocks, int iters, float* out, unsigned long long* clk, void* stream);
+/* resident workgroups per CU the runtime computes for the plain bf16x3 (which = 0) / fp32 (1) conv kernel */
+int sisr_diag_conv_occupancy(int which);
 
 /* ---- fp32 through the bf16 matrix cores ("bf16x3", opt-in; the reference has no such mode) -----------------------
  * Same contract as sisr_conv3x3_c64_bf16, but every fp32 operand is split exactly into three bf16 numbers (hi + mid +

@@ -68,6 +68,8 @@ class TrainingHandler:
         self.max_im_val = max_im_val
         self.metrics = list(metrics) if metrics is not None else None
         if self.world > 1:
+            if os.environ.get("SISR_BENCH_SHARE_GPU"):  # rehearsal on a 1-GPU box: every rank on cuda:0
+                local = 0
             gpu, sp_gpu = 'multi', local
         if self.rank != 0 and os.path.isdir(save_loc):
             pass  # every rank builds the interface; only rank 0 writes checkpoints / logs
@@ -85,9 +87,17 @@ class TrainingHandler:
     def train(self):
         losses = defaultdict(list)
         for batch in self.train_data:
+            n = len(batch['tag'])
             if self.world > 1:
                 batch = parallel.shard_batch(batch, self.rank, self.world)
             loss, _ = self.model.train_batch(**batch)
+            if self.world > 1:  # logging only: the mean over the global batch from the ranks' shard means
+                mine = len(batch['tag'])
+                t = torch.tensor([float(loss) * mine if mine else 0.0, float(mine)], dtype=torch.float64)
+                if torch.distributed.get_backend() == 'nccl':
+                    t = t.to(self.model.model.device)
+                torch.distributed.all_reduce(t)
+                loss = np.float32(t[0].item() / n)
             losses['train-loss'].append(loss)
         losses['learning-rate'].append(self.model.get_learning_rate())
         self.model.epoch_end_calls()
@@ -120,6 +130,9 @@ class TrainingHandler:
             if i == 0 and self.rank == 0:
                 self.model.save(override=self.overwrite, dry_run=True)
             cur = dict(self.train())
+            if self.rank != 0:
+                iter(self.val_data)  # rank 0's validation iterator draws its base seed from the global torch RNG: keep
+                #                      every rank's stream -- hence next epoch's shuffle -- identical
             if self.rank == 0:
                 cur.update(self.eval(epoch_idx))
                 val_psnr = np.mean(cur['val-PSNR']) if 'val-PSNR' in cur else float('nan')

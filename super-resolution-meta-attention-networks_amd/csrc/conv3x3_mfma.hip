@@ -800,7 +800,7 @@ __device__ __forceinline__ void sisr_store_split3(unsigned char* dst, f32x4 a, f
 
 // BD = B-fragment prefetch distance in K-steps (ring of BD + 1 slots); the A fragments of step s + 1 are requested before
 // the MFMAs of step s (double buffer).
-template <bool AFFINE, bool MASK, bool RES, bool GATE = false, bool DOT = false, int BD = 4>
+template <bool AFFINE, bool MASK, bool RES, bool GATE = false, bool DOT = false, int BD = 4, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, long wplane) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -823,6 +823,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, lo
   const int Cout = p.cout_chunks * 64;
 
   const float bv = p.bias ? p.bias[co * p.bias_n + q * p.bias_q] : 0.f;
+  unsigned long long st0 = 0, st1 = 0, st2 = 0;  // STAMP: diagnostic build (tools/x3_phases.py), outputs meaningless
+  if (STAMP) st0 = __builtin_amdgcn_s_memtime();
   f32x16 acc0, acc1, cor0 = {0}, cor1 = {0};  // hi*hi products / the five correction products
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = bv;
@@ -940,6 +942,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, lo
     }
     __syncthreads();
 
+    if (STAMP) st1 = __builtin_amdgcn_s_memtime();
     // ---- K loop: 36 steps (tap t = s >> 2, 16-channel block kb = s & 3); per step and M-tile six MFMAs:
     // hi*hi into the main accumulator, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid into the correction accumulator
     const unsigned char* wq = wbase + ((long)q * p.cin_chunks + c) * (36 * 2048);  // scalar
@@ -993,6 +996,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, lo
 #undef BF_LOAD_B
   }
 
+  if (STAMP) st2 = __builtin_amdgcn_s_memtime();
   acc0 += cor0;
   acc1 += cor1;
   // ---- epilogue.  The kernel is HBM-bound, so output / mask / residual traffic must move as whole 256-B pixel
@@ -1072,6 +1076,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, lo
         const long parts = (long)p.tiles_w * p.tiles_h * 2;
         p.gap[(((long)b * parts) + tile * 2 + strip) * Cout + q * 64 + chn] = sacc;
       }
+    }
+  }
+  if (STAMP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && p.dot) {  // the stamp buffer rides in p.dot (unused by this instantiation)
+      unsigned* dbg = reinterpret_cast<unsigned*>(const_cast<float*>(p.dot)) + ((long)blockIdx.x * 4 + wave) * 4;
+      dbg[0] = (unsigned)(st1 - st0);
+      dbg[1] = (unsigned)(st2 - st1);
+      dbg[2] = (unsigned)(st3 - st2);
+      dbg[3] = (unsigned)(st0 & 0xffffffffu);
     }
   }
 }
@@ -1924,6 +1939,11 @@ extern "C" int sisr_conv3x3_c64_x3(const float* x, const int64_t* xview, const v
     SISR_ALLOW_LDS((conv3x3_c64_x3_kernel<AF, MK, RS, GT, DT>), lb);                                   \
     hipLaunchKernelGGL((conv3x3_c64_x3_kernel<AF, MK, RS, GT, DT>), grid, dim3(256), lb, st, p, wplane); \
   } while (0)
+  if (getenv("SISR_X3_STAMP") && dot && !gate && !in_scale && !mask && !res) {  // tools/x3_phases.py
+    SISR_ALLOW_LDS((conv3x3_c64_x3_kernel<false, false, false, false, false, 4, true>), lb);
+    hipLaunchKernelGGL((conv3x3_c64_x3_kernel<false, false, false, false, false, 4, true>), grid, dim3(256), lb, st, p, wplane);
+    return sisr_check_launch();
+  }
   static const int x3_bd = getenv("SISR_X3_BD") ? atoi(getenv("SISR_X3_BD")) : 4;  // diagnostic A/B of the plain form
   if (x3_bd == 6 && !gate && !dot && !in_scale && !mask && !res) {
     SISR_ALLOW_LDS((conv3x3_c64_x3_kernel<false, false, false, false, false, 6>), lb);
@@ -1959,4 +1979,18 @@ extern "C" int sisr_pack_conv3x3_x3_both(const float* w, void* packed_fwd, void*
   hipLaunchKernelGGL(pack_conv3x3_x3_both_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
                      static_cast<__bf16*>(packed_fwd), static_cast<__bf16*>(packed_dgrad), cout, cin, shuffle_r);
   return sisr_check_launch();
+}
+
+// Diagnostic: resident workgroups per CU the runtime computes for the plain bf16x3 / fp32 kernels with their LDS sizes.
+extern "C" int sisr_diag_conv_occupancy(int which) {
+  int n = -1;
+  if (which == 0) {
+    const size_t lb = 3 * (size_t)X3_PLANE;
+    SISR_ALLOW_LDS((conv3x3_c64_x3_kernel<false, false, false, false, false>), lb);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_c64_x3_kernel<false, false, false, false, false>, 256, lb) != hipSuccess) return -2;
+  } else {
+    const size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3_c64_v4_kernel<false, false, false, 2>, 256, lb) != hipSuccess) return -2;
+  }
+  return n;
 }

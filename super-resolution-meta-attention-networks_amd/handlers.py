@@ -34,8 +34,7 @@ class L1Loss(nn.Module):
 
 def create_dir_if_empty(*directories):
     for d in directories:
-        if not os.path.exists(d):
-            os.mkdir(d)
+        os.makedirs(d, exist_ok=True)  # exist_ok: every rank of a data-parallel run builds the interface
 
 
 class BaseModel(nn.Module):
@@ -155,20 +154,27 @@ class BaseModel(nn.Module):
         return state
 
     # -- train / eval steps (ref :466-533)
-    def train_step(self, x, y, tag=None, **kwargs):
+    def train_step(self, x, y, tag=None, loss_scale=1.0, **kwargs):
         """run_train without its host round trips: returns (loss, out) as device tensors and never
-        synchronises, so consecutive steps queue back to back on the stream."""
+        synchronises, so consecutive steps queue back to back on the stream.
+        loss_scale: weight of this rank's mean loss in the data-parallel average (parallel.shard_batch sets it for
+        ragged batches); 0 with an empty shard = take part in the gradient exchange and the update with zero gradients."""
         if self.eval_mode:
             raise RuntimeError('Model initialized in eval mode, training not possible.')
         self.net.train()
         x, y = x.to(device=self.device), y.to(device=self.device)
-        if self.use_graph and x.is_cuda:
+        if x.shape[0] == 0:
+            self.optimizer.zero_grad()
+            self._finish_update()
+            nan = torch.full((), float('nan'), device=x.device)
+            return nan, x.new_zeros((0,) + tuple(y.shape[1:]))
+        if self.use_graph and x.is_cuda and loss_scale == 1.0:
             return self._graphed_step(x, y, kwargs)
         try:
             ops.pack_all(self.net, A.conv_weights)  # every conv weight repacked by one launch
             out = self.run_model(x, image_names=tag, **kwargs)
             loss = self.criterion(out, y)
-            self.standard_update(loss)
+            self.standard_update(loss if loss_scale == 1.0 else loss * loss_scale)
         finally:
             ops.invalidate_packs()  # the optimiser moved the weights
         return loss.detach(), out.detach()
@@ -242,6 +248,9 @@ class BaseModel(nn.Module):
     def standard_update(self, loss):
         self.optimizer.zero_grad()
         loss.backward()
+        self._finish_update()
+
+    def _finish_update(self):
         if self.reducer is not None:
             self.reducer.reduce()
         if self.grad_clip is not None:

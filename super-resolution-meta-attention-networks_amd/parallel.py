@@ -40,28 +40,33 @@ def init_distributed(backend=None):
 
 def shard_batch(batch, rank, world):
     """Contiguous rank slice of a collated batch dict (ref schema: sr_tools/data_handler.py:516-525).
-    'metadata_keys' is default_collate's list[M] of B-tuples, so it is sliced per entry."""
-    def sl(n):
-        if n % world:
-            raise ValueError(f"global batch {n} is not divisible by world size {world}")
-        per = n // world
-        return slice(rank * per, (rank + 1) * per)
+    'metadata_keys' is default_collate's list[M] of B-tuples, so it is sliced per entry.
 
-    out = {}
+    A batch that does not divide by the world size (the reference keeps the ragged last batch of an epoch:
+    drop_last_training_batch defaults to False, and its DataParallel scatters unevenly) is cut unevenly: the first
+    n % world ranks take one sample more.  The slice then carries 'loss_scale' = n_r * world / n, the factor that
+    turns the mean of the ranks' mean losses -- what averaging the all-reduced gradients computes -- back into the
+    mean over the n samples.  A rank left without a sample gets 'loss_scale' = 0 and empty tensors."""
     n = None
     for k, v in batch.items():
         if torch.is_tensor(v) and v.dim() > 0:
             n = v.shape[0]
             break
+    base, extra = divmod(n, world)
+    start = rank * base + min(rank, extra)
+    sl = slice(start, start + base + (1 if rank < extra else 0))
+    out = {}
     for k, v in batch.items():
         if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n:
-            out[k] = v[sl(n)]
+            out[k] = v[sl]
         elif k == "metadata_keys" and isinstance(v, (list, tuple)):
-            out[k] = [tuple(e[sl(n)]) if isinstance(e, (list, tuple)) and len(e) == n else e for e in v]
+            out[k] = [tuple(e[sl]) if isinstance(e, (list, tuple)) and len(e) == n else e for e in v]
         elif isinstance(v, (list, tuple)) and len(v) == n:
-            out[k] = list(v[sl(n)])
+            out[k] = list(v[sl])
         else:
             out[k] = v
+    if extra:
+        out["loss_scale"] = (sl.stop - sl.start) * world / n
     return out
 
 

@@ -88,6 +88,56 @@ def test_two_rank_gradients_match_single_process(overlap):
     assert torch.allclose(res[0][0], ref, rtol=1e-5, atol=1e-7)
 
 
+def _ragged_worker(rank, world, port, n, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sisr_amd
+    sisr_amd.parallel.init_distributed(backend="gloo")
+    torch.manual_seed(100)
+    net = TinyNet()
+    red = sisr_amd.parallel.GradReducer(net, bucket_mb=0.004)
+    g = torch.Generator().manual_seed(6)
+    x, y = torch.rand(n, 3, 8, 8, generator=g), torch.rand(n, 3, 8, 8, generator=g)
+    shard = sisr_amd.parallel.shard_batch({"lr": x, "hr": y, "tag": [str(i) for i in range(n)]}, rank, world)
+    net.zero_grad()
+    if shard["lr"].shape[0]:
+        (F.l1_loss(net(shard["lr"]), shard["hr"]) * shard.get("loss_scale", 1.0)).backward()
+    red.reduce()
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in net.parameters()])
+    out_q.put((rank, flat, shard["tag"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [3, 1])
+def test_ragged_batch_is_cut_unevenly_and_weighted(n):
+    """The reference keeps an epoch's ragged last batch (drop_last False) and its DataParallel scatters it unevenly.
+    shard_batch gives the first n % world ranks one sample more and a 'loss_scale' = n_r * world / n; with it the averaged
+    gradient is the single-process gradient of the n samples -- also when a rank gets no sample at all (n = 1)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29820 + (os.getpid() % 150) + n
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, flat, tags = q.get(timeout=120)
+        res[rank] = (flat, tags)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] + res[1][1] == [str(i) for i in range(n)] and len(res[0][1]) == (n + 1) // 2
+    torch.manual_seed(100)
+    net = TinyNet()
+    g = torch.Generator().manual_seed(6)
+    x, y = torch.rand(n, 3, 8, 8, generator=g), torch.rand(n, 3, 8, 8, generator=g)
+    F.l1_loss(net(x), y).backward()
+    ref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in net.parameters()])
+    assert torch.allclose(res[0][0], ref, rtol=1e-5, atol=1e-7) and torch.equal(res[0][0], res[1][0])
+
+
 def test_reducer_needs_process_group():
     sys.path.insert(0, ROOT)
     import sisr_amd

@@ -113,3 +113,42 @@ def test_device_tiles_reproduce_the_reference_run(name, tmp_path):
     np.testing.assert_allclose(total["train-loss"], ref["train-loss"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(total["val-loss"], ref["val-loss"], rtol=5e-4, atol=5e-5)
     np.testing.assert_allclose(total["val-PSNR"], ref["val-PSNR"], rtol=0, atol=5e-3)
+
+
+@pytest.mark.gpu
+def test_two_rank_cli_training_reproduces_the_reference_run(tmp_path):
+    """`gpu = 'multi'` through the train entry point with TWO ranks (both on cuda:0, gloo transport) on the reference's
+    own example experiment (G5: EDSR, batch 2, five Set5 images -> batches of 2, 2 and a ragged 1 per epoch, two epochs):
+    every global batch is cut across the ranks (1 + 1, 1 + 1, 1 + 0), gradients are averaged with the ragged-batch
+    weights, every rank walks the same shuffle in both epochs, rank 0 validates and writes -- and summary.csv is the
+    reference's single-process one."""
+    import json
+    import subprocess
+    import sys
+    ref = golden_json("g5_train_sisr")["edsr"]["summary"]
+    cfg = _config("edsr", tmp_path)
+    cfg["training"]["gpu"] = "multi"
+    cfg["training"]["sp_gpu"] = 0
+    cfg_path = os.path.join(str(tmp_path), "cfg.json")
+    with open(cfg_path, "w") as f:
+        json.dump(cfg, f)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys, json; sys.path.insert(0, {root!r}); import sisr_amd\n"
+            f"total = sisr_amd.cli.train_sisr(json.load(open({cfg_path!r})))\n"
+            "import torch.distributed as dist\n"
+            f"\nif dist.get_rank() == 0: json.dump({{k: [float(x) for x in v] for k, v in total.items()}}, open({cfg_path!r} + '.out', 'w'))\n"
+            "dist.barrier(); dist.destroy_process_group()\n")
+    env = dict(os.environ, SISR_DIST_BACKEND="gloo", SISR_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    prog = os.path.join(str(tmp_path), "run.py")
+    with open(prog, "w") as f:
+        f.write(code)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29777", prog], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    total = json.load(open(cfg_path + ".out"))
+    np.testing.assert_allclose(total["train-loss"], ref["train-loss"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(total["val-loss"], ref["val-loss"], rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(total["val-PSNR"], ref["val-PSNR"], rtol=0, atol=5e-3)
