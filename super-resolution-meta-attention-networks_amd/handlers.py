@@ -64,10 +64,12 @@ class BaseModel(nn.Module):
     # -- optimiser / scheduler (ref :292-335)
     def define_optimizer(self, lr=1e-4, optimizer_params=None):
         params = [p for p in self.net.parameters() if p.requires_grad]
-        if optimizer_params is not None:
-            self.optimizer = optim.Adam(params, lr=lr, betas=(optimizer_params['beta_1'], optimizer_params['beta_2']))
-        else:
-            self.optimizer = optim.Adam(params, lr=lr)
+        betas = (optimizer_params['beta_1'], optimizer_params['beta_2']) if optimizer_params is not None else (0.9, 0.999)
+        if params and all(p.is_cuda for p in params) and os.environ.get("SISR_FLAT_ADAM", "1") != "0":
+            from .optim import FlatAdam  # one-launch Adam over a flat arena, torch.optim.Adam's schema (optim.py)
+            self.optimizer = FlatAdam(params, lr=lr, betas=betas)
+        else:  # CPU handlers exist for construction / checkpoint plumbing only and are never stepped
+            self.optimizer = optim.Adam(params, lr=lr, betas=betas)
 
     def define_scheduler(self, scheduler, scheduler_params):
         if scheduler == 'cosine_annealing_warm_restarts':
@@ -106,7 +108,9 @@ class BaseModel(nn.Module):
     def set_multi_gpu(self, device_ids=None):
         """One process per GPU: gradients are averaged over the torch.distributed (RCCL) world."""
         from .parallel import GradReducer
-        self.reducer = GradReducer(self.net)
+        self.reducer = GradReducer(self.net, arena=getattr(self.optimizer, 'grad_views', None),
+                                   arena_flat=getattr(self.optimizer, 'flat_g', None),
+                                   arena_offsets=getattr(self.optimizer, 'offsets', None))
 
     # -- checkpoints (ref :349-464)
     def save_model(self, model_save_name, model_idx, extract_state_only=False):

@@ -71,7 +71,11 @@ def shard_batch(batch, rank, world):
 
 
 class GradReducer:
-    def __init__(self, net, bucket_mb=8.0, process_group=None, overlap=True):
+    def __init__(self, net, bucket_mb=8.0, process_group=None, overlap=True, arena=None, arena_flat=None,
+                 arena_offsets=None):
+        """arena / arena_flat / arena_offsets: optim.FlatAdam's gradient views, flat gradient buffer and parameter
+        offsets.  With them a bucket IS a slice of that buffer (buckets are runs of consecutive parameters), so the
+        gradients are all-reduced where the optimiser reads them and nothing is copied back."""
         if not dist.is_initialized():
             raise RuntimeError("gpu='multi' runs one process per GPU: launch with "
                                "`python -m torch.distributed.run --nproc-per-node N ...` "
@@ -91,16 +95,26 @@ class GradReducer:
         if cur:
             self.buckets.append(cur)
         dev = self.params[0].device
-        self.flat = [torch.zeros(sum(p.numel() for p in b), device=dev) for b in self.buckets]
         self.bucket_of = {}
         for bi, b in enumerate(self.buckets):
             for p in b:
                 self.bucket_of[p] = bi
         # views of the buckets in parameter shapes; conv weights advertise theirs to the weight-gradient kernels
         self.views = {}
-        for b, flat in zip(self.buckets, self.flat):
-            for p, piece in zip(b, flat.split([p.numel() for p in b])):
-                self.views[p] = piece.view_as(p)
+        if arena is not None and all(p in arena for p in self.params):
+            self.flat = []
+            for b in self.buckets:  # reversed registration order: b[-1] has the lowest offset
+                lo = min(arena_offsets[p] for p in b)
+                hi = max(arena_offsets[p] + (p.numel() + 3) // 4 * 4 for p in b)
+                if hi - lo != sum((p.numel() + 3) // 4 * 4 for p in b):
+                    raise RuntimeError("GradReducer: bucket is not a contiguous run of the optimiser's gradient arena")
+                self.flat.append(arena_flat[lo:hi])
+            self.views = {p: arena[p] for p in self.params}
+        else:
+            self.flat = [torch.zeros(sum(p.numel() for p in b), device=dev) for b in self.buckets]
+            for b, flat in zip(self.buckets, self.flat):
+                for p, piece in zip(b, flat.split([p.numel() for p in b])):
+                    self.views[p] = piece.view_as(p)
         if self.cuda:
             from . import ops
             for p, view in self.views.items():
