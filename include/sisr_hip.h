@@ -13,7 +13,8 @@
  *  - Return 0 on success, negative on error: -1 bad argument, -2 misaligned pointer/stride
  *    (16-byte alignment is required for activations), -3-16*hipError launch failure, -4 unsupported
  *    shape (channel counts must be multiples of 64 on the matrix-core kernels).
- *  - Re-entrant and thread-safe: no global state.
+ *  - Re-entrant and thread-safe: no global state (kernel-variant choices are per-call `select` arguments; the
+ *    diagnostic entry points at the end exist only in libsisr_hip_diag.so, built with -DSISR_DIAG).
  *  - fp32 everywhere.  Activations are NHWC in 64-channel chunks described by a 6-element int64
  *    "view": {sB, sH, sW, chi, clo, cdiv}; element (b,h,w,chunk q,c) is at
  *        base + b*sB + h*sH + w*sW + (q / cdiv)*chi + (q % cdiv)*clo + c        (strides in floats)
@@ -56,14 +57,13 @@ int sisr_pack_conv3x3_both(const float* w, float* packed_fwd, float* packed_dgra
 size_t sisr_pack_job_bytes(void);
 int sisr_pack_conv3x3_many(const void* jobs_device, int n_jobs, int total_blocks, int bf16, void* stream);
 int sisr_conv3x3_c64_gap_parts(int H, int W);
-int sisr_conv3x3_c64_set_variant(int v); /* 4 issue-lean kernel, tile height by grid size, + general fallback (default);
-                                             5 / 6 force its 4-row / 2-row tile; 2 general kernel only;
-                                             13 / 16 diagnostic builds (no operand loads / phase stamps) */
 int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked, const float* bias, int bias_n,
                      int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,
                      const float* in_scale, const float* in_shift, const float* out_scale, float alpha, int relu,
                      float* gap_partial, const float* gate_add, float* gate_out, const float* dot, int B, int H,
-                     int W, int cin, int cout, void* stream);
+                     int W, int cin, int cout, int select, void* stream);
+/* select: 0 (= 4) issue-lean kernel, tile height chosen by grid size, general kernel as fallback; 5 / 6 the same with
+ * the 4-row / 2-row tile forced (bit-identical results; A/B measurements and tests); 2 general kernel only. */
 /* gate_add / gate_out / dot (all nullable; 64 -> 64, x and y in one layout) fuse the gated-residual chain of
  * RCAB / QRCAB stacks (ref: advanced/architectures.py:68-71, :107-110) into the neighbouring convs:
  *   gate_add + gate_out : the conv reads  x * in_scale[b,c] + gate_add  (the previous block's `res * y + x`) and
@@ -200,8 +200,8 @@ int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const void* wpac
                           int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,
                           const float* in_scale, const float* in_shift, const float* out_scale, float alpha, int relu,
                           float* gap_partial, const float* gate_add, float* gate_out, const float* dot,
-                          int B, int H, int W, int cin, int cout, void* stream);
-int sisr_conv3x3_c64_bf16_set_persistent(int on); /* A/B switch: persistent double-buffered tile loop (default 1) */
+                          int B, int H, int W, int cin, int cout, int select, void* stream);
+/* select: 0 persistent double-buffered tile loop where it applies (64 -> 64, >= 1024 tiles), 1 per-tile kernel */
 size_t sisr_wgrad3x3_c64_bf16_workspace_bytes(int B, int H, int W, int cin, int cout);
 int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
                            const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so, int64_t si,
@@ -251,9 +251,11 @@ int sisr_adam_flat(float* p, const float* g, float* m, float* v, long n, float b
 int sisr_crop_augment(const float* const* src, const int* params, float* dst, int B, int C, int crop, void* stream);
 
 /* ---- diagnostics (not on the product path): sustained fp32-MFMA rate and in-kernel clock ---------- */
+#ifdef SISR_DIAG /* libsisr_hip_diag.so only (csrc/build.sh diag): not part of the product library */
 int sisr_diag_mfma_peak(int blocks, int iters, float* out, unsigned long long* clk, void* stream);
 /* resident workgroups per CU the runtime computes for the plain bf16x3 (which = 0) / fp32 (1) conv kernel */
 int sisr_diag_conv_occupancy(int which);
+#endif
 
 /* ---- fp32 through the bf16 matrix cores ("bf16x3", opt-in; the reference has no such mode) -----------------------
  * Same contract as sisr_conv3x3_c64_bf16, but every fp32 operand is split exactly into three bf16 numbers (hi + mid +
@@ -266,7 +268,7 @@ int sisr_conv3x3_c64_x3(const float* x, const int64_t* xview, const void* wpacke
                         int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,
                         const float* in_scale, const float* in_shift, const float* out_scale, float alpha, int relu,
                         float* gap_partial, const float* gate_add, float* gate_out, const float* dot, int B, int H,
-                        int W, int cin, int cout, void* stream);
+                        int W, int cin, int cout, int select /* must be 0 */, void* stream);
 
 /* weight / bias gradient in the same arithmetic (contract of sisr_wgrad3x3_c64) */
 size_t sisr_wgrad3x3_c64_x3_workspace_bytes(int B, int H, int W, int cin, int cout);

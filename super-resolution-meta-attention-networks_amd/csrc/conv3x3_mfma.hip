@@ -1626,14 +1626,7 @@ extern "C" int sisr_pack_conv3x3_many(const void* jobs_device, int n_jobs, int t
 // Kernel selection (process-wide, read-only during launches): 4 = issue-lean kernel (2-row tiles on small grids,
 // 4-row tiles otherwise) with the general kernel as fallback (default); 5 / 6 = the same with the 4-row / 2-row
 // tile forced; 2 = general kernel only; 13 / 16 = diagnostic builds of the general kernel (see above).
-static int g_conv_variant = 4;
 #define SMALL_GRID_BLOCKS 200  // 4-row-tile workgroups below which the 2-row kernel is used (measured: 1.6x at 128, a tie or worse from 256 up)
-extern "C" int sisr_conv3x3_c64_set_variant(int v) {
-  if (v != 4 && v != 5 && v != 6 && v != 2 && v != 13 && v != 16) return SISR_ERR_ARG;
-  g_conv_variant = v;
-  return SISR_OK;
-}
-
 extern "C" int sisr_conv3x3_c64_gap_parts(int H, int W) { return ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * 2; }
 
 extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked, const float* bias,
@@ -1641,8 +1634,19 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
                                 const float* mask, const float* in_scale, const float* in_shift,
                                 const float* out_scale, float alpha, int relu, float* gap_partial,
                                 const float* gate_add, float* gate_out, const float* dot, int B, int H, int W, int cin,
-                                int cout, void* stream) {
+                                int cout, int select, void* stream) {
   if (!x || !wpacked || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  // select (per call; the library keeps no state): 0 / 4 = issue-lean kernel, tile height by grid size, general kernel
+  // as fallback; 5 / 6 = the same with the 4-row / 2-row tile forced (A/B measurements, bit-identical results);
+  // 2 = general kernel only.  Diagnostic builds (-DSISR_DIAG) add 13 / 16.
+  const int variant = select == 0 ? 4 : select;
+#ifdef SISR_DIAG
+  if (variant != 4 && variant != 5 && variant != 6 && variant != 2 && variant != 13 &&
+      variant != 16)
+    return SISR_ERR_ARG;
+#else
+  if (variant != 4 && variant != 5 && variant != 6 && variant != 2) return SISR_ERR_ARG;
+#endif
   if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
   if (!sisr_aligned16(x) || !sisr_aligned16(wpacked) || !sisr_aligned16(in_scale) || !sisr_aligned16(in_shift))
     return SISR_ERR_ALIGN;
@@ -1686,7 +1690,7 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
       return SISR_ERR_UNSUPPORTED;
     if (memcmp(xview, yview, 6 * sizeof(int64_t)) != 0) return SISR_ERR_UNSUPPORTED;  // skip / dot share one layout
     hipStream_t st = (hipStream_t)stream;
-    const bool small = g_conv_variant == 6 || (g_conv_variant != 5 && nblk < SMALL_GRID_BLOCKS);
+    const bool small = variant == 6 || (variant != 5 && nblk < SMALL_GRID_BLOCKS);
     const bool rs = res != nullptr;
     dim3 g = grid;
     size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
@@ -1706,13 +1710,13 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
 #undef V4X
     return sisr_check_launch();
   }
-  if (g_conv_variant == 4 || g_conv_variant == 5 || g_conv_variant == 6) {
+  if (variant == 4 || variant == 5 || variant == 6) {
     const bool aff = in_scale != nullptr, msk = mask != nullptr, rs = res != nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (!(in_shift && !in_scale) && !(aff && !msk) && !(msk && rs)) {
       // Grids with fewer 4-row workgroups than CUs (a single 128x128 sample) leave half the chip idle: halve the tile.  Variant 5 / 6 force
       // the 4-row / 2-row kernel (A/B measurements); results are bit-identical either way.
-      const bool small = g_conv_variant == 6 || (g_conv_variant == 4 && nblk * p.cout_chunks < SMALL_GRID_BLOCKS);
+      const bool small = variant == 6 || (variant == 4 && nblk * p.cout_chunks < SMALL_GRID_BLOCKS);
       if (small) {
         p.tiles_h = (H + 1) / 2;
         const dim3 grid2((unsigned)((long)p.tiles_w * p.tiles_h * B), p.cout_chunks);
@@ -1743,21 +1747,15 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
     return sisr_check_launch();
   }
   const size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
-  if (g_conv_variant == 13)
+#ifdef SISR_DIAG
+  if (variant == 13)
     hipLaunchKernelGGL(conv3x3_c64_kernel<3>, grid, dim3(256), lb, (hipStream_t)stream, p);
-  else if (g_conv_variant == 16)
+  else if (variant == 16)
     hipLaunchKernelGGL(conv3x3_c64_kernel<6>, grid, dim3(256), lb, (hipStream_t)stream, p);
   else
+#endif
     hipLaunchKernelGGL(conv3x3_c64_kernel<0>, grid, dim3(256), lb, (hipStream_t)stream, p);
   return sisr_check_launch();
-}
-
-// Process-wide A/B switch for the bf16 conv: 1 = persistent double-buffered kernel where it applies (default),
-// 0 = one workgroup per tile everywhere.
-static int g_bf16_persist = 1;
-extern "C" int sisr_conv3x3_c64_bf16_set_persistent(int on) {
-  g_bf16_persist = on ? 1 : 0;
-  return SISR_OK;
 }
 
 extern "C" int sisr_pack_conv3x3_bf16_both(const float* w, void* packed_fwd, void* packed_dgrad, int cout, int cin,
@@ -1777,8 +1775,10 @@ extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const
                                      const float* mask, const float* in_scale, const float* in_shift,
                                      const float* out_scale, float alpha, int relu, float* gap_partial,
                                      const float* gate_add, float* gate_out, const float* dot, int B, int H, int W,
-                                     int cin, int cout, void* stream) {
+                                     int cin, int cout, int select, void* stream) {
   if (!x || !wpacked_bf16 || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if (select != 0 && select != 1) return SISR_ERR_ARG;
+  const bool persist = select != 1;  // per call: 0 = persistent tile loop where it applies, 1 = per-tile kernel
   const bool gate = gate_add != nullptr;
   if (gate_add || gate_out || dot) {  // fused gated-residual chain, same contract as the fp32 entry
     if (gate != (gate_out != nullptr) || (gate && !in_scale) || (gate && dot) || (dot && !gap_partial) ||
@@ -1825,7 +1825,7 @@ extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const
   const size_t lb_halo = HALO_H * HALO_W * BH_PIX, lb_out = TH * TW * BE_LD * sizeof(float);
   const size_t lb = lb_halo > lb_out ? lb_halo : lb_out;
   hipStream_t st = (hipStream_t)stream;
-  if (g_bf16_persist && cin == 64 && cout == 64 && nblk >= 1024) {
+  if (persist && cin == 64 && cout == 64 && nblk >= 1024) {
     // 64 -> 64 with enough tiles to give every persistent workgroup at least two: the double-buffered tile loop
     const int G = 512;  // two workgroups per CU
     const size_t plb = 2 * (size_t)PB_BUF;
@@ -1885,8 +1885,9 @@ extern "C" int sisr_conv3x3_c64_x3(const float* x, const int64_t* xview, const v
                                      const float* mask, const float* in_scale, const float* in_shift,
                                      const float* out_scale, float alpha, int relu, float* gap_partial,
                                      const float* gate_add, float* gate_out, const float* dot, int B, int H, int W,
-                                     int cin, int cout, void* stream) {
+                                     int cin, int cout, int select, void* stream) {
   if (!x || !wpacked_bf16 || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if (select != 0) return SISR_ERR_ARG;  // one kernel family; the argument keeps the three conv entries call-compatible
   const bool gate = gate_add != nullptr;
   if (gate_add || gate_out || dot) {  // fused gated-residual chain, same contract as the fp32 entry
     if (gate != (gate_out != nullptr) || (gate && !in_scale) || (gate && dot) || (dot && !gap_partial) ||
@@ -1939,6 +1940,7 @@ extern "C" int sisr_conv3x3_c64_x3(const float* x, const int64_t* xview, const v
     SISR_ALLOW_LDS((conv3x3_c64_x3_kernel<AF, MK, RS, GT, DT>), lb);                                   \
     hipLaunchKernelGGL((conv3x3_c64_x3_kernel<AF, MK, RS, GT, DT>), grid, dim3(256), lb, st, p, wplane); \
   } while (0)
+#ifdef SISR_DIAG
   if (getenv("SISR_X3_STAMP") && dot && !gate && !in_scale && !mask && !res) {  // tools/x3_phases.py
     SISR_ALLOW_LDS((conv3x3_c64_x3_kernel<false, false, false, false, false, 4, true>), lb);
     hipLaunchKernelGGL((conv3x3_c64_x3_kernel<false, false, false, false, false, 4, true>), grid, dim3(256), lb, st, p, wplane);
@@ -1950,6 +1952,7 @@ extern "C" int sisr_conv3x3_c64_x3(const float* x, const int64_t* xview, const v
     hipLaunchKernelGGL((conv3x3_c64_x3_kernel<false, false, false, false, false, 6>), grid, dim3(256), lb, st, p, wplane);
     return sisr_check_launch();
   }
+#endif
   if (gate) { if (res) X3L(false, false, true, true, false); else X3L(false, false, false, true, false); }
   else if (dot) { if (res) X3L(false, false, true, false, true); else X3L(false, false, false, false, true); }
   else {
@@ -1981,6 +1984,7 @@ extern "C" int sisr_pack_conv3x3_x3_both(const float* w, void* packed_fwd, void*
   return sisr_check_launch();
 }
 
+#ifdef SISR_DIAG
 // Diagnostic: resident workgroups per CU the runtime computes for the plain bf16x3 / fp32 kernels with their LDS sizes.
 extern "C" int sisr_diag_conv_occupancy(int which) {
   int n = -1;
@@ -1994,3 +1998,4 @@ extern "C" int sisr_diag_conv_occupancy(int which) {
   }
   return n;
 }
+#endif

@@ -20,9 +20,8 @@ _SIGS = {
     "sisr_pack_conv3x3": (c_int, [P, P, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_pack_conv3x3_both": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "sisr_conv3x3_c64_gap_parts": (c_int, [c_int, c_int]),
-    "sisr_conv3x3_c64_set_variant": (c_int, [c_int]),
     "sisr_conv3x3_c64": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int, c_int,
-                                 c_int, c_int, c_int, P]),
+                                 c_int, c_int, c_int, c_int, P]),
     "sisr_wgrad3x3_c64_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "sisr_wgrad3x3_c64": (c_int, [P, P, P, P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
                                   c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
@@ -46,12 +45,13 @@ _SIGS = {
     "sisr_sum_partials": (c_int, [P, c_int, c_int, c_int, c_float, P, P]),
     "sisr_l1_loss_workspace_bytes": (c_size_t, []),
     "sisr_l1_loss": (c_int, [P, P, c_long, P, P, P, P]),
-    "sisr_diag_mfma_peak": (c_int, [c_int, c_int, P, P, P]),
-    "sisr_diag_conv_occupancy": (c_int, [c_int]),
     "sisr_crop_augment": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "sisr_adam_flat": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_float, P]),
 }
-OPTIONAL_SIGS = {}
+OPTIONAL_SIGS = {  # only in libsisr_hip_diag.so (csrc/build.sh diag; select it with SISR_HIP_LIB)
+    "sisr_diag_mfma_peak": (c_int, [c_int, c_int, P, P, P]),
+    "sisr_diag_conv_occupancy": (c_int, [c_int]),
+}
 _SIGS.update({
     "sisr_lam_workspace_bytes": (c_size_t, [c_int, c_int, c_long]),
     "sisr_lam_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_long, P]),
@@ -62,9 +62,8 @@ _SIGS.update({
 })
 _SIGS.update({  # bf16 matrix-core variants (csrc/conv3x3_mfma.hip, csrc/wgrad3x3_mfma.hip)
     "sisr_pack_conv3x3_bf16_both": (c_int, [P, P, P, c_int, c_int, c_int, P]),
-    "sisr_conv3x3_c64_bf16_set_persistent": (c_int, [c_int]),
     "sisr_conv3x3_c64_bf16": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int, c_int,
-                                 c_int, c_int, c_int, P]),
+                                 c_int, c_int, c_int, c_int, P]),
     "sisr_wgrad3x3_c64_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "sisr_wgrad3x3_c64_bf16": (c_int, [P, P, P, P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
                                   c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
@@ -92,7 +91,7 @@ _SIGS.update({  # fp32 through the bf16 matrix cores: three-way operand split, s
     "sisr_wgrad3x3_c64_x3": (c_int, [P, P, P, P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
                                 c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_conv3x3_c64_x3": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int, c_int,
-                               c_int, c_int, c_int, P]),
+                               c_int, c_int, c_int, c_int, P]),
 })
 _SIGS.update({  # on-the-fly degradation (csrc/degrade.hip)
     "sisr_blur_quant": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -261,7 +261,8 @@ def pack_pair(w, shuffle=1):
 
 
 def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=None, mask=None, in_scale=None,
-             in_shift=None, out_scale=None, alpha=1.0, relu=False, gap=None, gate_add=None, gate_out=None, dot=None):
+             in_shift=None, out_scale=None, alpha=1.0, relu=False, gap=None, gate_add=None, gate_out=None, dot=None,
+             select=0):
     L = hip.lib()
     # the packing decides: a weight packed under one mode runs under it (three bf16 planes = the bf16x3 split)
     if packed.dtype != torch.bfloat16:
@@ -272,7 +273,7 @@ def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=
         fn, name = L.sisr_conv3x3_c64_bf16, "sisr_conv3x3_c64_bf16"
     rc = fn(hip.ptr(x), xview, _wptr(packed), hip.ptr(bias), bias_nq[0], bias_nq[1], hip.ptr(y), yview, hip.ptr(res),
             hip.ptr(mask), hip.ptr(in_scale), hip.ptr(in_shift), hip.ptr(out_scale), float(alpha), int(relu),
-            hip.ptr(gap), hip.ptr(gate_add), hip.ptr(gate_out), hip.ptr(dot), B, H, W, cin, cout, hip.stream())
+            hip.ptr(gap), hip.ptr(gate_add), hip.ptr(gate_out), hip.ptr(dot), B, H, W, cin, cout, int(select), hip.stream())
     hip.check(rc, name)
 
 

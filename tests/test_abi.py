@@ -10,6 +10,7 @@ def _declared():
     with open(os.path.join(ROOT, "include", "sisr_hip.h")) as f:
         src = f.read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef SISR_DIAG.*?#endif", "", src, flags=re.S)  # diagnostic entries: libsisr_hip_diag.so only
     return sorted(set(re.findall(r"\b(sisr_\w+)\s*\(", src)))
 
 
@@ -31,6 +32,17 @@ def test_binding_table_matches_header():
     import sisr_amd
     bound = set(sisr_amd.hip.exported_symbols())
     assert set(_declared()) == bound
+
+
+def test_product_library_has_no_process_wide_switches():
+    """include/sisr_hip.h promises 'no global state': kernel-variant choices are per-call arguments, and the ablation /
+    stamp builds and probes live in libsisr_hip_diag.so only."""
+    path = os.path.join(ROOT, "super-resolution-meta-attention-networks_amd", "libsisr_hip.so")
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(path)
+    for name in ("sisr_conv3x3_c64_set_variant", "sisr_conv3x3_c64_bf16_set_persistent", "sisr_diag_mfma_peak",
+                 "sisr_diag_conv_occupancy"):
+        assert not hasattr(lib, name), name
 
 
 def test_pure_host_queries():

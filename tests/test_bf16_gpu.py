@@ -133,19 +133,16 @@ def test_persistent_conv_is_bit_identical_to_per_tile_conv(B, H, W):
              dict(in_scale=sc, gate_add=skip, gate_out=True, res=res), dict(gap=True, dot=dot),
              dict(gap=True, dot=dot, res=res)]
     outs = {}
-    try:
-        for persist in (1, 0):
-            hip.check(hip.lib().sisr_conv3x3_c64_bf16_set_persistent(persist), "set_persistent")
-            for i, kw in enumerate(cases):
-                kw = dict(kw)
-                y = torch.full((B, 64, H, W), float("nan"), device=DEV).contiguous(memory_format=cl)
-                gap = torch.full((B, ops.gap_parts(H, W), 64), float("nan"), device=DEV) if kw.pop("gap", False) else None
-                go = torch.full((B, 64, H, W), float("nan"), device=DEV).contiguous(memory_format=cl) \
-                    if kw.pop("gate_out", False) else None
-                ops.conv_c64(x, v, pk, kw.pop("bias", None), (1, 64), y, v, B, H, W, 64, 64, gap=gap, gate_out=go, **kw)
-                outs[(persist, i)] = (y, gap, go)
-    finally:
-        hip.lib().sisr_conv3x3_c64_bf16_set_persistent(1)
+    for persist in (1, 0):  # per-call kernel selection: select = 0 persistent tile loop, 1 per-tile kernel
+        for i, kw in enumerate(cases):
+            kw = dict(kw)
+            y = torch.full((B, 64, H, W), float("nan"), device=DEV).contiguous(memory_format=cl)
+            gap = torch.full((B, ops.gap_parts(H, W), 64), float("nan"), device=DEV) if kw.pop("gap", False) else None
+            go = torch.full((B, 64, H, W), float("nan"), device=DEV).contiguous(memory_format=cl) \
+                if kw.pop("gate_out", False) else None
+            ops.conv_c64(x, v, pk, kw.pop("bias", None), (1, 64), y, v, B, H, W, 64, 64, gap=gap, gate_out=go,
+                         select=0 if persist else 1, **kw)
+            outs[(persist, i)] = (y, gap, go)
     for i in range(len(cases)):
         for a, bb, what in zip(outs[(1, i)], outs[(0, i)], ("output", "gap / dot partials", "gate_out")):
             if a is not None:

@@ -71,17 +71,13 @@ def test_conv_tile_heights_are_bit_identical(B, H, W):
     cases = [dict(bias=b, relu=True, gap=True), dict(res=res, alpha=0.3), dict(mask=mask),
              dict(mask=mask, in_scale=sc, in_shift=sh)]
     outs = {}
-    try:
-        for variant in (5, 6):
-            hip.check(hip.lib().sisr_conv3x3_c64_set_variant(variant), "set_variant")
-            for i, kw in enumerate(cases):
-                kw = dict(kw)
-                y = torch.zeros(B, 64, H, W, device=DEV).contiguous(memory_format=cl)
-                gap = torch.full((B, ops.gap_parts(H, W), 64), float("nan"), device=DEV) if kw.pop("gap", False) else None
-                ops.conv_c64(x, v, pk, kw.pop("bias", None), (1, 64), y, v, B, H, W, 64, 64, gap=gap, **kw)
-                outs[(variant, i)] = (y, gap)
-    finally:
-        hip.lib().sisr_conv3x3_c64_set_variant(4)
+    for variant in (5, 6):  # per-call kernel selection (the library keeps no state)
+        for i, kw in enumerate(cases):
+            kw = dict(kw)
+            y = torch.zeros(B, 64, H, W, device=DEV).contiguous(memory_format=cl)
+            gap = torch.full((B, ops.gap_parts(H, W), 64), float("nan"), device=DEV) if kw.pop("gap", False) else None
+            ops.conv_c64(x, v, pk, kw.pop("bias", None), (1, 64), y, v, B, H, W, 64, 64, gap=gap, select=variant, **kw)
+            outs[(variant, i)] = (y, gap)
     for i in range(len(cases)):
         y5, g5 = outs[(5, i)]
         y6, g6 = outs[(6, i)]

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-workgroup phase durations of the general conv3x3_c64 kernel (stamped build, variant 16)."""
+"""Diagnostic: per-workgroup phase durations of the general conv3x3_c64 kernel (stamped build, select 16).
+Needs the diagnostic library: `bash csrc/build.sh diag` and SISR_HIP_LIB=.../libsisr_hip_diag.so."""
 import json
 import os
 import sys
@@ -21,11 +22,10 @@ pk = ops.pack_weight(w, "fwd")
 v = hip.view_plain(H, W, 64)
 nblk = B * 32 * 4
 dbg = torch.zeros(nblk * 16, dtype=torch.int32, device=dev)
-hip.lib().sisr_conv3x3_c64_set_variant(int(sys.argv[2]) if len(sys.argv) > 2 else 16)
+sel = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 for _ in range(3):
-    ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64, gap=dbg.view(torch.float32))
+    ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64, gap=dbg.view(torch.float32), select=sel)
 torch.cuda.synchronize()
-hip.lib().sisr_conv3x3_c64_set_variant(4)
 d = dbg.cpu().numpy().astype(np.int64).reshape(nblk, 4, 4) & 0xffffffff
 for name, k in (("staging", 0), ("kloop", 1), ("epilogue", 2)):
     a = d[:, :, k].reshape(-1)

@@ -77,21 +77,22 @@ def main():
     variants = [int(t) for t in a.variants.split(",")]
     if a.precision == "bf16" and a.rounds > 0:
         # interleaved A/B of the persistent (1) and per-tile (0) bf16 conv kernels, plain and dgrad-with-mask forms
-        forms = {"conv": lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64),
+        SEL = [0]
+        forms = {"conv": lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64, select=SEL[0]),
                  "conv_dgrad2": lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1, in_scale=sc,
-                                                     in_shift=sh),
-                 "conv_res": lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, res=x)}
+                                                     in_shift=sh, select=SEL[0]),
+                 "conv_res": lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, res=x, select=SEL[0])}
         for name, fn in forms.items():
             times = {0: [], 1: []}
             for r in range(a.rounds):
                 for mode in (1, 0):
-                    hip.lib().sisr_conv3x3_c64_bf16_set_persistent(mode)
+                    SEL[0] = 0 if mode else 1
                     times[mode].append(timeit(fn, a.iters, warm=1))
             for mode in (1, 0):
                 ts = sorted(times[mode])
                 print(json.dumps({"kernel": f"{name}_persist{mode}", "batch": B, "median_us": ts[len(ts) // 2] * 1e6,
                                   "min_us": ts[0] * 1e6}), flush=True)
-        hip.lib().sisr_conv3x3_c64_bf16_set_persistent(1)
+        SEL[0] = 0
         return
     if a.rounds > 0 and (not only or "conv" in only):
         # interleaved A/B (guide rule 24): rounds x variants in one process, median and min per variant
@@ -100,8 +101,8 @@ def main():
             ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64)
         for r in range(a.rounds):
             for var in variants:
-                hip.lib().sisr_conv3x3_c64_set_variant(var)
-                times[var].append(timeit(lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64), a.iters, warm=1))
+                times[var].append(timeit(lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64, select=var), a.iters,
+                                         warm=1))
         for var in variants:
             ts = sorted(times[var])
             med, mn = ts[len(ts) // 2], ts[0]
@@ -109,11 +110,10 @@ def main():
                               "median_TFLOP/s": flop / med / 1e12, "best_TFLOP/s": flop / mn / 1e12}), flush=True)
     else:
         for var in variants:
-            hip.lib().sisr_conv3x3_c64_set_variant(var)
-            run(f"conv_v{var}", lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64), flop, "TFLOP/s")
+            sel = var if a.precision == "fp32" else 0
+            run(f"conv_v{var}", lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64, select=sel), flop, "TFLOP/s")
             run(f"conv_dgrad2_v{var}", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1,
-                                                            in_scale=sc, in_shift=sh), flop, "TFLOP/s")
-    hip.lib().sisr_conv3x3_c64_set_variant(4)
+                                                            in_scale=sc, in_shift=sh, select=sel), flop, "TFLOP/s")
     run("conv_relu_gap", lambda: ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64, relu=True, gap=gap), flop,
         "TFLOP/s")
     run("conv_dgrad2", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1, in_scale=sc,

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-workgroup phase durations (cycles) of the bf16x3 conv kernel (stamped instantiation, SISR_X3_STAMP=1)
-and the resident-workgroup count the runtime reports.  python tools/x3_phases.py [batch]"""
+and the resident-workgroup count the runtime reports.  Needs the diagnostic library (`bash csrc/build.sh diag`):
+    SISR_HIP_LIB=super-resolution-meta-attention-networks_amd/libsisr_hip_diag.so python tools/x3_phases.py [batch]"""
 import json
 import os
 import sys
