@@ -420,53 +420,52 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
   const long tile_base = (long)b * p.yv.sB + p.yv.chunk(q) + (long)w0 * p.yv.sW;  // scalar
   const bool full = (h0 + THv <= H) && (w0 + TW <= W);                             // scalar
   float grow[2] = {0.f, 0.f};  // per output row: the GAP partial is (row 0) + (row 1) of a 2-row strip
+  // Epilogue operands (ReLU mask / residual / DOT map) of BOTH output rows are requested before the first store: y, mask,
+  // res and dot are distinct buffers, but the compiler cannot know that, and with loads and stores interleaved it emitted
+  // load -> s_waitcnt vmcnt(0) -> store per element (a full memory round trip each).  One round trip per tile remains.
+  float mk[MT][16], rs[MT][16], dt[MT][16];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int row = h0 + MT * ph + m;
+    const long row_base = tile_base + (long)min(row, H - 1) * p.yv.sH;  // scalar
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cr = (r & 3) + 8 * (r >> 2);
+      // partial tiles: unconditional loads from a clamped (in-image) address instead of a branch + wait per element
+      const long off = full ? row_base + (long)cr * p.yv.sW
+                            : row_base + (long)(min(w0 + cr + 4 * hh, W - 1) - (w0 + 4 * hh)) * p.yv.sW;
+      if (MASK) mk[m][r] = (p.mask + off)[loff_y];
+      if (RES) rs[m][r] = (p.res + off)[loff_y];
+      if (DOT) dt[m][r] = (p.dot + off)[loff_y];
+    }
+  }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     float gsum = 0.f;
     const int row = h0 + MT * ph + m;
     const f32x16 acc = m ? acc1 : acc0;
     const long row_base = tile_base + (long)row * p.yv.sH;  // scalar
-    // Epilogue operands (ReLU mask / residual / DOT map) are fetched for the whole row BEFORE the first store: y, mask,
-    // res and dot are distinct buffers, but the compiler cannot know that, and with loads and stores interleaved it
-    // emitted load -> s_waitcnt vmcnt(0) -> store sixteen times per row (a full memory round trip per element).
-    float mk[16], rs[16], dt[16];
     if (full) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long off = row_base + (long)((r & 3) + 8 * (r >> 2)) * p.yv.sW;  // scalar
-        if (MASK) mk[r] = (p.mask + off)[loff_y];
-        if (RES) rs[r] = (p.res + off)[loff_y];
-        if (DOT) dt[r] = (p.dot + off)[loff_y];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long off = row_base + (long)((r & 3) + 8 * (r >> 2)) * p.yv.sW;  // scalar
         float v = fmaxf(acc[r], lo) * os;
-        if (MASK) v = mk[r] > 0.f ? v : 0.f;
-        if (RES) v += rs[r];
+        if (MASK) v = mk[m][r] > 0.f ? v : 0.f;
+        if (RES) v += rs[m][r];
         (p.y + off)[loff_y] = v;
-        gsum = DOT ? __builtin_fmaf(v, dt[r], gsum) : gsum + v;  // explicit fma: same bits in every build
+        gsum = DOT ? __builtin_fmaf(v, dt[m][r], gsum) : gsum + v;  // explicit fma: same bits in every build
       }
     } else if (row < H) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cr = (r & 3) + 8 * (r >> 2);
-        // unconditional loads from a clamped (in-row) column: a predicated load would be a branch + wait per element
-        const long off = row_base + (long)(min(w0 + cr + 4 * hh, W - 1) - (w0 + 4 * hh)) * p.yv.sW;
-        if (MASK) mk[r] = (p.mask + off)[loff_y];
-        if (RES) rs[r] = (p.res + off)[loff_y];
-        if (DOT) dt[r] = (p.dot + off)[loff_y];
-      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cr = (r & 3) + 8 * (r >> 2);
         if (w0 + cr + 4 * hh < W) {
           const long off = row_base + (long)cr * p.yv.sW;
           float v = fmaxf(acc[r], lo) * os;
-          if (MASK) v = mk[r] > 0.f ? v : 0.f;
-          if (RES) v += rs[r];
+          if (MASK) v = mk[m][r] > 0.f ? v : 0.f;
+          if (RES) v += rs[m][r];
           (p.y + off)[loff_y] = v;
-          gsum = DOT ? __builtin_fmaf(v, dt[r], gsum) : gsum + v;  // explicit fma: same bits in every build
+          gsum = DOT ? __builtin_fmaf(v, dt[m][r], gsum) : gsum + v;  // explicit fma: same bits in every build
         }
       }
     }

@@ -71,12 +71,13 @@ class FlatAdam(optim.Adam):
             self._missed[p] = self._t  # it has missed every step so far
 
     def _segments(self, skipped):
-        key = (frozenset(skipped), tuple(sorted(self._missed.values())) if any(self._missed.values()) else ())
+        skip = frozenset(id(p) for p in skipped)  # identity: `in` on tensors would compare element-wise
+        key = (skip, tuple(self._missed.values()) if any(self._missed.values()) else ())
         if self._plan is not None and self._plan[0] == key:
             return self._plan[1]
         segs = []
         for p in self.param_groups[0]['params']:
-            if p in skipped:
+            if id(p) in skip:
                 continue
             o, n = self.offsets[p], (p.numel() + ALIGN - 1) // ALIGN * ALIGN
             missed = self._missed.get(p, 0)
