@@ -41,15 +41,15 @@ def test_flat_adam_matches_torch_adam_and_keeps_its_state_dict_schema():
         sched_a.step()
         sched_b.step()
     for x, y in zip(pa, pb):
-        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)  # ~ulps of the weights
     sa, sb = fa.state_dict(), ta.state_dict()
     assert sa["param_groups"][0].keys() == sb["param_groups"][0].keys() and sa["state"].keys() == sb["state"].keys()
     for k in sb["state"]:
         assert sa["state"][k].keys() == sb["state"][k].keys()
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]), k
         for key in ("exp_avg", "exp_avg_sq"):
-            np.testing.assert_allclose(sa["state"][k][key].cpu().numpy(), sb["state"][k][key].cpu().numpy(), rtol=2e-6,
-                                       atol=1e-12)
+            want = sb["state"][k][key].cpu().numpy()
+            np.testing.assert_allclose(sa["state"][k][key].cpu().numpy(), want, rtol=2e-6, atol=1e-6 * np.abs(want).max())
     # round trip into a fresh optimiser over a fresh copy of the net, then one more identical step on both
     nc = copy.deepcopy(nb)
     with torch.no_grad():
@@ -63,7 +63,7 @@ def test_flat_adam_matches_torch_adam_and_keeps_its_state_dict_schema():
     fc.step()
     ta.step()
     for z, y in zip(nc.parameters(), pb):
-        np.testing.assert_allclose(z.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(z.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
 
 
 def test_handlers_train_with_flat_adam_and_conv_gradients_land_in_its_arena():
