@@ -240,9 +240,10 @@ int sisr_nl_attn_bwd(const float* theta, const float* phi, const float* g, const
 size_t sisr_l1_loss_workspace_bytes(void);
 int sisr_l1_loss(const float* a, const float* b, long n, float* loss, float* grad, float* workspace, void* stream);
 /* torch.optim.Adam's update over one flat range (parameters, gradients, exp_avg, exp_avg_sq laid out alike):
- * step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) (host, double); gradients are read as g * grad_scale */
-int sisr_adam_flat(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
-                   float step_size, float bc2_sqrt, float grad_scale, void* stream);
+ * one_minus_beta*, step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) computed by the host in double;
+ * gradients are read as g * grad_scale */
+int sisr_adam_flat(float* p, const float* g, float* m, float* v, long n, float beta2, float one_minus_beta1,
+                   float one_minus_beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, void* stream);
 
 /* ---- training tiles cut on the device (the step in front of the path) ---------------
  * ref: sr_tools/image_manipulation.py:233-257 random_flip_rotate + random_matched_crop, in the order

@@ -423,9 +423,10 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
   // Epilogue operands (ReLU mask / residual / DOT map) of BOTH output rows are requested before the first store: y, mask,
   // res and dot are distinct buffers, but the compiler cannot know that, and with loads and stores interleaved it emitted
   // load -> s_waitcnt vmcnt(0) -> store per element (a full memory round trip each).  One round trip per tile remains.
+  // (With two operand sets -- DOT + residual -- the second set is fetched per row: 64 values in flight measured slower.)
+  constexpr bool TWO_SETS = DOT && RES;
   float mk[MT][16], rs[MT][16], dt[MT][16];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
+  auto fetch = [&](int m, bool first_set, bool second_set) {
     const int row = h0 + MT * ph + m;
     const long row_base = tile_base + (long)min(row, H - 1) * p.yv.sH;  // scalar
 #pragma unroll
@@ -434,17 +435,20 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
       // partial tiles: unconditional loads from a clamped (in-image) address instead of a branch + wait per element
       const long off = full ? row_base + (long)cr * p.yv.sW
                             : row_base + (long)(min(w0 + cr + 4 * hh, W - 1) - (w0 + 4 * hh)) * p.yv.sW;
-      if (MASK) mk[m][r] = (p.mask + off)[loff_y];
-      if (RES) rs[m][r] = (p.res + off)[loff_y];
-      if (DOT) dt[m][r] = (p.dot + off)[loff_y];
+      if (MASK && first_set) mk[m][r] = (p.mask + off)[loff_y];
+      if (RES && first_set) rs[m][r] = (p.res + off)[loff_y];
+      if (DOT && (TWO_SETS ? second_set : first_set)) dt[m][r] = (p.dot + off)[loff_y];
     }
-  }
+  };
+#pragma unroll
+  for (int m = 0; m < MT; ++m) fetch(m, true, false);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     float gsum = 0.f;
     const int row = h0 + MT * ph + m;
     const f32x16 acc = m ? acc1 : acc0;
     const long row_base = tile_base + (long)row * p.yv.sH;  // scalar
+    if (TWO_SETS) fetch(m, false, true);
     if (full) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

@@ -62,19 +62,20 @@ extern "C" int sisr_l1_loss(const float* a, const float* b, long n, float* loss,
 // torch.optim.Adam (no amsgrad, no weight decay) over one flat fp32 range, in torch's operation order:
 //   exp_avg.lerp_(g, 1 - b1);  exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2);
 //   denom = exp_avg_sq.sqrt() / sqrt(1 - b2^t) + eps;  p.addcdiv_(exp_avg, denom, value = -lr / (1 - b1^t))
-// step_size = lr / (1 - b1^t) and bc2_sqrt = sqrt(1 - b2^t) are computed on the host in double (as torch does).
+// step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t) and the weights omb1 = 1 - b1, omb2 = 1 - b2 are computed on
+// the host in double and then rounded to fp32, as torch does (1.f - 0.999f is 4.7e-5 off the fp32 value of 0.001).
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long n4, long n,
-                                                        float b1, float b2, float eps, float step_size, float bc2_sqrt,
-                                                        float gscale) {
+                                                        float b2, float omb1, float omb2, float eps, float step_size,
+                                                        float bc2_sqrt, float gscale) {
 #pragma clang fp contract(off)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     f32x4 gg = reinterpret_cast<const f32x4*>(g)[i] * gscale;
     f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
     f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
-    mm = mm + (gg - mm) * (1.f - b1);
-    vv = vv * b2 + gg * gg * (1.f - b2);
+    mm = mm + (gg - mm) * omb1;
+    vv = vv * b2 + gg * gg * omb2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) pp[e] = pp[e] - step_size * (mm[e] / (sqrtf(vv[e]) / bc2_sqrt + eps));
     reinterpret_cast<f32x4*>(m)[i] = mm;
@@ -84,24 +85,25 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
     const long i = (n4 << 2) + threadIdx.x;
     const float gg = g[i] * gscale;
-    const float mm = m[i] + (gg - m[i]) * (1.f - b1);
-    const float vv = v[i] * b2 + gg * gg * (1.f - b2);
+    const float mm = m[i] + (gg - m[i]) * omb1;
+    const float vv = v[i] * b2 + gg * gg * omb2;
     p[i] = p[i] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
     m[i] = mm;
     v[i] = vv;
   }
 }
 
-extern "C" int sisr_adam_flat(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
-                              float step_size, float bc2_sqrt, float grad_scale, void* stream) {
+extern "C" int sisr_adam_flat(float* p, const float* g, float* m, float* v, long n, float beta2, float one_minus_beta1,
+                              float one_minus_beta2, float eps, float step_size, float bc2_sqrt, float grad_scale,
+                              void* stream) {
   if (!p || !g || !m || !v || n <= 0) return SISR_ERR_ARG;
   if (!sisr_aligned16(p) || !sisr_aligned16(g) || !sisr_aligned16(m) || !sisr_aligned16(v)) return SISR_ERR_ALIGN;
   const long n4 = n >> 2;
   long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
-                     beta2, eps, step_size, bc2_sqrt, grad_scale);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta2,
+                     one_minus_beta1, one_minus_beta2, eps, step_size, bc2_sqrt, grad_scale);
   return sisr_check_launch();
 }
 

@@ -46,7 +46,7 @@ _SIGS = {
     "sisr_l1_loss_workspace_bytes": (c_size_t, []),
     "sisr_l1_loss": (c_int, [P, P, c_long, P, P, P, P]),
     "sisr_crop_augment": (c_int, [P, P, P, c_int, c_int, c_int, P]),
-    "sisr_adam_flat": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_float, P]),
+    "sisr_adam_flat": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P]),
 }
 OPTIONAL_SIGS = {  # only in libsisr_hip_diag.so (csrc/build.sh diag; select it with SISR_HIP_LIB)
     "sisr_diag_mfma_peak": (c_int, [c_int, c_int, P, P, P]),

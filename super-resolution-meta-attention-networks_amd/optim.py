@@ -119,8 +119,8 @@ class FlatAdam(optim.Adam):
             t = self._t - missed
             bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
             hip.check(L.sisr_adam_flat(self.flat_p.data_ptr() + 4 * o, self.flat_g.data_ptr() + 4 * o,
-                                       self.flat_m.data_ptr() + 4 * o, self.flat_v.data_ptr() + 4 * o, n, b1, b2, eps,
-                                       lr / bc1, math.sqrt(bc2), 1.0, st), "sisr_adam_flat")
+                                       self.flat_m.data_ptr() + 4 * o, self.flat_v.data_ptr() + 4 * o, n, b2, 1 - b1,
+                                       1 - b2, eps, lr / bc1, math.sqrt(bc2), 1.0, st), "sisr_adam_flat")
 
     # -- torch-compatible (de)serialisation
     def state_dict(self):
