@@ -844,102 +844,92 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, lo
   const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w);
   for (int c = 0; c < p.cin_chunks; ++c) {
     if (c) __syncthreads();
-    {  // ---- halo staging: thread = (8-channel chunk c8, column pcol [+32]); rows in two batches of three
+    {  // ---- halo staging, balanced over the waves (the split costs ~7 VALU per element, and VALU issue is what a
+       // co-resident wave's MFMA stream leaves over): thread (c8, pcol) owns channels 8 c8 .. +7 of INTERIOR column
+       // pcol + 1 in all six rows; the two edge columns (6 rows x 2 x 8 chunks = 96 items) go one per thread to
+       // tid < 96.  Every load is unconditional (clamped address, masked value).
       int tl = tid;
       asm volatile("" : "+v"(tl));
       const int c8 = tl & 7, pcol = tl >> 3;
+      const int eidx = tl % 96, er = eidx >> 4, eside = (eidx >> 3) & 1, ec8 = eidx & 7;
       const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(c);
-      f32x4 s4a = {1.f, 1.f, 1.f, 1.f}, s4b = s4a, t4a = {0.f, 0.f, 0.f, 0.f}, t4b = t4a;
-      if (AFFINE) {
-        const float* sp = p.in_scale + ((long)b * p.cin_chunks + c) * 64 + c8 * 8;
-        s4a = *reinterpret_cast<const f32x4*>(sp);
-        s4b = *reinterpret_cast<const f32x4*>(sp + 4);
-        if (p.in_shift) {
-          const float* tp = p.in_shift + ((long)b * p.cin_chunks + c) * 64 + c8 * 8;
-          t4a = *reinterpret_cast<const f32x4*>(tp);
-          t4b = *reinterpret_cast<const f32x4*>(tp + 4);
+      const long boffs = (long)b * p.xv.sB;
+      f32x4 s4a = {1.f, 1.f, 1.f, 1.f}, s4b = s4a, t4a = {0.f, 0.f, 0.f, 0.f}, t4b = t4a, e4a = s4a, e4b = s4a,
+            f4a = t4a, f4b = t4a;
+      if (AFFINE || GATE) {
+        const float* sp = p.in_scale + ((long)b * p.cin_chunks + c) * 64;
+        s4a = *reinterpret_cast<const f32x4*>(sp + c8 * 8);
+        s4b = *reinterpret_cast<const f32x4*>(sp + c8 * 8 + 4);
+        e4a = *reinterpret_cast<const f32x4*>(sp + ec8 * 8);
+        e4b = *reinterpret_cast<const f32x4*>(sp + ec8 * 8 + 4);
+        if (AFFINE && p.in_shift) {
+          const float* tp = p.in_shift + ((long)b * p.cin_chunks + c) * 64;
+          t4a = *reinterpret_cast<const f32x4*>(tp + c8 * 8);
+          t4b = *reinterpret_cast<const f32x4*>(tp + c8 * 8 + 4);
+          f4a = *reinterpret_cast<const f32x4*>(tp + ec8 * 8);
+          f4b = *reinterpret_cast<const f32x4*>(tp + ec8 * 8 + 4);
         }
       }
-      unsigned goff[2], loff[2];
-      bool cok[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int col = pcol + 32 * k;
-        const int gw = w0 - 1 + col;
-        cok[k] = gw >= 0 && gw < W && col < HALO_W;
-        goff[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c8 * 8);
-        loff[k] = col * BH_PIX + ((c8 ^ ((col >> 1) & 7)) << 4);
+      const int gw = w0 + pcol;  // interior column pcol + 1
+      const bool cok = gw < W;
+      const unsigned goff = (unsigned)(min(gw, W - 1) * (int)p.xv.sW + c8 * 8);
+      const unsigned loff = (pcol + 1) * BH_PIX + ((c8 ^ (((pcol + 1) >> 1) & 7)) << 4);
+      const int ecol = eside ? HALO_W - 1 : 0, gwe = eside ? w0 + TW : w0 - 1, ghe = h0 - 1 + er;
+      const unsigned egoff = (unsigned)(min(max(gwe, 0), W - 1) * (int)p.xv.sW + ec8 * 8);
+      const long erow = (long)min(max(ghe, 0), H - 1) * p.xv.sH;
+      const unsigned eloff = er * (HALO_W * BH_PIX) + ecol * BH_PIX + ((ec8 ^ ((ecol >> 1) & 7)) << 4);
+      const unsigned emask = (ghe >= 0 && ghe < H && gwe >= 0 && gwe < W) ? 0xffffffffu : 0u;
+      // edge item: requested first, converted with the first batch
+      f32x4 ea = *reinterpret_cast<const f32x4*>(xb + erow + egoff), eb = *reinterpret_cast<const f32x4*>(xb + erow + egoff + 4);
+      f32x4 ua = {0.f, 0.f, 0.f, 0.f}, ub = ua;
+      if (GATE) {
+        ua = *reinterpret_cast<const f32x4*>(p.gate_add + boffs + erow + egoff);
+        ub = *reinterpret_cast<const f32x4*>(p.gate_add + boffs + erow + egoff + 4);
       }
-      if (!GATE) {
+      constexpr int RB = GATE ? 2 : 3;  // rows per batch (GATE holds two operand tensors)
 #pragma unroll
-        for (int r0 = 0; r0 < HALO_H; r0 += 3) {
-          f32x4 v[3][2][2];
+      for (int r0 = 0; r0 < HALO_H; r0 += RB) {
+        f32x4 v[RB][2], u[RB][2];
 #pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            const int gh = h0 - 1 + r0 + r;
-            const float* xrow = xb + (long)min(max(gh, 0), H - 1) * p.xv.sH;  // scalar
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-              if (k == 0 || pcol < 2) {
-                v[r][k][0] = *reinterpret_cast<const f32x4*>(xrow + goff[k]);
-                v[r][k][1] = *reinterpret_cast<const f32x4*>(xrow + goff[k] + 4);
-              }
-          }
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            const int gh = h0 - 1 + r0 + r;
-            const bool rok = gh >= 0 && gh < H;  // scalar
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-              if (k == 0 || pcol < 2) {
-                f32x4 ta = v[r][k][0], tb = v[r][k][1];
-                if (AFFINE) {
-                  ta = ta * s4a + t4a;
-                  tb = tb * s4b + t4b;
-                }
-                const unsigned m = (rok && cok[k]) ? 0xffffffffu : 0u;
-                sisr_store_split3(ldsb + (r0 + r) * (HALO_W * BH_PIX) + loff[k], ta, tb, m);
-              }
+        for (int r = 0; r < RB; ++r) {
+          const long ro = (long)min(max(h0 - 1 + r0 + r, 0), H - 1) * p.xv.sH;  // scalar
+          v[r][0] = *reinterpret_cast<const f32x4*>(xb + ro + goff);
+          v[r][1] = *reinterpret_cast<const f32x4*>(xb + ro + goff + 4);
+          if (GATE) {
+            u[r][0] = *reinterpret_cast<const f32x4*>(p.gate_add + boffs + ro + goff);
+            u[r][1] = *reinterpret_cast<const f32x4*>(p.gate_add + boffs + ro + goff + 4);
           }
         }
-      } else {  // GATE: u = t * gate + skip in fp32, written out once by the owning tile, then rounded for the MFMA
-        const float* gp = p.in_scale + (long)b * 64 + c8 * 8;
-        const f32x4 g4a = *reinterpret_cast<const f32x4*>(gp), g4b = *reinterpret_cast<const f32x4*>(gp + 4);
-        const long boffs = (long)b * p.xv.sB;
-#pragma unroll
-        for (int r0 = 0; r0 < HALO_H; r0 += 2) {
-          f32x4 v[2][2][2], u[2][2][2];
-#pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            const long ro = boffs + (long)min(max(h0 - 1 + r0 + r, 0), H - 1) * p.xv.sH;  // scalar
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-              if (k == 0 || pcol < 2) {
-                v[r][k][0] = *reinterpret_cast<const f32x4*>(p.x + ro + goff[k]);
-                v[r][k][1] = *reinterpret_cast<const f32x4*>(p.x + ro + goff[k] + 4);
-                u[r][k][0] = *reinterpret_cast<const f32x4*>(p.gate_add + ro + goff[k]);
-                u[r][k][1] = *reinterpret_cast<const f32x4*>(p.gate_add + ro + goff[k] + 4);
-              }
+        if (r0 == 0) {
+          if (AFFINE) {
+            ea = ea * e4a + f4a;
+            eb = eb * e4b + f4b;
           }
-#pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            const int hr = r0 + r, gh = h0 - 1 + hr;
-            const bool rok = gh >= 0 && gh < H;              // scalar
-            const bool rown = hr >= 1 && hr <= TH && gh < H;  // scalar
-            const long ro = boffs + (long)min(max(gh, 0), H - 1) * p.xv.sH;
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-              if (k == 0 || pcol < 2) {
-                const f32x4 ta = sisr_mul_add4(v[r][k][0], g4a, u[r][k][0]), tb = sisr_mul_add4(v[r][k][1], g4b, u[r][k][1]);
-                const int col = pcol + 32 * k;
-                if (rown && cok[k] && col >= 1 && col <= TW) {
-                  *reinterpret_cast<f32x4*>(p.gate_out + ro + goff[k]) = ta;
-                  *reinterpret_cast<f32x4*>(p.gate_out + ro + goff[k] + 4) = tb;
-                }
-                const unsigned m = (rok && cok[k]) ? 0xffffffffu : 0u;
-                sisr_store_split3(ldsb + hr * (HALO_W * BH_PIX) + loff[k], ta, tb, m);
-              }
+          if (GATE) {
+            ea = sisr_mul_add4(ea, e4a, ua);
+            eb = sisr_mul_add4(eb, e4b, ub);
           }
+          if (tl < 96) sisr_store_split3(ldsb + eloff, ea, eb, emask);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int hr = r0 + r, gh = h0 - 1 + hr;
+          const bool rok = gh >= 0 && gh < H;  // scalar
+          f32x4 ta = v[r][0], tb = v[r][1];
+          if (AFFINE) {
+            ta = ta * s4a + t4a;
+            tb = tb * s4b + t4b;
+          }
+          if (GATE) {  // u = t * gate + skip in fp32, written out once by the owning tile, then split for the MFMA
+            ta = sisr_mul_add4(ta, s4a, u[r][0]);
+            tb = sisr_mul_add4(tb, s4b, u[r][1]);
+            if (hr >= 1 && hr <= TH && gh < H && cok) {  // interior columns are exactly the pixels this tile owns
+              float* o = p.gate_out + boffs + (long)gh * p.xv.sH + goff;
+              *reinterpret_cast<f32x4*>(o) = ta;
+              *reinterpret_cast<f32x4*>(o + 4) = tb;
+            }
+          }
+          sisr_store_split3(ldsb + hr * (HALO_W * BH_PIX) + loff, ta, tb, (rok && cok) ? 0xffffffffu : 0u);
         }
       }
     }
