@@ -61,7 +61,7 @@ def _han_tail(net, x_head, maps):
     out2 = ops.conv3x3_stack(net.la.forward_stack(stack), net.last_conv.weight, net.last_conv.bias)
     out1 = net.csa(maps[-1])
     pair = _stack_maps([out1, out2])                      # torch.cat([out1, out2], 1) as two chunks
-    res = ops.conv3x3_stack(pair, net.last.weight, net.last.bias) + x_head
+    res = ops.conv3x3_stack(pair, net.last.weight, net.last.bias, residual=x_head)  # + x fused into the conv's store
     return A._conv(net.tail[1], net.tail[0](res))
 
 

@@ -1411,7 +1411,7 @@ class _ConvStack(Function):
     last, ref: advanced/architectures.py:349-350,366-371) -- torch.cat is never materialised."""
 
     @staticmethod
-    def forward(ctx, stack, weight, bias):
+    def forward(ctx, stack, weight, bias, residual=None):
         B, N, H, W, C = stack.shape
         if C != 64 or weight.shape[0] != 64 or weight.shape[1] != 64 * N:
             raise NotImplementedError("stack conv expects N maps of 64 channels -> 64 channels")
@@ -1422,9 +1422,10 @@ class _ConvStack(Function):
         else:
             packed, ctx.pd = pack_weight(w, "fwd"), None
         y = _empty_cl(B, 64, H, W, stack.device)
-        conv_c64(stack, hip.view_maps(H, W, N), packed, bias, (1, 64), y, hip.view_plain(H, W, 64), B, H, W, 64 * N, 64)
+        conv_c64(stack, hip.view_maps(H, W, N), packed, bias, (1, 64), y, hip.view_plain(H, W, 64), B, H, W, 64 * N, 64,
+                 res=_cl(residual) if residual is not None else None)
         ctx.save_for_backward(stack, w)
-        ctx.has_bias = bias is not None
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         return y
 
     @staticmethod
@@ -1444,13 +1445,14 @@ class _ConvStack(Function):
             dw = torch.empty_like(w)
             db = torch.empty(64, device=dev, dtype=torch.float32) if ctx.has_bias else None
             wgrad_c64(stack, hip.view_maps(H, W, N), dy, hip.view_plain(H, W, 64), dw, db, B, H, W, 64 * N, 64)
-            return dstack, dw, db
+            return dstack, dw, db, (dy if ctx.has_res else None)
         finally:
             IN_BACKWARD = False
 
 
-def conv3x3_stack(stack, weight, bias):
-    return _ConvStack.apply(stack, weight, bias)
+def conv3x3_stack(stack, weight, bias, residual=None):
+    """conv over the stack's N maps as channel chunks (+ residual, added by the conv's epilogue)."""
+    return _ConvStack.apply(stack, weight, bias, residual)
 
 
 # ----------------------------------------------------------------------------- SAN attention modules
@@ -1605,8 +1607,15 @@ class _ScaleAdd(Function):
         B, C, H, W = r.shape
         dy = _cl(dy)
         dr = _affine(dy, gv, None, None, B, H, W, C)
-        dgp, _ = _pixel_sums(dy, r, B, H, W)
-        return dy, dr, dgp.sum().reshape(ctx.gshape)
+        if C != 64:
+            raise NotImplementedError("scale_add backward is specialised for 64 channels")
+        dgp, parts = _pixel_sums(dy, r, B, H, W)  # [B][parts][64] ordered partial sums of dy * r
+        L = hip.lib()
+        per = _vec(B, C, dy.device)
+        hip.check(L.sisr_sum_partials(hip.ptr(dgp), parts, B, C, 1.0, hip.ptr(per), hip.stream()), "sisr_sum_partials")
+        dgam = torch.empty(1, device=dy.device, dtype=torch.float32)
+        hip.check(L.sisr_sum_partials(hip.ptr(per), B * C, 1, 1, 1.0, hip.ptr(dgam), hip.stream()), "sisr_sum_partials")
+        return dy, dr, dgam.reshape(ctx.gshape)
 
 
 def scale_add(a, r, gamma):
