@@ -61,7 +61,24 @@ int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked,
                      int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,
                      const float* in_scale, const float* in_shift, const float* out_scale, float alpha, int relu,
                      float* gap_partial, const float* gate_add, float* gate_out, const float* dot, int B, int H,
-                     int W, int cin, int cout, int select, void* stream);
+                     int W, int cin, int cout, const void* ca_tail, int select, void* stream);
+/* ca_tail (nullable HOST pointer to a sisr_ca_tail, copied into the launch; 64 -> 64 only): the workgroup that finishes a
+ * sample last turns the partial sums this launch writes into the channel-attention gate (backward = 0: the forward gate
+ * from gap_partial -- sisr_ca_gate_fwd's outputs) or into the gate's backward (backward = 1: from the `dot` partial sums
+ * -- sisr_ca_gate_bwd's outputs; the last sample's finisher sums the parameter gradients over the batch).  Same
+ * arithmetic and summation order as those two entry points.  counter: B + 1 zero-initialised device words, returned to
+ * zero; workspace (backward): B * 80 floats. */
+typedef struct {
+  int backward, hidden;
+  float inv_hw;
+  const float *w1, *b1, *w2, *b2, *mul; /* gate parameters (b1, b2 unused backward), optional second factor [B][64] */
+  const float *s, *hid, *ca;            /* backward: what the forward kept */
+  float *s_out, *hid_out, *ca_out, *g_out;       /* forward outputs */
+  float *shift, *dmul, *dw1, *db1, *dw2, *db2;   /* backward outputs */
+  float* workspace;
+  unsigned* counter;
+} sisr_ca_tail;
+size_t sisr_ca_tail_bytes(void);
 /* select: 0 (= 4) issue-lean kernel, tile height chosen by grid size, general kernel as fallback; 5 / 6 the same with
  * the 4-row / 2-row tile forced (bit-identical results; A/B measurements and tests); 2 general kernel only. */
 /* gate_add / gate_out / dot (all nullable; 64 -> 64, x and y in one layout) fuse the gated-residual chain of

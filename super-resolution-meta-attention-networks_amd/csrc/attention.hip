@@ -10,42 +10,8 @@
 // it.  All reductions run in a fixed order (no atomics), so results are run-to-run reproducible.
 // These are M = batch sized contractions (64x4, 10x32x64): VALU + wave shuffles, not MFMA.
 #include "sisr_common.h"
+#include "ca_gate.h"
 #include <string.h>
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
-
-// Sum `parts` rows of 64 floats with the whole 256-thread block: thread (c4 = t & 15, group = t >> 4) adds rows
-// group, group + 16, ... of its float4 column, up to sixteen 16-byte loads in flight at once (the kernels that call
-// this sit on the serial chain between two convs and are pure latency: 256 rows used to be eight dependent load
-// rounds); the sixteen group sums are then added in group order.  Result valid in threads 0..63 (channel = t).
-// `red` must hold 16 * 64 floats.
-__device__ __forceinline__ float block_sum_parts(const float* __restrict__ pp, int parts, float* red) {
-  const int c4 = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  int k = grp;
-  for (; k + 15 * 16 < parts; k += 16 * 16) {
-    f32x4 t[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const f32x4*>(pp + (long)(k + 16 * u) * 64 + c4 * 4);
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s += t[u];
-  }
-  for (; k < parts; k += 16) s += *reinterpret_cast<const f32x4*>(pp + (long)k * 64 + c4 * 4);
-  *reinterpret_cast<f32x4*>(red + grp * 64 + c4 * 4) = s;
-  __syncthreads();
-  float r = 0.f;
-  if (threadIdx.x < 64) {
-    r = red[threadIdx.x];
-#pragma unroll
-    for (int g = 1; g < 16; ++g) r += red[g * 64 + threadIdx.x];
-  }
-  return r;
-}
 
 // ---------------------------------------------------------------- CA gate forward (C = 64, one block per sample)
 // part: [B][parts][64] partial sums.  Outputs s, ca, g: [B][64]; hid: [B][R].
@@ -56,21 +22,7 @@ __global__ __launch_bounds__(256) void ca_gate_fwd_kernel(const float* __restric
                                                           float* __restrict__ hid_out, float* __restrict__ ca_out,
                                                           float* __restrict__ g_out) {
   __shared__ __attribute__((aligned(16))) float red[16 * 64];
-  const int b = blockIdx.x, c = threadIdx.x & 63;
-  float s = block_sum_parts(part + (long)b * parts * 64, parts, red);
-  if (threadIdx.x >= 64) return;
-  s *= inv_hw;
-  s_out[b * 64 + c] = s;
-  float z = b2[c];
-  for (int j = 0; j < R; ++j) {
-    float h = wave_sum(w1[j * 64 + c] * s) + b1[j];
-    h = fmaxf(h, 0.f);
-    if (c == 0) hid_out[b * R + j] = h;
-    z += w2[c * R + j] * h;
-  }
-  const float ca = sigmoidf(z);
-  ca_out[b * 64 + c] = ca;
-  g_out[b * 64 + c] = mul ? ca * mul[b * 64 + c] : ca;
+  ca_gate_fwd_sample<false>(part, parts, inv_hw, blockIdx.x, w1, b1, w2, b2, R, mul, s_out, hid_out, ca_out, g_out, red);
 }
 
 // ---------------------------------------------------------------- CA gate backward
@@ -91,26 +43,7 @@ __global__ __launch_bounds__(256) void ca_gate_bwd_kernel(const float* __restric
                                                           unsigned* counter, int B) {
   __shared__ __attribute__((aligned(16))) float red[16 * 64];
   __shared__ int is_last;
-  const int b = blockIdx.x, c = threadIdx.x & 63;
-  const float dg = block_sum_parts(dgpart + (long)b * parts * 64, parts, red);
-  if (threadIdx.x < 64) {
-    const float ca = ca_in[b * 64 + c];
-    float dca = dg;
-    if (mul) {
-      dmul[b * 64 + c] = dg * ca;
-      dca = dg * mul[b * 64 + c];
-    }
-    const float dz2 = dca * ca * (1.f - ca);
-    dz2_out[b * 64 + c] = dz2;
-    float ds = 0.f;
-    for (int j = 0; j < R; ++j) {
-      const float dh = wave_sum(w2[c * R + j] * dz2);
-      const float dz1 = hid[b * R + j] > 0.f ? dh : 0.f;
-      if (c == 0) dz1_out[b * R + j] = dz1;
-      ds += w1[j * 64 + c] * dz1;
-    }
-    shift[b * 64 + c] = ds * inv_hw;
-  }
+  ca_gate_bwd_sample<false>(dgpart, parts, inv_hw, blockIdx.x, w1, w2, R, hid, ca_in, mul, shift, dmul, dz2_out, dz1_out, red);
   __threadfence();  // this block's dz2 / dz1 are visible device-wide before it is counted
   __syncthreads();
   if (threadIdx.x == 0) is_last = atomicAdd(counter, 1u) == (unsigned)(B - 1);
@@ -118,27 +51,7 @@ __global__ __launch_bounds__(256) void ca_gate_bwd_kernel(const float* __restric
   if (!is_last) return;
   __threadfence();
   if (threadIdx.x == 0) *counter = 0u;
-  const int n = 64 * R;
-  for (int i = threadIdx.x; i < 2 * n + 64 + R; i += 256) {
-    float acc = 0.f;
-    if (i < n) {  // dw2[c][j] = sum_b dz2[b][c] * hid[b][j]
-      const int cc = i / R, j = i - cc * R;
-      for (int bb = 0; bb < B; ++bb) acc += __builtin_nontemporal_load(dz2_out + bb * 64 + cc) * hid[bb * R + j];
-      dw2[i] = acc;
-    } else if (i < 2 * n) {  // dw1[j][c] = sum_b dz1[b][j] * s[b][c]
-      const int k = i - n, j = k >> 6, cc = k & 63;
-      for (int bb = 0; bb < B; ++bb) acc += __builtin_nontemporal_load(dz1_out + bb * R + j) * s_in[bb * 64 + cc];
-      dw1[k] = acc;
-    } else if (i < 2 * n + 64) {
-      const int cc = i - 2 * n;
-      for (int bb = 0; bb < B; ++bb) acc += __builtin_nontemporal_load(dz2_out + bb * 64 + cc);
-      db2[cc] = acc;
-    } else {
-      const int j = i - 2 * n - 64;
-      for (int bb = 0; bb < B; ++bb) acc += __builtin_nontemporal_load(dz1_out + bb * R + j);
-      db1[j] = acc;
-    }
-  }
+  ca_gate_bwd_params(dz2_out, dz1_out, hid, s_in, R, B, dw1, db1, dw2, db2);
 }
 
 // ---------------------------------------------------------------- meta gate (ParaCALayer) forward / backward

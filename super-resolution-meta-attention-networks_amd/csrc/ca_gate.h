@@ -1,0 +1,159 @@
+// Channel-attention gate arithmetic shared by the stand-alone gate kernels (attention.hip) and by the conv kernels'
+// last-arriving-workgroup tails (conv3x3_mfma.hip): one code path, one summation order, identical bits either way.
+//   forward  (ref: advanced/architectures.py:13-32):  s = mean_hw(t); h = relu(W1 s + b1); ca = sigmoid(W2 h + b2); g = ca [* mul]
+//   backward: see ca_gate_bwd_sample / ca_gate_bwd_params
+#pragma once
+#include "sisr_common.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
+
+// Sum `parts` rows of 64 floats with the whole 256-thread block: thread (c4 = t & 15, group = t >> 4) adds rows
+// group, group + 16, ... of its float4 column, up to sixteen 16-byte loads in flight at once (the kernels that call
+// this sit on the serial chain between two convs and are pure latency: 256 rows used to be eight dependent load
+// rounds); the sixteen group sums are then added in group order.  Result valid in threads 0..63 (channel = t).
+// `red` must hold 16 * 64 floats.
+__device__ __forceinline__ float block_sum_parts(const float* __restrict__ pp, int parts, float* red) {
+  const int c4 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = grp;
+  for (; k + 15 * 16 < parts; k += 16 * 16) {
+    f32x4 t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const f32x4*>(pp + (long)(k + 16 * u) * 64 + c4 * 4);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += t[u];
+  }
+  for (; k < parts; k += 16) s += *reinterpret_cast<const f32x4*>(pp + (long)k * 64 + c4 * 4);
+  *reinterpret_cast<f32x4*>(red + grp * 64 + c4 * 4) = s;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x < 64) {
+    r = red[threadIdx.x];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) r += red[g * 64 + threadIdx.x];
+  }
+  return r;
+}
+
+
+// ---- forward for ONE sample b, executed by a whole 256-thread workgroup.  red: 16 * 64 floats of LDS.
+// part: that sample's [parts][64] partial sums.  NT: read the partials with cache-bypassing loads (they were written by
+// other workgroups of the SAME launch).
+template <bool NT>
+__device__ __forceinline__ float block_sum_parts_t(const float* __restrict__ pp, int parts, float* red) {
+  const int c4 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = grp;
+  for (; k + 15 * 16 < parts; k += 16 * 16) {
+    f32x4 t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const f32x4* q = reinterpret_cast<const f32x4*>(pp + (long)(k + 16 * u) * 64 + c4 * 4);
+      t[u] = NT ? __builtin_nontemporal_load(q) : *q;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += t[u];
+  }
+  for (; k < parts; k += 16) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(pp + (long)k * 64 + c4 * 4);
+    s += NT ? __builtin_nontemporal_load(q) : *q;
+  }
+  *reinterpret_cast<f32x4*>(red + grp * 64 + c4 * 4) = s;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x < 64) {
+    r = red[threadIdx.x];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) r += red[g * 64 + threadIdx.x];
+  }
+  return r;
+}
+
+template <bool NT>
+__device__ __forceinline__ void ca_gate_fwd_sample(const float* __restrict__ part, int parts, float inv_hw, int b,
+                                                   const float* __restrict__ w1, const float* __restrict__ b1,
+                                                   const float* __restrict__ w2, const float* __restrict__ b2, int R,
+                                                   const float* __restrict__ mul, float* __restrict__ s_out,
+                                                   float* __restrict__ hid_out, float* __restrict__ ca_out,
+                                                   float* __restrict__ g_out, float* red) {
+  const int c = threadIdx.x & 63;
+  float s = block_sum_parts_t<NT>(part + (long)b * parts * 64, parts, red);
+  if (threadIdx.x >= 64) return;
+  s *= inv_hw;
+  s_out[b * 64 + c] = s;
+  float z = b2[c];
+  for (int j = 0; j < R; ++j) {
+    float h = wave_sum(w1[j * 64 + c] * s) + b1[j];
+    h = fmaxf(h, 0.f);
+    if (c == 0) hid_out[b * R + j] = h;
+    z += w2[c * R + j] * h;
+  }
+  const float ca = sigmoidf(z);
+  ca_out[b * 64 + c] = ca;
+  g_out[b * 64 + c] = mul ? ca * mul[b * 64 + c] : ca;
+}
+
+// ---- backward, per sample (whole workgroup):  dg = sum of the partials of sum_hw dOut*t;  dca = dg*mul;
+//   dz2 = dca*ca*(1-ca); dh = W2^T dz2; dz1 = dh*[hid>0]; ds = W1^T dz1  ->  shift[b][c] = ds*inv_hw (the GAP backward
+//   broadcast, consumed as the dgrad / wgrad prologue shift), dmul = dg*ca, and dz2 [B][64], dz1 [B][R] into the workspace.
+template <bool NT>
+__device__ __forceinline__ void ca_gate_bwd_sample(const float* __restrict__ dgpart, int parts, float inv_hw, int b,
+                                                   const float* __restrict__ w1, const float* __restrict__ w2, int R,
+                                                   const float* __restrict__ hid, const float* __restrict__ ca_in,
+                                                   const float* __restrict__ mul, float* __restrict__ shift,
+                                                   float* __restrict__ dmul, float* dz2_out, float* dz1_out, float* red) {
+  const int c = threadIdx.x & 63;
+  const float dg = block_sum_parts_t<NT>(dgpart + (long)b * parts * 64, parts, red);
+  if (threadIdx.x < 64) {
+    const float ca = ca_in[b * 64 + c];
+    float dca = dg;
+    if (mul) {
+      dmul[b * 64 + c] = dg * ca;
+      dca = dg * mul[b * 64 + c];
+    }
+    const float dz2 = dca * ca * (1.f - ca);
+    dz2_out[b * 64 + c] = dz2;
+    float ds = 0.f;
+    for (int j = 0; j < R; ++j) {
+      const float dh = wave_sum(w2[c * R + j] * dz2);
+      const float dz1 = hid[b * R + j] > 0.f ? dh : 0.f;
+      if (c == 0) dz1_out[b * R + j] = dz1;
+      ds += w1[j * 64 + c] * dz1;
+    }
+    shift[b * 64 + c] = ds * inv_hw;
+  }
+}
+
+// ---- backward, parameter gradients: sums over the batch in batch order (whole workgroup; run by whichever workgroup
+// finished last -- which one it is does not change the result).  dz2 / dz1 were written by other workgroups.
+__device__ __forceinline__ void ca_gate_bwd_params(const float* dz2_out, const float* dz1_out, const float* __restrict__ hid,
+                                                   const float* __restrict__ s_in, int R, int B, float* __restrict__ dw1,
+                                                   float* __restrict__ db1, float* __restrict__ dw2,
+                                                   float* __restrict__ db2) {
+  const int n = 64 * R;
+  for (int i = threadIdx.x; i < 2 * n + 64 + R; i += 256) {
+    float acc = 0.f;
+    if (i < n) {  // dw2[c][j] = sum_b dz2[b][c] * hid[b][j]
+      const int cc = i / R, j = i - cc * R;
+      for (int bb = 0; bb < B; ++bb) acc += __builtin_nontemporal_load(dz2_out + bb * 64 + cc) * hid[bb * R + j];
+      dw2[i] = acc;
+    } else if (i < 2 * n) {  // dw1[j][c] = sum_b dz1[b][j] * s[b][c]
+      const int k = i - n, j = k >> 6, cc = k & 63;
+      for (int bb = 0; bb < B; ++bb) acc += __builtin_nontemporal_load(dz1_out + bb * R + j) * s_in[bb * 64 + cc];
+      dw1[k] = acc;
+    } else if (i < 2 * n + 64) {
+      const int cc = i - 2 * n;
+      for (int bb = 0; bb < B; ++bb) acc += __builtin_nontemporal_load(dz2_out + bb * 64 + cc);
+      db2[cc] = acc;
+    } else {
+      const int j = i - 2 * n - 64;
+      for (int bb = 0; bb < B; ++bb) acc += __builtin_nontemporal_load(dz1_out + bb * R + j);
+      db1[j] = acc;
+    }
+  }
+}

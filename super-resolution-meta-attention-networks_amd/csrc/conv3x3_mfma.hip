@@ -20,6 +20,7 @@
 // Fused epilogue: +bias, ReLU, scalar and per-(b,co) scale, ReLU-mask, residual add, pixel-shuffle
 // address map, and per-wave partial sums for the global average pool.
 #include "sisr_common.h"
+#include "ca_gate.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -49,6 +50,25 @@ struct ConvParams {
   float alpha;
   int bias_n, bias_q;
   int B, H, W, cin_chunks, cout_chunks, relu, tiles_w, tiles_h;
+  // Channel-attention tails (64 -> 64, fp32 kernels): the workgroup that finishes a sample LAST (device-scope counter,
+  // returned to zero) turns the GAP partial sums this launch wrote into the gate (forward: `gap` of a plain conv), or the
+  // DOT partial sums into the gate's backward (per sample; the last sample's finisher then sums the parameter gradients
+  // over the batch).  Same arithmetic and summation order as ca_gate_fwd / ca_gate_bwd (ca_gate.h): which workgroup
+  // does it does not change a bit.  Saves one launch on the serial chain per block and direction.
+  struct {
+    const float *w1, *b1, *w2, *b2, *mul;
+    float *s, *hid, *ca, *g;
+    unsigned* counter;  // [B]
+    float inv_hw;
+    int R;
+  } fwd_tail;  // active when g != nullptr
+  struct {
+    const float *w1, *w2, *s, *hid, *ca, *mul;
+    float *shift, *dmul, *dz2, *dz1, *dw1, *db1, *dw2, *db2;
+    unsigned* counter;  // [B + 1]: per sample, then one for the batch
+    float inv_hw;
+    int R;
+  } bwd_tail;  // active when shift != nullptr
 };
 
 // General kernel: every prologue / epilogue combination, XOR-swizzled LDS (16-B chunk k of halo pixel p lives
@@ -488,6 +508,38 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
         g[0] = grow[0] + lds[co];
         if ((th & 1) == 0 && th + 1 >= p.tiles_h) g[Cout] = 0.f;  // H % 4 in {1, 2}: the tile's second strip is empty
       }
+    }
+  }
+  if (p.fwd_tail.g || p.bwd_tail.shift) {  // uniform
+    const long parts = (long)p.tiles_w * ((H + 3) / 4) * 2;
+    const unsigned per_sample = gridDim.x / (unsigned)p.B;  // workgroups of one sample (cout_chunks == 1 here)
+    unsigned* cnt = p.fwd_tail.g ? p.fwd_tail.counter : p.bwd_tail.counter;
+    int* flag = reinterpret_cast<int*>(lds);
+    float* red = lds + 64;
+    __threadfence();  // this workgroup's partial sums are visible device-wide before it is counted
+    __syncthreads();  // ... and every wave is done with the halo / strip exchange in LDS
+    if (tid == 0) flag[0] = atomicAdd(cnt + b, 1u) == per_sample - 1;
+    __syncthreads();
+    if (!flag[0]) return;
+    __threadfence();
+    if (tid == 0) cnt[b] = 0u;
+    if (p.fwd_tail.g) {
+      ca_gate_fwd_sample<true>(p.gap, (int)parts, p.fwd_tail.inv_hw, b, p.fwd_tail.w1, p.fwd_tail.b1, p.fwd_tail.w2,
+                               p.fwd_tail.b2, p.fwd_tail.R, p.fwd_tail.mul, p.fwd_tail.s, p.fwd_tail.hid, p.fwd_tail.ca,
+                               p.fwd_tail.g, red);
+    } else {
+      ca_gate_bwd_sample<true>(p.gap, (int)parts, p.bwd_tail.inv_hw, b, p.bwd_tail.w1, p.bwd_tail.w2, p.bwd_tail.R,
+                               p.bwd_tail.hid, p.bwd_tail.ca, p.bwd_tail.mul, p.bwd_tail.shift, p.bwd_tail.dmul,
+                               p.bwd_tail.dz2, p.bwd_tail.dz1, red);
+      __threadfence();  // this sample's dz2 / dz1 before it is counted on the batch counter
+      __syncthreads();
+      if (tid == 0) flag[0] = atomicAdd(cnt + p.B, 1u) == (unsigned)(p.B - 1);
+      __syncthreads();
+      if (!flag[0]) return;
+      __threadfence();
+      if (tid == 0) cnt[p.B] = 0u;
+      ca_gate_bwd_params(p.bwd_tail.dz2, p.bwd_tail.dz1, p.bwd_tail.hid, p.bwd_tail.s, p.bwd_tail.R, p.B, p.bwd_tail.dw1,
+                         p.bwd_tail.db1, p.bwd_tail.dw2, p.bwd_tail.db2);
     }
   }
 }
@@ -1620,6 +1672,19 @@ extern "C" int sisr_pack_conv3x3_many(const void* jobs_device, int n_jobs, int t
 // 4-row tiles otherwise) with the general kernel as fallback (default); 5 / 6 = the same with the 4-row / 2-row
 // tile forced; 2 = general kernel only; 13 / 16 = diagnostic builds of the general kernel (see above).
 #define SMALL_GRID_BLOCKS 200  // 4-row-tile workgroups below which the 2-row kernel is used (measured: 1.6x at 128, a tie or worse from 256 up)
+// Host-side description of a channel-attention tail (include/sisr_hip.h: sisr_ca_tail).
+struct sisr_ca_tail_host {
+  int backward, hidden;
+  float inv_hw;
+  const float *w1, *b1, *w2, *b2, *mul;
+  const float *s, *hid, *ca;
+  float *s_out, *hid_out, *ca_out, *g_out;
+  float *shift, *dmul, *dw1, *db1, *dw2, *db2;
+  float* workspace;
+  unsigned* counter;
+};
+extern "C" size_t sisr_ca_tail_bytes() { return sizeof(sisr_ca_tail_host); }
+
 extern "C" int sisr_conv3x3_c64_gap_parts(int H, int W) { return ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * 2; }
 
 extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked, const float* bias,
@@ -1627,8 +1692,19 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
                                 const float* mask, const float* in_scale, const float* in_shift,
                                 const float* out_scale, float alpha, int relu, float* gap_partial,
                                 const float* gate_add, float* gate_out, const float* dot, int B, int H, int W, int cin,
-                                int cout, int select, void* stream) {
+                                int cout, const void* ca_tail, int select, void* stream) {
   if (!x || !wpacked || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  const sisr_ca_tail_host* tail = static_cast<const sisr_ca_tail_host*>(ca_tail);
+  if (tail) {  // only on the issue-lean 64 -> 64 kernels, from the partial sums this launch writes
+    if (cin != 64 || cout != 64 || !gap_partial || !tail->counter || tail->hidden < 1 || tail->hidden > 16 || select == 2)
+      return SISR_ERR_UNSUPPORTED;
+    if (tail->backward ? (!dot || !tail->w1 || !tail->w2 || !tail->s || !tail->hid || !tail->ca || !tail->shift ||
+                          !tail->dw1 || !tail->db1 || !tail->dw2 || !tail->db2 || !tail->workspace ||
+                          (tail->mul && !tail->dmul))
+                       : (dot || gate_add || mask || res || in_scale || out_scale || !tail->w1 || !tail->b1 || !tail->w2 ||
+                          !tail->b2 || !tail->s_out || !tail->hid_out || !tail->ca_out || !tail->g_out))
+      return SISR_ERR_ARG;
+  }
   // select (per call; the library keeps no state): 0 / 4 = issue-lean kernel, tile height by grid size, general kernel
   // as fallback; 5 / 6 = the same with the 4-row / 2-row tile forced (A/B measurements, bit-identical results);
   // 2 = general kernel only.  Diagnostic builds (-DSISR_DIAG) add 13 / 16.
@@ -1644,6 +1720,7 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   if (!sisr_aligned16(x) || !sisr_aligned16(wpacked) || !sisr_aligned16(in_scale) || !sisr_aligned16(in_shift))
     return SISR_ERR_ALIGN;
   ConvParams p;
+  memset(&p, 0, sizeof(p));
   p.x = x;
   p.xv = view_from(xview);
   p.y = y;
@@ -1669,6 +1746,18 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   p.cin_chunks = cin / 64;
   p.cout_chunks = cout / 64;
   p.relu = relu;
+  if (tail && !tail->backward) {
+    p.fwd_tail.w1 = tail->w1; p.fwd_tail.b1 = tail->b1; p.fwd_tail.w2 = tail->w2; p.fwd_tail.b2 = tail->b2;
+    p.fwd_tail.mul = tail->mul; p.fwd_tail.s = tail->s_out; p.fwd_tail.hid = tail->hid_out; p.fwd_tail.ca = tail->ca_out;
+    p.fwd_tail.g = tail->g_out; p.fwd_tail.counter = tail->counter; p.fwd_tail.inv_hw = tail->inv_hw;
+    p.fwd_tail.R = tail->hidden;
+  } else if (tail) {
+    p.bwd_tail.w1 = tail->w1; p.bwd_tail.w2 = tail->w2; p.bwd_tail.s = tail->s; p.bwd_tail.hid = tail->hid;
+    p.bwd_tail.ca = tail->ca; p.bwd_tail.mul = tail->mul; p.bwd_tail.shift = tail->shift; p.bwd_tail.dmul = tail->dmul;
+    p.bwd_tail.dz2 = tail->workspace; p.bwd_tail.dz1 = tail->workspace + (size_t)B * 64;
+    p.bwd_tail.dw1 = tail->dw1; p.bwd_tail.db1 = tail->db1; p.bwd_tail.dw2 = tail->dw2; p.bwd_tail.db2 = tail->db2;
+    p.bwd_tail.counter = tail->counter; p.bwd_tail.inv_hw = tail->inv_hw; p.bwd_tail.R = tail->hidden;
+  }
   p.tiles_w = (W + TW - 1) / TW;
   p.tiles_h = (H + TH - 1) / TH;
   const long nblk = (long)p.tiles_w * p.tiles_h * B;
@@ -1735,10 +1824,12 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
         hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, 2>), grid, dim3(256), lb, st, p);
       return sisr_check_launch();
     }
+    if (tail) return SISR_ERR_UNSUPPORTED;  // the general kernel has no tail
     const size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
     hipLaunchKernelGGL(conv3x3_c64_kernel<0>, grid, dim3(256), lb, st, p);
     return sisr_check_launch();
   }
+  if (tail) return SISR_ERR_UNSUPPORTED;
   const size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
 #ifdef SISR_DIAG
   if (variant == 13)
@@ -1784,6 +1875,7 @@ extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const
   if (!sisr_aligned16(x) || !sisr_aligned16(wpacked_bf16) || !sisr_aligned16(in_scale) || !sisr_aligned16(in_shift))
     return SISR_ERR_ALIGN;
   ConvParams p;
+  memset(&p, 0, sizeof(p));
   p.x = x;
   p.xv = view_from(xview);
   p.y = y;
@@ -1893,6 +1985,7 @@ extern "C" int sisr_conv3x3_c64_x3(const float* x, const int64_t* xview, const v
   if (!sisr_aligned16(x) || !sisr_aligned16(wpacked_bf16) || !sisr_aligned16(in_scale) || !sisr_aligned16(in_shift))
     return SISR_ERR_ALIGN;
   ConvParams p;
+  memset(&p, 0, sizeof(p));
   p.x = x;
   p.xv = view_from(xview);
   p.y = y;

@@ -21,7 +21,8 @@ _SIGS = {
     "sisr_pack_conv3x3_both": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "sisr_conv3x3_c64_gap_parts": (c_int, [c_int, c_int]),
     "sisr_conv3x3_c64": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int, c_int,
-                                 c_int, c_int, c_int, c_int, P]),
+                                 c_int, c_int, c_int, P, c_int, P]),
+    "sisr_ca_tail_bytes": (c_size_t, []),
     "sisr_wgrad3x3_c64_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "sisr_wgrad3x3_c64": (c_int, [P, P, P, P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
                                   c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
@@ -117,6 +118,28 @@ class GateMlpDesc(ctypes.Structure):
     _fields_ = [("w", c_void_p * GM_MAXL), ("b", c_void_p * GM_MAXL), ("nin", c_int * GM_MAXL), ("nout", c_int * GM_MAXL),
                 ("cat", c_int * GM_MAXL), ("relu_in", c_int * GM_MAXL), ("act", c_int * GM_MAXL), ("L", c_int),
                 ("M", c_int), ("C", c_int), ("final_mode", c_int)]
+
+
+class CaTail(ctypes.Structure):
+    """Host mirror of sisr_ca_tail (include/sisr_hip.h): the channel-attention gate computed by the last-arriving
+    workgroup of the conv launch that writes its partial sums."""
+    _fields_ = [("backward", c_int), ("hidden", c_int), ("inv_hw", c_float)] + \
+               [(n, c_void_p) for n in ("w1", "b1", "w2", "b2", "mul", "s", "hid", "ca", "s_out", "hid_out", "ca_out", "g_out",
+                                        "shift", "dmul", "dw1", "db1", "dw2", "db2", "workspace", "counter")]
+
+
+_tail_counters = {}
+
+
+def tail_counter(device, B):
+    """Zero-initialised device words the tails count workgroups on (B per-sample words + one for the batch; every launch
+    returns them to zero; one set per device and batch size: tails only run on the stream that drives the pass)."""
+    key = (device.index, B)
+    c = _tail_counters.get(key)
+    if c is None:
+        c = torch.zeros(B + 1, device=device, dtype=torch.int32)
+        _tail_counters[key] = c
+    return c.data_ptr()
 
 
 class HipLibraryMissing(ImportError):

@@ -132,6 +132,11 @@ def _vec(B, C, device):
 # Process-wide; packed weights are rebuilt every step, so switching between steps is safe.
 PRECISION = os.environ.get("SISR_PRECISION", "fp32")
 X3_WGRAD = os.environ.get("SISR_X3_WGRAD", "1") != "0"  # bf16x3 mode: weight gradients split too (0: exact fp32 kernel)
+# Channel-attention gate (and its backward) computed by the last-arriving workgroup of the conv launch that produces its
+# partial sums, instead of by a launch of its own on the serial chain: "auto" = launches of at most CA_TAIL_MAX_BLOCKS
+# workgroups (small per-GPU batches, where a 6-14 us launch is a tenth of a conv), "1" always, "0" never.
+CA_TAIL = os.environ.get("SISR_CA_TAIL", "auto")
+CA_TAIL_MAX_BLOCKS = 1024
 FUSED_GROUPS = os.environ.get("SISR_FUSED_GROUPS", "1") != "0"  # group-level autograd node for CA block stacks
 
 
@@ -262,12 +267,21 @@ def pack_pair(w, shuffle=1):
 
 def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=None, mask=None, in_scale=None,
              in_shift=None, out_scale=None, alpha=1.0, relu=False, gap=None, gate_add=None, gate_out=None, dot=None,
-             select=0):
+             select=0, ca_tail=None):
     L = hip.lib()
     # the packing decides: a weight packed under one mode runs under it (three bf16 planes = the bf16x3 split)
     if packed.dtype != torch.bfloat16:
-        fn, name = L.sisr_conv3x3_c64, "sisr_conv3x3_c64"
-    elif packed.numel() == 3 * cin * cout * 9:
+        import ctypes
+        rc = L.sisr_conv3x3_c64(hip.ptr(x), xview, _wptr(packed), hip.ptr(bias), bias_nq[0], bias_nq[1], hip.ptr(y), yview,
+                                hip.ptr(res), hip.ptr(mask), hip.ptr(in_scale), hip.ptr(in_shift), hip.ptr(out_scale),
+                                float(alpha), int(relu), hip.ptr(gap), hip.ptr(gate_add), hip.ptr(gate_out), hip.ptr(dot), B,
+                                H, W, cin, cout, ctypes.addressof(ca_tail) if ca_tail is not None else None, int(select),
+                                hip.stream())
+        hip.check(rc, "sisr_conv3x3_c64")
+        return
+    if ca_tail is not None:
+        raise RuntimeError("channel-attention tails exist on the fp32 conv kernels only")
+    if packed.numel() == 3 * cin * cout * 9:
         fn, name = L.sisr_conv3x3_c64_x3, "sisr_conv3x3_c64_x3"
     else:
         fn, name = L.sisr_conv3x3_c64_bf16, "sisr_conv3x3_c64_bf16"
@@ -296,6 +310,32 @@ def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_sc
 
 def gap_parts(H, W):
     return hip.lib().sisr_conv3x3_c64_gap_parts(H, W)
+
+
+def _use_ca_tail(B, H, W):
+    if PRECISION != "fp32" or CA_TAIL == "0":
+        return False
+    return CA_TAIL == "1" or B * ((H + 3) // 4) * ((W + 31) // 32) <= CA_TAIL_MAX_BLOCKS
+
+
+def _tail_fwd(B, H, W, R, caw1c, cab1, caw2c, cab2, mm, sv, hid, ca, g, dev):
+    t = hip.CaTail()
+    t.backward, t.hidden, t.inv_hw = 0, R, 1.0 / (H * W)
+    t.w1, t.b1, t.w2, t.b2, t.mul = hip.ptr(caw1c), hip.ptr_c(cab1), hip.ptr(caw2c), hip.ptr_c(cab2), hip.ptr(mm)
+    t.s_out, t.hid_out, t.ca_out, t.g_out = hip.ptr(sv), hip.ptr(hid), hip.ptr(ca), hip.ptr(g)
+    t.counter = hip.tail_counter(dev, B)
+    return t
+
+
+def _tail_bwd(B, H, W, R, caw1c, caw2c, s, hid, ca, mm, shift, dmv, dcaw1, dcab1, dcaw2, dcab2, dev):
+    t = hip.CaTail()
+    t.backward, t.hidden, t.inv_hw = 1, R, 1.0 / (H * W)
+    t.w1, t.w2, t.mul = hip.ptr(caw1c), hip.ptr(caw2c), hip.ptr(mm)
+    t.s, t.hid, t.ca = hip.ptr(s), hip.ptr(hid), hip.ptr(ca)
+    t.shift, t.dmul = hip.ptr(shift), hip.ptr(dmv)
+    t.dw1, t.db1, t.dw2, t.db2 = hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2)
+    t.workspace, t.counter = hip.ptr(_gate_ws(B, dev)), hip.tail_counter(dev, B)
+    return t
 
 
 # ----------------------------------------------------------------------------- conv3x3
@@ -792,6 +832,7 @@ class _GatedGroup(Function):
         v = hip.view_plain(H, W, 64)
         need = any(ctx.needs_input_grad)
         parts = gap_parts(H, W)
+        tails = _use_ca_tail(B, H, W)
         PER = _GatedGroup.PER
         cur, pend = x, None
         tensors, packs, meta = [], [], []
@@ -814,14 +855,18 @@ class _GatedGroup(Function):
                 cur = u
             t2 = _empty_cl(B, 64, H, W, dev)
             gap = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
-            conv_c64(t1, v, p2, b2, (1, 64), t2, v, B, H, W, 64, 64, gap=gap)
             R = caw1.shape[0]
             caw1c, caw2c = caw1.reshape(R, 64).contiguous(), caw2.reshape(64, R).contiguous()
             sv, hid, ca, g = _vec(B, 64, dev), _vec(B, R, dev), _vec(B, 64, dev), _vec(B, 64, dev)
             mm = m.contiguous() if m is not None else None
-            hip.check(L.sisr_ca_gate_fwd(hip.ptr(gap), parts, B, 1.0 / (H * W), hip.ptr(caw1c), hip.ptr_c(cab1),
-                                         hip.ptr(caw2c), hip.ptr_c(cab2), 64, R, hip.ptr(mm), hip.ptr(sv),
-                                         hip.ptr(hid), hip.ptr(ca), hip.ptr(g), hip.stream()), "sisr_ca_gate_fwd")
+            if tails:  # the gate is computed by conv2's last-arriving workgroup per sample
+                conv_c64(t1, v, p2, b2, (1, 64), t2, v, B, H, W, 64, 64, gap=gap,
+                         ca_tail=_tail_fwd(B, H, W, R, caw1c, cab1, caw2c, cab2, mm, sv, hid, ca, g, dev))
+            else:
+                conv_c64(t1, v, p2, b2, (1, 64), t2, v, B, H, W, 64, 64, gap=gap)
+                hip.check(L.sisr_ca_gate_fwd(hip.ptr(gap), parts, B, 1.0 / (H * W), hip.ptr(caw1c), hip.ptr_c(cab1),
+                                             hip.ptr(caw2c), hip.ptr_c(cab2), 64, R, hip.ptr(mm), hip.ptr(sv),
+                                             hip.ptr(hid), hip.ptr(ca), hip.ptr(g), hip.stream()), "sisr_ca_gate_fwd")
             pend = (t2, g)
             blk = [cur, w1, w2, t1, t2, caw1c, caw2c, sv, hid, ca, g] + ([mm] if mm is not None else [])
             meta.append((len(blk), mm is not None, tuple(caw1.shape), tuple(caw2.shape)))
@@ -866,9 +911,29 @@ class _GatedGroup(Function):
             # tail conv: weight gradient from (u_n, dout); dU_n = convT(dout), with sum(dU_n * t2_n) on the side
             dwt, dbt = _grad_buf(wt), torch.empty(64, device=dev)
             run(lambda: wgrad_c64(un, v, dout, v, dwt, dbt, B, H, W, 64, 64), (un, dout, dwt, dbt))
+            tails = _use_ca_tail(B, H, W)
+
+            def gate_bwd_out(k):
+                """Outputs of block k's gate backward (allocated before the conv launch whose tail fills them)."""
+                tens, has_m, s_caw1, s_caw2 = blocks[k]
+                R = tens[5].shape[0]
+                return dict(shift=_vec(B, 64, dev), dmv=_vec(B, 64, dev) if has_m else None,
+                            dcaw1=torch.empty(s_caw1, device=dev), dcab1=torch.empty(R, device=dev),
+                            dcaw2=torch.empty(s_caw2, device=dev), dcab2=torch.empty(64, device=dev))
+
+            def tail_for(k, o):
+                if not tails:
+                    return None
+                tens, has_m = blocks[k][0], blocks[k][1]
+                caw1c, caw2c, s, hid, ca = tens[5:10]
+                return _tail_bwd(B, H, W, caw1c.shape[0], caw1c, caw2c, s, hid, ca, tens[11] if has_m else None, o["shift"],
+                                 o["dmv"], o["dcaw1"], o["dcab1"], o["dcaw2"], o["dcab2"], dev)
+
             dy = _empty_cl(B, 64, H, W, dev)
             dgp = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
-            conv_c64(dout, v, ctx.pdt, None, (1, 64), dy, v, B, H, W, 64, 64, gap=dgp, dot=blocks[-1][0][4])
+            go = gate_bwd_out(n - 1)
+            conv_c64(dout, v, ctx.pdt, None, (1, 64), dy, v, B, H, W, 64, 64, gap=dgp, dot=blocks[-1][0][4],
+                     ca_tail=tail_for(n - 1, go))
             grads = [None] * (n * _GatedGroup.PER)
             for k in range(n - 1, -1, -1):
                 tens, has_m, s_caw1, s_caw2 = blocks[k]
@@ -876,15 +941,13 @@ class _GatedGroup(Function):
                 mm = tens[11] if has_m else None
                 pd1, pd2 = ctx.packs[k]
                 R = caw1c.shape[0]
-                shift = _vec(B, 64, dev)
-                dmv = _vec(B, 64, dev) if has_m else None
-                dcaw1, dcab1 = torch.empty(s_caw1, device=dev), torch.empty(R, device=dev)
-                dcaw2, dcab2 = torch.empty(s_caw2, device=dev), torch.empty(64, device=dev)
-                hip.check(L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
-                                             hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
-                                             hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
-                                             hip.ptr(_gate_ws(B, dev)), hip.gate_counter(dev), hip.stream()),
-                          "sisr_ca_gate_bwd")
+                shift, dmv, dcaw1, dcab1, dcaw2, dcab2 = (go[key] for key in ("shift", "dmv", "dcaw1", "dcab1", "dcaw2", "dcab2"))
+                if not tails:
+                    hip.check(L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
+                                                 hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
+                                                 hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
+                                                 hip.ptr(_gate_ws(B, dev)), hip.gate_counter(dev), hip.stream()),
+                              "sisr_ca_gate_bwd")
                 dw2, db2 = _grad_buf(w2), torch.empty(64, device=dev)
                 dw1, db1 = _grad_buf(w1), torch.empty(64, device=dev)
                 run(lambda t1=t1, dy=dy, dw2=dw2, db2=db2, g=g, shift=shift:
@@ -897,7 +960,9 @@ class _GatedGroup(Function):
                 dprev = _empty_cl(B, 64, H, W, dev)
                 if k > 0:
                     dgp = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
-                    conv_c64(dt1, v, pd1, None, (1, 64), dprev, v, B, H, W, 64, 64, res=dy, gap=dgp, dot=blocks[k - 1][0][4])
+                    go = gate_bwd_out(k - 1)
+                    conv_c64(dt1, v, pd1, None, (1, 64), dprev, v, B, H, W, 64, 64, res=dy, gap=dgp, dot=blocks[k - 1][0][4],
+                             ca_tail=tail_for(k - 1, go))
                 else:
                     conv_c64(dt1, v, pd1, None, (1, 64), dprev, v, B, H, W, 64, 64, res=dy)
                 dy = dprev

@@ -154,6 +154,39 @@ def test_fused_group_node_matches_per_block_nodes(meta):
         assert float((a - b).norm()) <= 2e-5 * float(b.norm()) + 1e-7, (k, float((a - b).norm()), float(b.norm()))
 
 
+@pytest.mark.parametrize("meta", [False, True])
+def test_channel_attention_tails_are_bit_identical_to_the_gate_launches(meta):
+    """The gate (and its backward) computed by the last-arriving workgroup of the conv launch that writes its partial sums
+    (ops.CA_TAIL) against the stand-alone gate launches: same code path (ca_gate.h), same summation order -> every output
+    and every gradient equal to the bit, on a batch whose samples finish in any order (B = 3, odd sizes)."""
+    torch.manual_seed(8)
+    if meta:
+        net = A.QRCAN(n_resblocks=3, n_resgroups=2, n_feats=64, scale=2, style="standard", num_metadata=10,
+                      include_q_layer=True).to(DEV)
+    else:
+        net = A.RCAN(n_resblocks=3, n_resgroups=2, n_feats=64, scale=2).to(DEV)
+    x = rnd(3, 3, 37, 70, seed=80, scale=0.5).to(DEV)
+    md = rnd(3, 10, 1, 1, seed=81, scale=0.3).to(DEV)
+    cot, res, prev = None, {}, ops.CA_TAIL
+    try:
+        for mode in ("1", "0", "1"):  # twice with tails: the counters must come back to zero
+            ops.CA_TAIL = mode
+            net.zero_grad(set_to_none=True)
+            out = net(x, md) if meta else net(x)
+            if cot is None:
+                cot = rnd(*out.shape, seed=82).to(DEV)
+            out.backward(cot)
+            cur = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+            if mode in res:
+                assert torch.equal(res[mode][0], cur[0]) and all(torch.equal(res[mode][1][k], cur[1][k]) for k in cur[1])
+            res[mode] = cur
+    finally:
+        ops.CA_TAIL = prev
+    assert torch.equal(res["1"][0], res["0"][0])
+    for k in res["1"][1]:
+        assert torch.equal(res["1"][1][k], res["0"][1][k]), k
+
+
 def test_conv_residual_alpha_and_multichunk():
     # 128 -> 192 channels, y = conv*alpha + res  (multi-chunk K loop and multiple output chunks)
     B, H, W = 1, 9, 35
