@@ -647,3 +647,36 @@ class Trainer:
     @property
     def lr(self):
         return self.opt.param_groups[0]["lr"]
+
+
+# ----------------------------------------------------------------------------- SFTMD (second half)
+def _sft_standard(sd, key, feat, para):
+    """StandardSft.  ref: SFTMD_variants/architectures.py:25-56 (mask_para False, repeats None)."""
+    cat = torch.cat((feat, para), dim=1)
+    mul = torch.sigmoid(conv(sd, key + ".mul_conv2", F.leaky_relu(conv(sd, key + ".mul_conv1", cat), 0.2)))
+    add = conv(sd, key + ".add_conv2", F.leaky_relu(conv(sd, key + ".add_conv1", cat), 0.2))
+    return feat * mul + add
+
+
+def sftmd(sd, x, para_maps, num_blocks=16, scale=4):
+    """ref: SFTMD_variants/architectures.py:110-176 (SFT_type 'standard', no q-injection); para_maps (B, M, H, W)."""
+    lr = lambda t: F.leaky_relu(t, 0.2)  # noqa: E731
+    bef = conv(sd, "conv3", lr(conv(sd, "conv2", lr(conv(sd, "conv1", x)))))
+    fea = bef
+    for i in range(num_blocks):
+        k = f"SFT-residual{i + 1}"
+        f1 = F.relu(_sft_standard(sd, k + ".sft1.sft_module", fea, para_maps))
+        f2 = F.relu(_sft_standard(sd, k + ".sft2.sft_module", conv(sd, k + ".conv1", f1), para_maps))
+        fea = fea + conv(sd, k + ".conv2", f2)
+    fin = _sft_standard(sd, "sft.sft_module", fea + bef, para_maps)
+    up = conv(sd, "conv_mid", fin)
+    if scale == 4:
+        up = lr(F.pixel_shuffle(conv(sd, "upscale.0", up), 2))
+        up = lr(F.pixel_shuffle(conv(sd, "upscale.3", up), 2))
+    else:
+        up = lr(F.pixel_shuffle(conv(sd, "upscale.0", up), scale))
+    return torch.clamp(conv(sd, "conv_output", up), min=0.0, max=1.0)
+
+
+NETS["sftmd"] = sftmd
+META_NETS = META_NETS + ("sftmd",)

@@ -50,6 +50,7 @@ struct ConvParams {
   float alpha;
   int bias_n, bias_q;
   int B, H, W, cin_chunks, cout_chunks, relu, tiles_w, tiles_h;
+  int mask_leaky;  // relu: 0 none, 1 ReLU, 2 LeakyReLU(0.2); mask_leaky: the mask is LeakyReLU's derivative, not ReLU's
   // Channel-attention tails (64 -> 64, fp32 kernels): the workgroup that finishes a sample LAST (device-scope counter,
   // returned to zero) turns the GAP partial sums this launch wrote into the gate (forward: `gap` of a plain conv), or the
   // DOT partial sums into the gate's backward (per sample; the last sample's finisher then sums the parameter gradients
@@ -221,10 +222,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
       const int col = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
       if (row < H && col < W) {
         float v = acc[r] + bv;
-        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.relu == 1) v = fmaxf(v, 0.f);
+        if (p.relu == 2) v = v > 0.f ? v : 0.2f * v;
         v *= os;
         const long off = ybase + (long)row * p.yv.sH + (long)col * p.yv.sW;
-        if (p.mask) v = p.mask[off] > 0.f ? v : 0.f;
+        if (p.mask) v = p.mask[off] > 0.f ? v : (p.mask_leaky ? 0.2f * v : 0.f);
         if (p.res) v += p.res[off];
         p.y[off] = v;
         gsum += v;
@@ -278,7 +280,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
 // more than by a plain conv, hidden under the MFMA-bound K loop.  DOT (backward of the same chain): the GAP
 // partial slot receives sum(v * dot) -- the gate gradient sum(dY * t) of the block that produced this conv's
 // input -- saving that block's separate reduction pass over two maps.
-template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false>
+// LEAKY (SFTMD, csrc/sft.hip): without MASK the activation is LeakyReLU(0.2) (p.relu == 2); with MASK the mask is that
+// activation's derivative (slope 0.2 where the masking map is <= 0) instead of ReLU's.
+template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false, bool LEAKY = false>
 __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(ConvParams p) {
   constexpr int THv = 2 * MT, HHv = THv + 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -473,8 +477,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long off = row_base + (long)((r & 3) + 8 * (r >> 2)) * p.yv.sW;  // scalar
-        float v = fmaxf(acc[r], lo) * os;
-        if (MASK) v = mk[m][r] > 0.f ? v : 0.f;
+        float v = (LEAKY && !MASK ? (acc[r] > 0.f ? acc[r] : 0.2f * acc[r]) : fmaxf(acc[r], lo)) * os;
+        if (MASK) v = mk[m][r] > 0.f ? v : (LEAKY ? 0.2f * v : 0.f);
         if (RES) v += rs[m][r];
         (p.y + off)[loff_y] = v;
         gsum = DOT ? __builtin_fmaf(v, dt[m][r], gsum) : gsum + v;  // explicit fma: same bits in every build
@@ -485,8 +489,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
         const int cr = (r & 3) + 8 * (r >> 2);
         if (w0 + cr + 4 * hh < W) {
           const long off = row_base + (long)cr * p.yv.sW;
-          float v = fmaxf(acc[r], lo) * os;
-          if (MASK) v = mk[m][r] > 0.f ? v : 0.f;
+          float v = (LEAKY && !MASK ? (acc[r] > 0.f ? acc[r] : 0.2f * acc[r]) : fmaxf(acc[r], lo)) * os;
+          if (MASK) v = mk[m][r] > 0.f ? v : (LEAKY ? 0.2f * v : 0.f);
           if (RES) v += rs[m][r];
           (p.y + off)[loff_y] = v;
           gsum = DOT ? __builtin_fmaf(v, dt[m][r], gsum) : gsum + v;  // explicit fma: same bits in every build
@@ -1745,7 +1749,14 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   p.W = W;
   p.cin_chunks = cin / 64;
   p.cout_chunks = cout / 64;
-  p.relu = relu;
+  // relu: 0 none, 1 ReLU, 2 LeakyReLU(0.2); + 4: `mask` carries LeakyReLU's derivative (slope 0.2 where the map is <= 0)
+  if (relu < 0 || relu > 6 || (relu & 3) == 3 || ((relu & 4) && !mask)) return SISR_ERR_ARG;
+  p.relu = relu & 3;
+  p.mask_leaky = (relu & 4) != 0;
+  const bool leaky = p.relu == 2 || p.mask_leaky;
+  if (leaky && (tail || gate_add || gate_out || dot || in_scale || in_shift || (p.relu == 2 && (mask || res)) ||
+                (p.mask_leaky && res)))
+    return SISR_ERR_UNSUPPORTED;
   if (tail && !tail->backward) {
     p.fwd_tail.w1 = tail->w1; p.fwd_tail.b1 = tail->b1; p.fwd_tail.w2 = tail->w2; p.fwd_tail.b2 = tail->b2;
     p.fwd_tail.mul = tail->mul; p.fwd_tail.s = tail->s_out; p.fwd_tail.hid = tail->hid_out; p.fwd_tail.ca = tail->ca_out;
@@ -1803,7 +1814,11 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
         p.tiles_h = (H + 1) / 2;
         const dim3 grid2((unsigned)((long)p.tiles_w * p.tiles_h * B), p.cout_chunks);
         const size_t lb2 = 4 * HALO_W * 64 * sizeof(float);
-        if (aff)
+        if (leaky && msk)
+          hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, true, false, 1, false, false, true>), grid2, dim3(256), lb2, st, p);
+        else if (leaky)
+          hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, 1, false, false, true>), grid2, dim3(256), lb2, st, p);
+        else if (aff)
           hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 1>), grid2, dim3(256), lb2, st, p);
         else if (msk)
           hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, true, false, 1>), grid2, dim3(256), lb2, st, p);
@@ -1814,7 +1829,11 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
         return sisr_check_launch();
       }
       const size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
-      if (aff)
+      if (leaky && msk)
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, true, false, 2, false, false, true>), grid, dim3(256), lb, st, p);
+      else if (leaky)
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, 2, false, false, true>), grid, dim3(256), lb, st, p);
+      else if (aff)
         hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 2>), grid, dim3(256), lb, st, p);
       else if (msk)
         hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, true, false, 2>), grid, dim3(256), lb, st, p);
@@ -1900,6 +1919,7 @@ extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const
   p.W = W;
   p.cin_chunks = cin / 64;
   p.cout_chunks = cout / 64;
+  if (relu != 0 && relu != 1) return SISR_ERR_UNSUPPORTED;  // LeakyReLU codes: fp32 kernels only
   p.relu = relu;
   p.tiles_w = (W + TW - 1) / TW;
   p.tiles_h = (H + TH - 1) / TH;
@@ -2010,6 +2030,7 @@ extern "C" int sisr_conv3x3_c64_x3(const float* x, const int64_t* xview, const v
   p.W = W;
   p.cin_chunks = cin / 64;
   p.cout_chunks = cout / 64;
+  if (relu != 0 && relu != 1) return SISR_ERR_UNSUPPORTED;  // LeakyReLU codes: fp32 kernels only
   p.relu = relu;
   p.tiles_w = (W + TW - 1) / TW;
   p.tiles_h = (H + TH - 1) / TH;

@@ -474,6 +474,11 @@ try:  # SRMD (srmd.py)
     HANDLERS += [SRMDHandler]
 except ImportError:
     pass
+try:  # SFTMD (sftmd.py)
+    from .sftmd import SFTMDHandler
+    HANDLERS += [SFTMDHandler]
+except ImportError:
+    pass
 # registry key = class name minus 'Handler', lower-cased (ref: models/__init__.py:26-30)
 available_models = {h.__name__.split('Handler')[0].lower(): h for h in HANDLERS}
 

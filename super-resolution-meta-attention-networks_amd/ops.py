@@ -133,9 +133,13 @@ def _vec(B, C, device):
 PRECISION = os.environ.get("SISR_PRECISION", "fp32")
 X3_WGRAD = os.environ.get("SISR_X3_WGRAD", "1") != "0"  # bf16x3 mode: weight gradients split too (0: exact fp32 kernel)
 # Channel-attention gate (and its backward) computed by the last-arriving workgroup of the conv launch that produces its
-# partial sums, instead of by a launch of its own on the serial chain: "auto" = launches of at most CA_TAIL_MAX_BLOCKS
-# workgroups (small per-GPU batches, where a 6-14 us launch is a tenth of a conv), "1" always, "0" never.
-CA_TAIL = os.environ.get("SISR_CA_TAIL", "auto")
+# partial sums, instead of by a launch of its own on the serial chain ("1" always, "auto" = launches of at most
+# CA_TAIL_MAX_BLOCKS workgroups, "0" never).  Bit-identical, but MEASURED SLOWER on MI355X (QRCAN B = 4: 43.7 vs 58.2
+# patches/s; RCAN B = 32: 50.6 vs 75.0): the device-scope release every workgroup needs before it is counted
+# (__threadfence = L2 write-back on a part whose 8 XCDs have private L2s) flushes the conv's freshly written output
+# lines and stalls the wave, which costs far more than the 6-14 us launch it saves.  Default off; kept as the measured
+# negative (profiles/r02_ca_tail.json).
+CA_TAIL = os.environ.get("SISR_CA_TAIL", "0")
 CA_TAIL_MAX_BLOCKS = 1024
 FUSED_GROUPS = os.environ.get("SISR_FUSED_GROUPS", "1") != "0"  # group-level autograd node for CA block stacks
 

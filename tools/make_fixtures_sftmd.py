@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""SFTMD golden vectors, produced by RUNNING THE REFERENCE on CPU (build container only).
+
+    python tools/make_fixtures_sftmd.py
+
+f1  reduced net (2 blocks, seed-8 init -- the weights are NOT stored: the builder's module reproduces them from the seed,
+    which f2's digest pins) on an odd-sized input with random metadata maps: output, and per parameter the gradient's
+    norm and its first 32 values
+f2  full-depth (16 blocks) seed-8 init digest + handler.run_eval on two Set5 images with their blur-kernel metadata
+f3  five handler.run_train steps
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_fixtures as MF  # noqa: E402
+
+from SISR.models import ModelInterface  # noqa: E402
+from SISR.models.SFTMD_variants.architectures import SFTMD  # noqa: E402
+from sr_tools.image_manipulation import ycbcr_convert  # noqa: E402
+from sr_tools.metrics import psnr as ref_psnr  # noqa: E402
+
+OUT, _np, rnd = MF.OUT, MF._np, MF.rnd
+PARAMS = {"metadata": ["blur_kernel"], "num_blocks": 16, "num_features": 64, "in_nc": 3}
+
+
+def make_f1():
+    torch.manual_seed(8)
+    net = SFTMD(in_nc=3, num_features=64, num_blocks=2, scale=4, input_para=10)
+    x = rnd(2, 3, 9, 13, seed=91, scale=0.3, grad=False) + 0.5
+    md = rnd(2, 10, 1, 1, seed=92, scale=0.3, grad=False).expand(2, 10, 9, 13).contiguous()
+    out = net(x, md)
+    cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(93))
+    out.backward(cot)
+    blob = {"in0": _np(x), "in1": _np(md), "out": _np(out), "cot": _np(cot)}
+    blob["sd_sha256"] = np.array(MF.sd_digest(net.state_dict()))
+    for k, p in net.named_parameters():
+        blob["pgn/" + k] = np.array(float(p.grad.double().norm()))
+        blob["pg32/" + k] = _np(p.grad.reshape(-1)[:32])
+    blob["meta"] = np.array(json.dumps({"num_blocks": 2, "scale": 4, "input_para": 10,
+                                        "clamped_fraction": float(((out <= 0) | (out >= 1)).float().mean())}))
+    np.savez_compressed(os.path.join(OUT, "f1_sftmd_reduced.npz"), **blob)
+    print("f1_sftmd_reduced out", tuple(out.shape), "clamped", float(((out <= 0) | (out >= 1)).float().mean()))
+
+
+def make_f2():
+    ims = MF.read_set5()
+    torch.manual_seed(8)
+    model = ModelInterface.define_model("sftmd", device=torch.device("cpu"), model_save_dir="/tmp", eval_mode=True,
+                                        scale=4, **PARAMS)
+    sd = model.net.state_dict()
+    entry = {"sha256": MF.sd_digest(sd), "n_tensors": len(sd),
+             "n_params": int(sum(p.numel() for p in model.net.parameters())), "keys": list(sd), "images": {}}
+    crops = {}
+    for im_name in ("butterfly.png", "woman.png"):
+        lr, hr, blur = ims[im_name]
+        x = torch.from_numpy(lr.transpose(2, 0, 1).copy()).float().div(255)[None]
+        y = torch.from_numpy(hr.transpose(2, 0, 1).copy()).float().div(255)[None]
+        out, loss, _ = model.run_eval(x, y, request_loss=True, metadata=torch.tensor([blur], dtype=torch.float64),
+                                      metadata_keys=[("blur_kernel",)] * 10)
+        o = out.numpy()[0]
+        ycb = ycbcr_convert(np.clip(o, 0, 1), im_type="jpg", input="rgb", y_only=False)
+        yref = ycbcr_convert(y.numpy()[0], im_type="jpg", input="rgb", y_only=False)
+        p = float(ref_psnr(ycb[0], yref[0], max_value=1))
+        entry["images"][im_name] = {"mean": float(o.mean()), "std": float(o.std()), "l1": float(loss), "y_psnr": p}
+        hh, ww = o.shape[1:]
+        crops[im_name] = o[:, hh // 2 - 16:hh // 2 + 16, ww // 2 - 16:ww // 2 + 16].copy()
+        print(f"f2 sftmd {im_name:14s} psnr={p:.4f} l1={float(loss):.6f}")
+    np.savez_compressed(os.path.join(OUT, "f2_sftmd_crops.npz"), **crops)
+    return entry
+
+
+def make_f3():
+    sched = {"scheduler": "cosine_annealing_warm_restarts",
+             "scheduler_params": {"t_mult": 1, "restart_period": 3, "lr_min": 1e-7}}
+    torch.manual_seed(8)
+    model = ModelInterface.define_model("sftmd", device=torch.device("cpu"), model_save_dir="/tmp", eval_mode=False,
+                                        scale=4, lr=1e-4, **sched, **PARAMS)
+    g = torch.Generator().manual_seed(77)
+    steps = []
+    for it in range(5):
+        x = torch.rand(2, 3, 16, 16, generator=g)
+        y = torch.rand(2, 3, 64, 64, generator=g)
+        md = torch.rand(2, 10, generator=g, dtype=torch.float64) * 0.4
+        lr_before = model.get_learning_rate()
+        loss, o = model.run_train(x, y, metadata=md, metadata_keys=[("blur_kernel", "blur_kernel")] * 10)
+        gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.net.parameters())))
+        steps.append({"loss": float(loss), "lr_before": lr_before, "lr_after": model.get_learning_rate(),
+                      "grad_norm": gn, "out_mean": float(o.mean()), "out_std": float(o.std())})
+        print(f"f3 sftmd step {it} loss={float(loss):.6f} gn={gn:.5f}")
+    sdv = model.net.state_dict()
+    return {"steps": steps, "final_param_sum": float(sum(v.double().sum() for v in sdv.values())), **sched}
+
+
+if __name__ == "__main__":
+    make_f1()
+    doc = {"full_depth": make_f2(), "train_steps": make_f3(), "params": PARAMS}
+    with open(os.path.join(OUT, "f_sftmd.json"), "w") as f:
+        json.dump(doc, f, indent=1)
