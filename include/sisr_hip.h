@@ -43,7 +43,9 @@ extern "C" {
  *   bias index    = n*bias_n + q*bias_q   (nullable)
  *   in_scale/shift: [B][cin]  (nullable; applied to in-image pixels only, zero padding stays zero)
  *   out_scale     : [B][cout] (nullable)          res, mask: same view as y (nullable)
- *   gap_partial   : [B][sisr_conv3x3_c64_gap_parts(H,W)][cout] (nullable) */
+ *   gap_partial   : [B][sisr_conv3x3_c64_gap_parts(H,W)][cout] (nullable)
+ *   relu          : 0 none, 1 ReLU, 2 LeakyReLU(0.2); + 4: `mask` is LeakyReLU(0.2)'s derivative (slope 0.2 where the
+ *                   masking map is <= 0) instead of ReLU's.  Codes 2 and 4 exist on the fp32 kernels only (SFTMD). */
 int sisr_pack_conv3x3(const float* w, float* packed, int cout, int cin, int64_t so, int64_t si, int flip_taps,
                       int out_perm_n, int out_perm_q, int in_perm_n, int in_perm_q, void* stream);
 /* forward and input-gradient packings of one weight in one launch (shuffle_r > 1: conv feeds PixelShuffle(r)) */
@@ -318,6 +320,34 @@ int sisr_blur_quant(const float* x, const float* kernel, unsigned char* y_u8, fl
                     void* stream);
 int sisr_pil_resample(const unsigned char* in, void* out, const int* bounds, const int* coef, int ksize, int C, int Hin,
                       int Win, int Hout, int Wout, int vertical, int to_float, void* stream);
+
+/* ---- SFTMD pieces (csrc/sft.hip) ------------------------------------------------------------------------------
+ * ref: SFTMD_variants/architectures.py:25-56 StandardSft (x * sigmoid(mul) + add), :110-176 SFTMD (LeakyReLU(0.2),
+ * 9x9 64 -> 3 output conv, clamp).  The network's 3x3 convs run on sisr_conv3x3_c64 with `relu` = 2 (LeakyReLU(0.2)
+ * epilogue) or `relu` | 4 (the `mask` operand carries LeakyReLU's derivative: slope 0.2 where the map is <= 0).
+ * sisr_compose_oihw2: dst[cop][cip][taps] = zeros with block A (a[coa][cia][taps]) at (oa0, ia0) and block B at
+ *   (ob0, ib0) -- the merged [mul_conv1 | add_conv1] and block-diagonal [mul_conv2, add_conv2] weights of an SFT layer;
+ *   split != 0: the two blocks of dst are copied back into a / b (their gradients).
+ * sisr_sft_combine_fwd: out = [relu](x * sigmoid(y2[:, :64]) + y2[:, 64:]); x / out with pixel strides (floats), y2
+ *   [npix][128]; md (nullable) [npix][64] is copied into out's second 64-channel chunk.  _bwd: dx [npix][64], dy2.
+ * sisr_map64: 64-channel maps with pixel strides: op 0 copy, 1 a + b, 2 LeakyReLU(a), 3 b * LeakyReLU'(a).
+ * sisr_conv9_*: 9x9 conv 64 -> 3 (OIHW weight), x NHWC [B][H][W][64], y NCHW; dgrad optionally masked by LeakyReLU'
+ *   of `leaky_mask` (the activated map that fed the conv); wgrad: ordered two-stage sums (dw OIHW, db).
+ * sisr_clamp01: backward == 0: out = clamp(a, 0, 1); else out = grad * [0 <= a <= 1]. */
+int sisr_compose_oihw2(float* a, float* b, float* dst, int cop, int cip, int taps, int oa0, int ia0, int coa, int cia,
+                       int ob0, int ib0, int cob, int cib, int split, void* stream);
+int sisr_sft_combine_fwd(const float* x, long x_stride, const float* y2, const float* md, float* out, long out_stride,
+                         long npix, int relu, void* stream);
+int sisr_sft_combine_bwd(const float* dout, long dout_stride, const float* x, long x_stride, const float* y2, float* dx,
+                         float* dy2, long npix, int relu, void* stream);
+int sisr_map64(const float* a, long a_stride, const float* b, long b_stride, float* out, long out_stride, long npix, int op,
+               void* stream);
+int sisr_conv9_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, void* stream);
+int sisr_conv9_dgrad(const float* dy, const float* w, const float* leaky_mask, float* dx, int B, int H, int W, void* stream);
+size_t sisr_conv9_wgrad_workspace_bytes(int B, int H, int W);
+int sisr_conv9_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, size_t workspace_bytes, int B,
+                     int H, int W, void* stream);
+int sisr_clamp01(const float* a, const float* grad, float* out, long n, int backward, void* stream);
 
 #ifdef __cplusplus
 }

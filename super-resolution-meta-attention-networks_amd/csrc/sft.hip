@@ -137,8 +137,8 @@ extern "C" int sisr_sft_combine_bwd(const float* dout, long dout_stride, const f
 // op 1: out = a + b                  (fea_mid + fea_bef; gradient sums)
 // op 2: out = leaky(a)               (a > 0 ? a : 0.2 a)
 // op 3: out = b * (a > 0 ? 1 : 0.2)  (LeakyReLU backward: a = the activation's output, b = incoming gradient)
-__global__ __launch_bounds__(256) void map64_kernel(const float* __restrict__ a, long as, const float* __restrict__ b, long bs,
-                                                    float* __restrict__ out, long os, long npix, int op) {
+__global__ __launch_bounds__(256) void map64_kernel(const float* a, long as, const float* b, long bs,
+                                                    float* out, long os, long npix, int op) {
   const long total = npix * 16;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long p = i >> 4;

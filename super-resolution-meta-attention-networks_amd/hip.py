@@ -98,6 +98,17 @@ _SIGS.update({  # on-the-fly degradation (csrc/degrade.hip)
     "sisr_blur_quant": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "sisr_pil_resample": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
 })
+_SIGS.update({  # SFTMD pieces (csrc/sft.hip)
+    "sisr_compose_oihw2": (c_int, [P, P, P] + [c_int] * 12 + [P]),
+    "sisr_sft_combine_fwd": (c_int, [P, c_long, P, P, P, c_long, c_long, c_int, P]),
+    "sisr_sft_combine_bwd": (c_int, [P, c_long, P, c_long, P, P, P, c_long, c_int, P]),
+    "sisr_map64": (c_int, [P, c_long, P, c_long, P, c_long, c_long, c_int, P]),
+    "sisr_conv9_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "sisr_conv9_dgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "sisr_conv9_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "sisr_conv9_wgrad": (c_int, [P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
+    "sisr_clamp01": (c_int, [P, P, P, c_long, c_int, P]),
+})
 _SIGS.update({  # SAN attention (csrc/san.hip)
     "sisr_covpool_workspace_bytes": (c_size_t, [c_int, c_long]),
     "sisr_covpool_fwd": (c_int, [P, P, P, P, c_int, c_long, c_int, P]),

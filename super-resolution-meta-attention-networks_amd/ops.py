@@ -1213,6 +1213,292 @@ def shuffle_rgb(y, channels, r):
     return _ShuffleRGB.apply(y, int(channels), int(r))
 
 
+# ----------------------------------------------------------------------------- SFTMD (csrc/sft.hip)
+LEAKY, LEAKY_MASK = 2, 4  # `relu` codes of sisr_conv3x3_c64: LeakyReLU(0.2) epilogue / the mask is its derivative
+
+
+def _fp32_only(what):
+    if PRECISION != "fp32":
+        raise NotImplementedError(f"{what} runs on the fp32 kernels only (SISR_PRECISION={PRECISION})")
+
+
+def _compose2(a, b, dst, cop, cip, taps, oa0, ia0, coa, cia, ob0, ib0, cob, cib, split=0):
+    hip.check(hip.lib().sisr_compose_oihw2(hip.ptr(a), hip.ptr(b), hip.ptr(dst), cop, cip, taps, oa0, ia0, coa, cia, ob0,
+                                           ib0, cob, cib, int(split), hip.stream()), "sisr_compose_oihw2")
+
+
+def _map64(a, a_stride, b, b_stride, out, out_stride, npix, op, a_off=0, out_off=0):
+    """op 0 copy / 1 a + b / 2 LeakyReLU(a) / 3 b * LeakyReLU'(a) on 64-channel maps with pixel strides (floats)."""
+    hip.check(hip.lib().sisr_map64(hip.ptr(a) + 4 * a_off, a_stride, hip.ptr(b), b_stride, hip.ptr(out) + 4 * out_off,
+                                   out_stride, npix, op, hip.stream()), "sisr_map64")
+
+
+class _SftLayer(Function):
+    """out = [relu](x * sigmoid(mul(cat)) + add(cat)), cat = (x, metadata maps); mul / add = conv3x3 -> LeakyReLU(0.2) ->
+    conv3x3 with 32 hidden channels each (ref: SFTMD_variants/architectures.py:25-56 StandardSft; the F.relu of
+    SFT_Residual_Block.forward :100-102 folded in).  Two MFMA convs instead of four: A = [mul_conv1 | add_conv1] merged
+    along the outputs (128 -> 64, LeakyReLU epilogue), B = block-diagonal [mul_conv2, add_conv2] (64 -> 128); the merged
+    weights are composed per call from the four parameters and their gradients split back.  md: channels-last
+    [B, 64, H, W], the M metadata maps zero-padded (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, md, relu, M, mw1, mb1, aw1, ab1, mw2, mb2, aw2, ab2):
+        _fp32_only("SFT layer")
+        B, C, H, W = x.shape
+        if C != 64 or md.shape != (B, 64, H, W) or tuple(mw1.shape) != (32, 64 + M, 3, 3) or tuple(mw2.shape) != (64, 32, 3, 3):
+            raise NotImplementedError("SFT layer: 64 features, 32 hidden channels, at most 64 metadata maps")
+        dev, npix = x.device, B * H * W
+        x, md = _cl(x), _cl(md)
+        cat = _empty_cl(B, 128, H, W, dev)
+        _map64(x, 64, None, 0, cat, 128, npix, 0)
+        _map64(md, 64, None, 0, cat, 128, npix, 0, out_off=64)
+        WA = torch.empty((64, 128, 3, 3), device=dev)
+        bA = torch.empty(64, device=dev)
+        WB = torch.empty((128, 64, 3, 3), device=dev)
+        bB = torch.empty(128, device=dev)
+        _compose2(mw1.contiguous(), aw1.contiguous(), WA, 64, 128, 9, 0, 0, 32, 64 + M, 32, 0, 32, 64 + M)
+        _compose2(mb1, ab1, bA, 64, 1, 1, 0, 0, 32, 1, 32, 0, 32, 1)
+        _compose2(mw2.contiguous(), aw2.contiguous(), WB, 128, 64, 9, 0, 0, 64, 32, 64, 32, 64, 32)
+        _compose2(mb2, ab2, bB, 128, 1, 1, 0, 0, 64, 1, 64, 0, 64, 1)
+        pfA, pdA = pack_pair(WA)
+        pfB, pdB = pack_pair(WB)
+        t = _empty_cl(B, 64, H, W, dev)
+        conv_c64(cat, hip.view_plain(H, W, 128), pfA, bA, (1, 64), t, hip.view_plain(H, W, 64), B, H, W, 128, 64, relu=LEAKY)
+        y2 = _empty_cl(B, 128, H, W, dev)
+        conv_c64(t, hip.view_plain(H, W, 64), pfB, bB, (1, 64), y2, hip.view_plain(H, W, 128), B, H, W, 64, 128)
+        out = _empty_cl(B, 64, H, W, dev)
+        hip.check(hip.lib().sisr_sft_combine_fwd(hip.ptr(cat), 128, hip.ptr(y2), None, hip.ptr(out), 64, npix, int(relu),
+                                                 hip.stream()), "sisr_sft_combine_fwd")
+        ctx.save_for_backward(cat, t, y2)
+        ctx.packs = (pdA, pdB)
+        ctx.cfg = (B, H, W, int(relu), M)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        global IN_BACKWARD
+        IN_BACKWARD = True
+        try:
+            cat, t, y2 = ctx.saved_tensors
+            pdA, pdB = ctx.packs
+            B, H, W, relu, M = ctx.cfg
+            dev, npix = dout.device, B * H * W
+            dout = _cl(dout)
+            v64, v128 = hip.view_plain(H, W, 64), hip.view_plain(H, W, 128)
+            dx0 = _empty_cl(B, 64, H, W, dev)
+            dy2 = _empty_cl(B, 128, H, W, dev)
+            hip.check(hip.lib().sisr_sft_combine_bwd(hip.ptr(dout), 64, hip.ptr(cat), 128, hip.ptr(y2), hip.ptr(dx0),
+                                                     hip.ptr(dy2), npix, relu, hip.stream()), "sisr_sft_combine_bwd")
+            dWB = torch.empty((128, 64, 3, 3), device=dev)
+            dbB = torch.empty(128, device=dev)
+            wgrad_c64(t, v64, dy2, v128, dWB, dbB, B, H, W, 64, 128)
+            dt = _empty_cl(B, 64, H, W, dev)
+            conv_c64(dy2, v128, pdB, None, (1, 64), dt, v64, B, H, W, 128, 64, mask=t, relu=LEAKY_MASK)
+            dWA = torch.empty((64, 128, 3, 3), device=dev)
+            dbA = torch.empty(64, device=dev)
+            wgrad_c64(cat, v128, dt, v64, dWA, dbA, B, H, W, 128, 64)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                # input gradient of A for the 64 feature channels only (output chunk 0 of the packing) + the direct term
+                dx = _empty_cl(B, 64, H, W, dev)
+                conv_c64(dt, v64, pdA, None, (1, 64), dx, v64, B, H, W, 64, 64, res=dx0)
+            g = [torch.empty(s, device=dev) for s in ((32, 64 + M, 3, 3), (32,), (32, 64 + M, 3, 3), (32,), (64, 32, 3, 3),
+                                                      (64,), (64, 32, 3, 3), (64,))]
+            _compose2(g[0], g[2], dWA, 64, 128, 9, 0, 0, 32, 64 + M, 32, 0, 32, 64 + M, split=1)
+            _compose2(g[1], g[3], dbA, 64, 1, 1, 0, 0, 32, 1, 32, 0, 32, 1, split=1)
+            _compose2(g[4], g[6], dWB, 128, 64, 9, 0, 0, 64, 32, 64, 32, 64, 32, split=1)
+            _compose2(g[5], g[7], dbB, 128, 1, 1, 0, 0, 64, 1, 64, 0, 64, 1, split=1)
+            return (dx, None, None, None, *g)
+        finally:
+            IN_BACKWARD = False
+
+
+def sft_layer(x, md, module, relu):
+    """module: sftmd.StandardSft (parameter holder)."""
+    M = module.mul_conv1.weight.shape[1] - 64
+    return _SftLayer.apply(x, md, bool(relu), int(M), *module.params())
+
+
+class _SftmdHead(Function):
+    """fea_bef = conv3(leaky(conv2(leaky(conv1(x))))) (ref: SFTMD_variants/architectures.py:162): x NCHW RGB."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3):
+        _fp32_only("SFTMD")
+        B, C, H, W = x.shape
+        if C != 3 or tuple(w1.shape) != (64, 3, 3, 3) or tuple(w2.shape) != (64, 64, 3, 3) or tuple(w3.shape) != (64, 64, 3, 3):
+            raise NotImplementedError("SFTMD head: RGB -> 64 -> 64 -> 64")
+        dev, npix = x.device, B * H * W
+        x = x.contiguous()
+        v64 = hip.view_plain(H, W, 64)
+        y1 = _empty_cl(B, 64, H, W, dev)
+        hip.check(hip.lib().sisr_conv3x3_cin3(hip.ptr(x), hip.ptr(w1.contiguous()), 27, 9, 0, hip.ptr(b1), hip.ptr(y1), v64, B,
+                                              H, W, 64, hip.stream()), "sisr_conv3x3_cin3")
+        _map64(y1, 64, None, 0, y1, 64, npix, 2)
+        pf2, pd2 = pack_pair(w2.contiguous())
+        pf3, pd3 = pack_pair(w3.contiguous())
+        y2 = _empty_cl(B, 64, H, W, dev)
+        conv_c64(y1, v64, pf2, b2, (1, 64), y2, v64, B, H, W, 64, 64, relu=LEAKY)
+        y3 = _empty_cl(B, 64, H, W, dev)
+        conv_c64(y2, v64, pf3, b3, (1, 64), y3, v64, B, H, W, 64, 64)
+        ctx.save_for_backward(x, y1, y2, w1, w2, w3)
+        ctx.packs = (pd2, pd3)
+        return y3
+
+    @staticmethod
+    def backward(ctx, d3):
+        global IN_BACKWARD
+        IN_BACKWARD = True
+        try:
+            x, y1, y2, w1, w2, w3 = ctx.saved_tensors
+            pd2, pd3 = ctx.packs
+            B, _, H, W = x.shape
+            dev = x.device
+            L = hip.lib()
+            d3 = _cl(d3)
+            v64 = hip.view_plain(H, W, 64)
+            dw3, db3 = _grad_buf(w3), torch.empty(64, device=dev)
+            wgrad_c64(y2, v64, d3, v64, dw3, db3, B, H, W, 64, 64)
+            d2 = _empty_cl(B, 64, H, W, dev)
+            conv_c64(d3, v64, pd3, None, (1, 64), d2, v64, B, H, W, 64, 64, mask=y2, relu=LEAKY_MASK)
+            dw2, db2 = _grad_buf(w2), torch.empty(64, device=dev)
+            wgrad_c64(y1, v64, d2, v64, dw2, db2, B, H, W, 64, 64)
+            d1 = _empty_cl(B, 64, H, W, dev)
+            conv_c64(d2, v64, pd2, None, (1, 64), d1, v64, B, H, W, 64, 64, mask=y1, relu=LEAKY_MASK)
+            dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
+            nbytes = L.sisr_corr3x3_c3_workspace_bytes(B, H, W, 64)
+            ws = hip.workspace(dev, nbytes)
+            hip.check(L.sisr_corr3x3_c3(hip.ptr(x), hip.ptr(d1), v64, 1.0, hip.ptr(dw1), 27, 9, 0, 0, hip.ptr(db1), hip.ptr(ws),
+                                        nbytes, B, H, W, 64, hip.stream()), "sisr_corr3x3_c3(head)")
+            return None, dw1, db1, dw2, db2, dw3, db3
+        finally:
+            IN_BACKWARD = False
+
+
+class _SftmdTail(Function):
+    """clamp(conv_output(upscale(conv_mid(fea)))) (ref: SFTMD_variants/architectures.py:137-176): conv_mid, then one
+    (x2, x3: PixelShuffle(scale)) or two (x4: PixelShuffle(2) twice) conv -> shuffle -> LeakyReLU(0.2) stages with the
+    shuffle as the conv's output view and the activation as its epilogue, the 9x9 64 -> 3 conv and the clamp to [0, 1]."""
+
+    @staticmethod
+    def forward(ctx, fea, n_up, *params):
+        _fp32_only("SFTMD")
+        B, C, H, W = fea.shape
+        dev = fea.device
+        wm, bm = params[0], params[1]
+        ups = [(params[2 + 2 * k], params[3 + 2 * k]) for k in range(n_up)]
+        wo, bo = params[2 + 2 * n_up], params[3 + 2 * n_up]
+        if C != 64 or tuple(wo.shape) != (3, 64, 9, 9):
+            raise NotImplementedError("SFTMD tail: 64 features, 9x9 64 -> 3 output conv")
+        fea = _cl(fea)
+        v64 = hip.view_plain(H, W, 64)
+        pfm, pdm = pack_pair(wm.contiguous())
+        m = _empty_cl(B, 64, H, W, dev)
+        conv_c64(fea, v64, pfm, bm, (1, 64), m, v64, B, H, W, 64, 64)
+        maps, geo, packs = [fea, m], [], [pdm]
+        cur, h, w = m, H, W
+        for wu, bu in ups:
+            rr = wu.shape[0] // 64
+            r = int(round(rr ** 0.5))
+            if r * r != rr or wu.shape[1] != 64 or r < 2:
+                raise NotImplementedError("SFTMD upscale conv: 64 -> 64 r^2 feeding PixelShuffle(r)")
+            pf, pd = pack_pair(wu.contiguous(), r)
+            y = _empty_cl(B, 64, h * r, w * r, dev)
+            conv_c64(cur, hip.view_plain(h, w, 64), pf, bu, (rr, 1), y, hip.view_shuffle(h, w, r), B, h, w, 64, 64 * rr,
+                     relu=LEAKY)
+            geo.append((h, w, r))
+            packs.append(pd)
+            maps.append(y)
+            cur, h, w = y, h * r, w * r
+        pre = torch.empty((B, 3, h, w), device=dev)
+        hip.check(hip.lib().sisr_conv9_fwd(hip.ptr(cur), hip.ptr(wo.contiguous()), hip.ptr(bo), hip.ptr(pre), B, h, w,
+                                           hip.stream()), "sisr_conv9_fwd")
+        out = torch.empty_like(pre)
+        hip.check(hip.lib().sisr_clamp01(hip.ptr(pre), None, hip.ptr(out), pre.numel(), 0, hip.stream()), "sisr_clamp01")
+        ctx.save_for_backward(pre, *maps, wm, *[u[0] for u in ups], wo)
+        ctx.cfg = (B, H, W, n_up, geo)
+        ctx.packs = packs
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        global IN_BACKWARD
+        IN_BACKWARD = True
+        try:
+            B, H, W, n_up, geo = ctx.cfg
+            sv = list(ctx.saved_tensors)
+            pre, maps, ws_ = sv[0], sv[1:3 + n_up], sv[3 + n_up:]
+            wm, wus, wo = ws_[0], ws_[1:1 + n_up], ws_[1 + n_up]
+            dev = pre.device
+            L = hip.lib()
+            h, w = pre.shape[2], pre.shape[3]
+            dpre = torch.empty_like(pre)
+            hip.check(L.sisr_clamp01(hip.ptr(pre), hip.ptr(dout.contiguous()), hip.ptr(dpre), pre.numel(), 1, hip.stream()),
+                      "sisr_clamp01(backward)")
+            top = maps[-1]  # the activated map the 9x9 conv read
+            dwo, dbo = torch.empty_like(wo), torch.empty(3, device=dev)
+            nbytes = L.sisr_conv9_wgrad_workspace_bytes(B, h, w)
+            ws = hip.workspace(dev, nbytes)
+            hip.check(L.sisr_conv9_wgrad(hip.ptr(top), hip.ptr(dpre), hip.ptr(dwo), hip.ptr(dbo), hip.ptr(ws), nbytes, B, h, w,
+                                         hip.stream()), "sisr_conv9_wgrad")
+            g = _empty_cl(B, 64, h, w, dev)
+            hip.check(L.sisr_conv9_dgrad(hip.ptr(dpre), hip.ptr(wo.contiguous()), hip.ptr(top) if n_up else None, hip.ptr(g), B,
+                                         h, w, hip.stream()), "sisr_conv9_dgrad")
+            grads = [None] * (4 + 2 * n_up)
+            grads[2 + 2 * n_up], grads[3 + 2 * n_up] = dwo, dbo
+            for k in range(n_up - 1, -1, -1):
+                hk, wk, r = geo[k]
+                rr = r * r
+                xin = maps[1 + k]  # m for k == 0, else the previous stage's activated output
+                dyv = hip.view_shuffle(hk, wk, r)
+                vin = hip.view_plain(hk, wk, 64)
+                dwu, dbu = _grad_buf(wus[k]), torch.empty(64 * rr, device=dev)
+                wgrad_c64(xin, vin, g, dyv, dwu, dbu, B, hk, wk, 64, 64 * rr, shuffle=r)
+                gin = _empty_cl(B, 64, hk, wk, dev)
+                if k > 0:  # the map below is a LeakyReLU output
+                    conv_c64(g, dyv, ctx.packs[1 + k], None, (1, 64), gin, vin, B, hk, wk, 64 * rr, 64, mask=xin,
+                             relu=LEAKY_MASK)
+                else:
+                    conv_c64(g, dyv, ctx.packs[1 + k], None, (1, 64), gin, vin, B, hk, wk, 64 * rr, 64)
+                grads[2 + 2 * k], grads[3 + 2 * k] = dwu, dbu
+                g = gin
+            v64 = hip.view_plain(H, W, 64)
+            dwm, dbm = _grad_buf(wm), torch.empty(64, device=dev)
+            wgrad_c64(maps[0], v64, g, v64, dwm, dbm, B, H, W, 64, 64)
+            grads[0], grads[1] = dwm, dbm
+            dfea = None
+            if ctx.needs_input_grad[0]:
+                dfea = _empty_cl(B, 64, H, W, dev)
+                conv_c64(g, v64, ctx.packs[0], None, (1, 64), dfea, v64, B, H, W, 64, 64)
+            return (dfea, None, *grads)
+        finally:
+            IN_BACKWARD = False
+
+
+def sftmd_forward(net, x, metadata):
+    """The whole SFTMD network (sftmd.SFTMD holds the parameters; ref: SFTMD_variants/architectures.py:161-176)."""
+    _fp32_only("SFTMD")
+    B, _, H, W = x.shape
+    if metadata.dim() != 4 or metadata.shape[0] != B or metadata.shape[1] != net.para or tuple(metadata.shape[2:]) != (H, W):
+        raise RuntimeError(f"SFTMD: metadata maps must be (B, {net.para}, H, W); got {tuple(metadata.shape)}")
+    md = nchw_to_nhwc_pad(metadata.detach().float(), 64)
+    fea_bef = _SftmdHead.apply(x, net.conv1.weight, net.conv1.bias, net.conv2.weight, net.conv2.bias, net.conv3.weight,
+                               net.conv3.bias)
+    fea = fea_bef
+    for blk in net.blocks():
+        f1 = sft_layer(fea, md, blk.sft1.sft_module, True)
+        c1 = conv3x3(f1, blk.conv1.weight, blk.conv1.bias)
+        f2 = sft_layer(c1, md, blk.sft2.sft_module, True)
+        fea = conv3x3(f2, blk.conv2.weight, blk.conv2.bias, residual=fea)
+    fea_fin = sft_layer(add_residual(fea, fea_bef), md, net.sft.sft_module, False)
+    convs = [m for m in net.upscale if isinstance(m, torch.nn.Conv2d)]
+    params = [net.conv_mid.weight, net.conv_mid.bias]
+    for c in convs:
+        params += [c.weight, c.bias]
+    params += [net.conv_output.weight, net.conv_output.bias]
+    return _SftmdTail.apply(fea_fin, len(convs), *params)
+
+
 # ----------------------------------------------------------------------------- stand-alone gates
 def _pixel_sums(t, other, B, H, W):
     """[B][parts][64] ordered partial sums of t*other (other None: of t)."""

@@ -1,0 +1,146 @@
+"""SFTMD on the HIP kernels vs the reference's own vectors (pytest -m gpu; fixtures: tools/make_fixtures_sftmd.py) and, for
+the new kernels one by one, vs the oracle's formulation of the same op."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import sisr_amd
+from sisr_amd import hip, ops
+from conftest import golden_json, load_golden
+from test_init_parity import set5
+from test_oracle_sftmd import PARAMS, reduced_net
+
+pytestmark = pytest.mark.gpu
+
+
+def build(eval_mode=True, **extra):
+    torch.manual_seed(8)
+    return sisr_amd.available_models["sftmd"](device=0, model_save_dir="/tmp", eval_mode=eval_mode, scale=4, **PARAMS, **extra)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("shape", [(1, 7, 9), (2, 16, 33), (1, 40, 70)])
+def test_conv9_forward_and_gradients(shape):
+    """9x9 64 -> 3 conv + clamp (ref: SFTMD.conv_output, :159): ragged sizes smaller and larger than the 9-tap window."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = (torch.randn(3, 64, 9, 9, generator=g) * 0.02).requires_grad_(True)
+    b = (torch.randn(3, generator=g) * 0.1 + 0.4).requires_grad_(True)
+    cot = torch.randn(B, 3, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    want = torch.clamp(F.conv2d(F.leaky_relu(xr, 0.2), w, b, padding=4), 0, 1)
+    want.backward(cot)
+    xa = F.leaky_relu(x, 0.2).cuda().contiguous(memory_format=torch.channels_last)
+    L, dev = hip.lib(), xa.device
+    wc, bc = w.detach().cuda(), b.detach().cuda()
+    pre = torch.empty(B, 3, H, W, device=dev)
+    hip.check(L.sisr_conv9_fwd(hip.ptr(xa), hip.ptr(wc), hip.ptr(bc), hip.ptr(pre), B, H, W, hip.stream()), "conv9")
+    out = torch.empty_like(pre)
+    hip.check(L.sisr_clamp01(hip.ptr(pre), None, hip.ptr(out), pre.numel(), 0, hip.stream()), "clamp")
+    np.testing.assert_allclose(out.cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=2e-6)
+    dpre = torch.empty_like(pre)
+    hip.check(L.sisr_clamp01(hip.ptr(pre), hip.ptr(cot.cuda()), hip.ptr(dpre), pre.numel(), 1, hip.stream()), "clamp bwd")
+    dx = torch.empty(B, 64, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    hip.check(L.sisr_conv9_dgrad(hip.ptr(dpre), hip.ptr(wc), hip.ptr(xa), hip.ptr(dx), B, H, W, hip.stream()), "conv9 dgrad")
+    assert rel(dx, xr.grad) < 2e-6
+    dw, db = torch.empty_like(wc), torch.empty(3, device=dev)
+    nbytes = L.sisr_conv9_wgrad_workspace_bytes(B, H, W)
+    ws = hip.workspace(dev, nbytes)
+    hip.check(L.sisr_conv9_wgrad(hip.ptr(xa), hip.ptr(dpre), hip.ptr(dw), hip.ptr(db), hip.ptr(ws), nbytes, B, H, W,
+                                 hip.stream()), "conv9 wgrad")
+    assert rel(dw, w.grad) < 2e-6 and rel(db, b.grad) < 2e-6
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("M", [1, 10, 64])
+def test_sft_layer_matches_the_four_conv_formulation(relu, M):
+    """Merged / block-diagonal MFMA convs + combine kernel vs StandardSft as the reference writes it (:46-56)."""
+    g = torch.Generator().manual_seed(5 + M)
+    B, H, W = 2, 10, 37
+    mod = sisr_amd.sftmd.StandardSft(nf=64, para=M)
+    x = torch.randn(B, 64, H, W, generator=g)
+    md = torch.rand(B, M, H, W, generator=g)
+    cot = torch.randn(B, 64, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    cat = torch.cat((xr, md), 1)
+    mul = torch.sigmoid(mod.mul_conv2(F.leaky_relu(mod.mul_conv1(cat), 0.2)))
+    add = mod.add_conv2(F.leaky_relu(mod.add_conv1(cat), 0.2))
+    want = xr * mul + add
+    want = F.relu(want) if relu else want
+    want.backward(cot)
+    ref_g = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    mod.zero_grad()
+    mod.cuda()
+    xg = x.cuda().requires_grad_(True)
+    out = ops.sft_layer(xg, ops.nchw_to_nhwc_pad(md.cuda(), 64), mod, relu)
+    assert rel(out, want) < 2e-6
+    out.backward(cot.cuda())
+    assert rel(xg.grad, xr.grad) < 5e-6
+    for k, p in mod.named_parameters():
+        assert rel(p.grad, ref_g[k]) < 5e-6, k
+
+
+def test_leaky_codes_are_refused_off_the_fp32_kernels():
+    x = torch.zeros(1, 64, 8, 32, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(64, 64, 3, 3, device="cuda")
+    prev = ops.PRECISION
+    try:
+        ops.set_precision("bf16")
+        pf, _ = ops.pack_pair(w)
+        with pytest.raises(RuntimeError, match="unsupported"):
+            ops.conv_c64(x, hip.view_plain(8, 32, 64), pf, None, (1, 64), torch.empty_like(x), hip.view_plain(8, 32, 64), 1, 8, 32,
+                         64, 64, relu=ops.LEAKY)
+        with pytest.raises(NotImplementedError):
+            ops.sftmd_forward(None, x, x)
+    finally:
+        ops.set_precision(prev)
+
+
+def test_f1_reduced_net_output_and_gradients():
+    a, meta = load_golden("f1_sftmd_reduced")
+    net = reduced_net().to("cuda:0")
+    out = net(torch.from_numpy(a["in0"]).cuda(), torch.from_numpy(a["in1"]).cuda())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), a["out"], rtol=2e-4, atol=2e-5)
+    out.backward(torch.from_numpy(a["cot"]).cuda())
+    for k, p in net.named_parameters():
+        gn = float(a["pgn/" + k])
+        assert abs(float(p.grad.double().norm()) / gn - 1) < 1e-4, k
+        np.testing.assert_allclose(p.grad.reshape(-1)[:32].cpu().numpy(), a["pg32/" + k], rtol=2e-3,
+                                   atol=5e-5 * gn / np.sqrt(p.numel()) + 1e-9, err_msg=k)
+
+
+def test_f2_set5_forward_psnr_parity_with_reference():
+    ref = golden_json("f_sftmd")["full_depth"]["images"]
+    crops = np.load(f"{sisr_amd.__path__[0]}/../tests/golden/f2_sftmd_crops.npz")
+    h = build()
+    for im, x, y, md in set5():
+        if im not in ref:
+            continue
+        out, loss, _ = h.run_eval(x, y, request_loss=True, metadata=md, metadata_keys=[("blur_kernel",)] * 10)
+        o = out[0].numpy()
+        assert abs(sisr_amd.metrics.y_psnr(o, y[0].numpy()) - ref[im]["y_psnr"]) < 1e-3, im
+        assert abs(float(loss) - ref[im]["l1"]) < 1e-5
+        hh, ww = o.shape[1:]
+        np.testing.assert_allclose(o[:, hh // 2 - 16:hh // 2 + 16, ww // 2 - 16:ww // 2 + 16], crops[im], rtol=1e-3, atol=1e-4)
+
+
+def test_f3_run_train_trajectory_matches_reference():
+    ref = golden_json("f_sftmd")["train_steps"]
+    h = build(eval_mode=False, lr=1e-4, scheduler=ref["scheduler"], scheduler_params=ref["scheduler_params"])
+    g = torch.Generator().manual_seed(77)
+    for step in ref["steps"]:
+        x, y = torch.rand(2, 3, 16, 16, generator=g), torch.rand(2, 3, 64, 64, generator=g)
+        md = torch.rand(2, 10, generator=g, dtype=torch.float64) * 0.4
+        assert abs(h.get_learning_rate() - step["lr_before"]) < 1e-12
+        loss, out = h.run_train(x, y, metadata=md, metadata_keys=[("blur_kernel", "blur_kernel")] * 10)
+        gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in h.net.parameters())))
+        assert abs(float(loss) - step["loss"]) < 5e-6 and abs(gn / step["grad_norm"] - 1) < 2e-4
+        assert abs(float(out.mean()) - step["out_mean"]) < 5e-5 and abs(h.get_learning_rate() - step["lr_after"]) < 1e-12
+    psum = float(sum(v.double().sum() for v in h.net.state_dict().values()))
+    assert abs(psum - ref["final_param_sum"]) < 5e-2
