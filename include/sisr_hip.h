@@ -325,17 +325,17 @@ int sisr_pil_resample(const unsigned char* in, void* out, const int* bounds, con
  * ref: SFTMD_variants/architectures.py:25-56 StandardSft (x * sigmoid(mul) + add), :110-176 SFTMD (LeakyReLU(0.2),
  * 9x9 64 -> 3 output conv, clamp).  The network's 3x3 convs run on sisr_conv3x3_c64 with `relu` = 2 (LeakyReLU(0.2)
  * epilogue) or `relu` | 4 (the `mask` operand carries LeakyReLU's derivative: slope 0.2 where the map is <= 0).
- * sisr_compose_oihw2: dst[cop][cip][taps] = zeros with block A (a[coa][cia][taps]) at (oa0, ia0) and block B at
- *   (ob0, ib0) -- the merged [mul_conv1 | add_conv1] and block-diagonal [mul_conv2, add_conv2] weights of an SFT layer;
- *   split != 0: the two blocks of dst are copied back into a / b (their gradients).
+ * sisr_sft_compose: split == 0: WA [64][128][9] = rows (mul_conv1 | add_conv1) over input channels 0 .. 63 + M (rest
+ *   zero), bA [64], WB [128][64][9] = block-diagonal (mul_conv2 on inputs 0..31, add_conv2 on inputs 32..63), bB [128]
+ *   from the layer's eight parameters; split != 0: the reverse copy (gradients).  M = metadata maps (<= 64).
  * sisr_sft_combine_fwd: out = [relu](x * sigmoid(y2[:, :64]) + y2[:, 64:]); x / out with pixel strides (floats), y2
  *   [npix][128]; md (nullable) [npix][64] is copied into out's second 64-channel chunk.  _bwd: dx [npix][64], dy2.
  * sisr_map64: 64-channel maps with pixel strides: op 0 copy, 1 a + b, 2 LeakyReLU(a), 3 b * LeakyReLU'(a).
  * sisr_conv9_*: 9x9 conv 64 -> 3 (OIHW weight), x NHWC [B][H][W][64], y NCHW; dgrad optionally masked by LeakyReLU'
  *   of `leaky_mask` (the activated map that fed the conv); wgrad: ordered two-stage sums (dw OIHW, db).
  * sisr_clamp01: backward == 0: out = clamp(a, 0, 1); else out = grad * [0 <= a <= 1]. */
-int sisr_compose_oihw2(float* a, float* b, float* dst, int cop, int cip, int taps, int oa0, int ia0, int coa, int cia,
-                       int ob0, int ib0, int cob, int cib, int split, void* stream);
+int sisr_sft_compose(float* mul_w1, float* mul_b1, float* add_w1, float* add_b1, float* mul_w2, float* mul_b2, float* add_w2,
+                     float* add_b2, float* WA, float* bA, float* WB, float* bB, int M, int split, void* stream);
 int sisr_sft_combine_fwd(const float* x, long x_stride, const float* y2, const float* md, float* out, long out_stride,
                          long npix, int relu, void* stream);
 int sisr_sft_combine_bwd(const float* dout, long dout_stride, const float* x, long x_stride, const float* y2, float* dx,

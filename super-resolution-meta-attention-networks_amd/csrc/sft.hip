@@ -2,8 +2,8 @@
 // ref: Code/SISR/models/SFTMD_variants/architectures.py:25-56 (StandardSft: x * sigmoid(mul) + add),
 //      :110-176 (SFTMD: LeakyReLU(0.2) head / upscale, 9x9 64 -> 3 output conv, clamp to [0, 1]).
 // The 3x3 convs of the network run on the MFMA kernels of conv3x3_mfma.hip (LeakyReLU as epilogue / mask slope); here:
-//   compose_oihw2   two weight blocks placed into one zero-padded OIHW tensor (the merged / block-diagonal SFT convs) and
-//                   the reverse split of its gradient
+//   sft_compose     the four conv weights / biases of an SFT layer placed into the merged / block-diagonal tensors of its
+//                   two MFMA convs, and the reverse split of their gradients (one launch each)
 //   sft_combine     out = [relu](x * sigmoid(y2[:64]) + y2[64:]) on pixel-strided maps, + copy of the metadata chunk;
 //                   backward -> dx and d y2 (ReLU mask recomputed)
 //   copy_chunk / add2 / leaky  strided 64-channel helpers (metadata chunk fill, fea_mid + fea_bef, LeakyReLU after the
@@ -21,40 +21,49 @@ static unsigned sft_blocks(long n) {
 }
 
 // ------------------------------------------------------------------ weight composition
-struct Compose2 {
-  int cop, cip, taps;
-  int oa0, ia0, coa, cia, ob0, ib0, cob, cib;
+// One launch per SFT layer and direction.  split == 0: the four conv weights / biases of the layer -> the merged
+//   WA [64][128][9]  rows 0..31 = mul_conv1 ([32][64 + M][9]), rows 32..63 = add_conv1, input channels >= 64 + M zero
+//   bA [64]          (mul_conv1.bias | add_conv1.bias)
+//   WB [128][64][9]  rows 0..63 = mul_conv2 ([64][32][9]) on inputs 0..31, rows 64..127 = add_conv2 on inputs 32..63
+//   bB [128]         (mul_conv2.bias | add_conv2.bias)
+// split == 1: the reverse copy (gradients of the merged tensors -> the eight parameter gradients).
+struct SftCompose {
+  float *mw1, *mb1, *aw1, *ab1, *mw2, *mb2, *aw2, *ab2, *WA, *bA, *WB, *bB;
+  int M, split;
 };
-// split == 0: dst[cop][cip][taps] = 0 except block A (a[coa][cia][taps]) at (oa0, ia0) and block B at (ob0, ib0)
-// split == 1: a / b <- the two blocks of dst (gradient of the composition)
-__global__ __launch_bounds__(256) void compose_oihw2_kernel(float* a, float* b, float* dst, Compose2 c, int split) {
-  const long total = (long)c.cop * c.cip * c.taps;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int t = (int)(i % c.taps);
-    const long r = i / c.taps;
-    const int o = (int)(r / c.cip), ci = (int)(r - (long)o * c.cip);
-    const bool inA = o >= c.oa0 && o < c.oa0 + c.coa && ci >= c.ia0 && ci < c.ia0 + c.cia;
-    const bool inB = o >= c.ob0 && o < c.ob0 + c.cob && ci >= c.ib0 && ci < c.ib0 + c.cib;
-    const long ia = ((long)(o - c.oa0) * c.cia + (ci - c.ia0)) * c.taps + t;
-    const long ib = ((long)(o - c.ob0) * c.cib + (ci - c.ib0)) * c.taps + t;
-    if (!split) {
-      dst[i] = inA ? a[ia] : (inB ? b[ib] : 0.f);
+__global__ __launch_bounds__(256) void sft_compose_kernel(SftCompose c) {
+  constexpr int NA = 64 * 128 * 9, NB = 128 * 64 * 9;
+  const int cin = 64 + c.M;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < NA + NB + 64 + 128; i += gridDim.x * 256) {
+    float *merged, *part = nullptr;
+    if (i < NA) {
+      const int t = i % 9, r = i / 9, o = r >> 7, ci = r & 127;
+      merged = c.WA + i;
+      if (ci < cin) part = (o < 32 ? c.mw1 : c.aw1) + ((long)(o & 31) * cin + ci) * 9 + t;
+    } else if (i < NA + NB) {
+      const int k = i - NA, t = k % 9, r = k / 9, o = r >> 6, ci = r & 63;
+      merged = c.WB + k;
+      if ((o < 64) == (ci < 32)) part = (o < 64 ? c.mw2 : c.aw2) + ((long)(o & 63) * 32 + (ci & 31)) * 9 + t;
+    } else if (i < NA + NB + 64) {
+      const int o = i - NA - NB;
+      merged = c.bA + o;
+      part = (o < 32 ? c.mb1 : c.ab1) + (o & 31);
     } else {
-      if (inA) a[ia] = dst[i];
-      if (inB) b[ib] = dst[i];
+      const int o = i - NA - NB - 64;
+      merged = c.bB + o;
+      part = (o < 64 ? c.mb2 : c.ab2) + (o & 63);
     }
+    if (!c.split) *merged = part ? *part : 0.f;
+    else if (part) *part = *merged;
   }
 }
 
-extern "C" int sisr_compose_oihw2(float* a, float* b, float* dst, int cop, int cip, int taps, int oa0, int ia0, int coa,
-                                  int cia, int ob0, int ib0, int cob, int cib, int split, void* stream) {
-  if (!a || !b || !dst || cop <= 0 || cip <= 0 || taps <= 0 || coa <= 0 || cia <= 0 || cob <= 0 || cib <= 0)
+extern "C" int sisr_sft_compose(float* mw1, float* mb1, float* aw1, float* ab1, float* mw2, float* mb2, float* aw2, float* ab2,
+                                float* WA, float* bA, float* WB, float* bB, int M, int split, void* stream) {
+  if (!mw1 || !mb1 || !aw1 || !ab1 || !mw2 || !mb2 || !aw2 || !ab2 || !WA || !bA || !WB || !bB || M < 0 || M > 64)
     return SISR_ERR_ARG;
-  if (oa0 < 0 || ia0 < 0 || ob0 < 0 || ib0 < 0 || oa0 + coa > cop || ob0 + cob > cop || ia0 + cia > cip || ib0 + cib > cip)
-    return SISR_ERR_ARG;
-  const Compose2 c = {cop, cip, taps, oa0, ia0, coa, cia, ob0, ib0, cob, cib};
-  hipLaunchKernelGGL(compose_oihw2_kernel, dim3(sft_blocks((long)cop * cip * taps)), dim3(256), 0, (hipStream_t)stream, a, b,
-                     dst, c, split);
+  const SftCompose c = {mw1, mb1, aw1, ab1, mw2, mb2, aw2, ab2, WA, bA, WB, bB, M, split};
+  hipLaunchKernelGGL(sft_compose_kernel, dim3(288), dim3(256), 0, (hipStream_t)stream, c);
   return sisr_check_launch();
 }
 
@@ -170,170 +179,276 @@ extern "C" int sisr_map64(const float* a, long a_stride, const float* b, long b_
 }
 
 // ------------------------------------------------------------------ 9x9 output conv, 64 -> 3 (OIHW weight [3][64][9][9])
-#define K9 9
+// All three directions run on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate) with the 3-channel side staged in LDS:
+//   forward  Z[q][(co, kw)] = sum_{kh, ci} x[q + (kh - 4) rows][ci] w[co][ci][kh][kw]   (M = 32 pixels of a row, N = 27 -> 32,
+//            K = 9 x 64), then y[co][p] = b[co] + sum_kw Z[p + kw - 4][(co, kw)] through LDS: the 3 output channels alone
+//            would leave 29 of the 32 MFMA columns empty, (co, kw) fills 27 of them; 24 of a tile's 32 columns are outputs.
+//   dgrad    dx[p][ci] = sum_{n = (co, kh, kw)} dy[co][p + 4 - (kh, kw)] w[n][ci]        (M = pixels, N = 64, K = 243 -> 270:
+//            kw padded to 10 so that the two K-halves of a lane pair are neighbouring columns), LeakyReLU' mask epilogue
+//   wgrad    dw[ci][n] = sum_p x[p][ci] dy[co][p + 4 - (kh, kw)]                         (M = 64, N = 243 -> 256, K = pixels),
+//            per-workgroup partial sums, ordered second stage
+// Operand maps of the instruction (as in conv3x3_mfma.hip): A lane = (row i = lane & 31, k = lane >> 5), B lane = (column
+// j = lane & 31, k = lane >> 5), D register r = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of column lane & 31.
 #define T9 81
-// Weights re-ordered once per launch into LDS as [tap][c4 = 16][co = 3][4 ch]: 48 B per (tap, lane), conflict-free.
-__device__ __forceinline__ void conv9_stage_w(const float* __restrict__ w, float* wl) {
-  for (int i = threadIdx.x; i < T9 * 16 * 12; i += 256) {
-    const int e = i & 3, co = (i >> 2) % 3, c4 = (i / 12) & 15, t = i / 192;
-    wl[i] = w[((long)co * 64 + c4 * 4 + e) * T9 + t];
+#define C9_GRID 512  // persistent grid (2 workgroups per CU); fixed, so the summation order does not depend on the device
+
+__device__ __forceinline__ float f4_at(f32x4 v, int e) { return v[e]; }
+
+// ---- forward
+#define F9_WAVES 8
+#define F9_ZLD 33
+#define F9_WZ (9 * 8 * 2 * 32 * 4)  // floats: [kh][octet j][k][n][e] = w[co(n)][8j + 4k + e][kh][kw(n)]
+__global__ __launch_bounds__(64 * F9_WAVES) void conv9_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                                       int B, int H, int W, int tiles_w, long ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds9[];
+  float* wz = lds9;
+  float* zt = lds9 + F9_WZ + (threadIdx.x >> 6) * (32 * F9_ZLD);
+  for (int i = threadIdx.x; i < F9_WZ; i += 64 * F9_WAVES) {
+    const int e = i & 3, n = (i >> 2) & 31, k = (i >> 7) & 1, j = (i >> 8) & 7, kh = i >> 11;
+    const int co = n / 9, kw = n - co * 9, ci = 8 * j + 4 * k + e;
+    wz[i] = n < 27 ? w[((long)co * 64 + ci) * T9 + kh * 9 + kw] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, kk = lane >> 5;
+  // wave tile = 24 output columns of one row; tiles are dealt to (workgroup, wave) in a fixed order
+  for (long t = (long)blockIdx.x * F9_WAVES + wave; t < ntiles; t += (long)gridDim.x * F9_WAVES) {
+    const int tw = (int)(t % tiles_w);
+    const long rr = t / tiles_w;
+    const int gy = (int)(rr % H), b = (int)(rr / H);
+    const int ox0 = tw * 24, qx = ox0 - 4 + li;
+    const bool colok = qx >= 0 && qx < W;
+    const float* xp = x + (((long)b * H) * W + min(max(qx, 0), W - 1)) * 64 + 4 * kk;
+    f32x16 acc = {0};
+    f32x4 cur[8], nxt[8];
+    int kh = max(0, 4 - gy);
+    const int kh_end = min(9, H + 4 - gy);  // rows gy + kh - 4 inside the image
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cur[j] = *reinterpret_cast<const f32x4*>(xp + (long)(gy + kh - 4) * W * 64 + 8 * j);
+    for (; kh < kh_end; ++kh) {
+      const int khn = min(kh + 1, kh_end - 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) nxt[j] = *reinterpret_cast<const f32x4*>(xp + (long)(gy + khn - 4) * W * 64 + 8 * j);
+      const float* wk = wz + kh * 2048 + kk * 128 + li * 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 a = sisr_keep_if(cur[j], colok);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(wk + j * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bb[e], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
+    }
+    // Z tile -> LDS (row = tile column i, column = n), then y[co][o] = b[co] + sum_kw Z[o + kw][co * 9 + kw]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zt[((r & 3) + 8 * (r >> 2) + 4 * kk) * F9_ZLD + li] = acc[r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed (one wave owns zt)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = lane + 64 * u;
+      if (idx < 72) {
+        const int co = idx / 24, o = idx - co * 24;
+        float v = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int kw = 0; kw < 9; ++kw) v += zt[(o + kw) * F9_ZLD + co * 9 + kw];
+        if (ox0 + o < W) y[(((long)b * 3 + co) * H + gy) * W + ox0 + o] = v;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
-// forward: 16 lanes per output pixel, a lane owns 4 input channels; x NHWC [B][H][W][64], y NCHW [B][3][H][W] (pre-clamp)
-__global__ __launch_bounds__(256) void conv9_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ y, int B, int H,
-                                                        int W) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];
-  conv9_stage_w(w, wl);
-  __syncthreads();
-  const int c4 = threadIdx.x & 15;
-  const long hw = (long)H * W, npix = (long)B * hw;
-  const long pend = (npix + 15) & ~15L;
-  for (long pix0 = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix0 < pend; pix0 += (long)gridDim.x * 16) {
-    const bool live = pix0 < npix;
-    const long pix = live ? pix0 : npix - 1;
-    const long b = pix / hw, r = pix - b * hw;
-    const int h = (int)(r / W), wc = (int)(r - (long)h * W);
-    const float* xb = x + b * hw * 64 + c4 * 4;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int kh = 0; kh < K9; ++kh) {
-      const int gh = h + kh - 4;
-      if (gh < 0 || gh >= H) continue;  // uniform within the 16-lane pixel group
+// ---- input gradient
+#define D9_TR 8
+#define D9_HC 40           // 32 + 8 halo columns
+#define D9_HS (16 * D9_HC)  // one channel's halo: (8 + 8) rows
+#define D9_W2 (270 * 64)   // floats: [(co, kh, kp, k)][ci], kw = 2 kp + k, kw == 9 -> 0
+__global__ __launch_bounds__(256) void conv9_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                               const float* __restrict__ mask, float* __restrict__ dx, int B,
+                                                               int H, int W, int tiles_w, int tiles_h, long ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds9[];
+  float* w2 = lds9;
+  float* dyh = lds9 + D9_W2 + 4;  // 4 floats of zero padding in front: kw == 9 reads column -1 (times a zero weight)
+  for (int i = threadIdx.x; i < D9_W2; i += 256) {
+    const int ci = i & 63, n = i >> 6, k = n & 1, kp = (n >> 1) % 5, ckh = n / 10;
+    const int kw = 2 * kp + k;
+    w2[i] = kw < 9 ? w[((long)(ckh / 9) * 64 + ci) * T9 + (ckh % 9) * 9 + kw] : 0.f;
+  }
+  if (threadIdx.x < 4) lds9[D9_W2 + threadIdx.x] = 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, kk = lane >> 5;
+  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int tw = (int)(t % tiles_w);
+    const long rr = t / tiles_w;
+    const int th = (int)(rr % tiles_h), b = (int)(rr / tiles_h);
+    const int ty0 = th * D9_TR, tx0 = tw * 32;
+    __syncthreads();  // the previous tile's gathers are done (and, first time, w2 is staged)
+    for (int i = threadIdx.x; i < 3 * D9_HS; i += 256) {
+      const int co = i / D9_HS, rem = i - co * D9_HS, hr = rem / D9_HC, hc = rem - hr * D9_HC;
+      const int gy = ty0 - 4 + hr, gx = tx0 - 4 + hc;
+      dyh[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? dy[(((long)b * 3 + co) * H + gy) * W + gx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      const int py = wave + 4 * half, gy = ty0 + py;
+      if (gy >= H) break;  // uniform per wave
+      f32x16 acc0 = {0}, acc1 = {0};
+      const float* ap = dyh + py * D9_HC + li - kk + 8;
+      const float* bp = w2 + kk * 64 + li;
+#pragma unroll 1
+      for (int ckh = 0; ckh < 27; ++ckh) {
+        const int co = ckh / 9, kh = ckh - co * 9;
+        const float* a_row = ap + co * D9_HS + (8 - kh) * D9_HC;
+        const float* b_row = bp + ckh * 640;
 #pragma unroll
-      for (int kw = 0; kw < K9; ++kw) {
-        const int gw = wc + kw - 4;
-        const bool ok = gw >= 0 && gw < W;
-        const f32x4 xv = sisr_keep_if(*reinterpret_cast<const f32x4*>(xb + ((long)gh * W + min(max(gw, 0), W - 1)) * 64), ok);
-        const float* wt = wl + ((kh * K9 + kw) * 16 + c4) * 12;
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4),
-                    w2 = *reinterpret_cast<const f32x4*>(wt + 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a0 += xv[e] * w0[e];
-          a1 += xv[e] * w1[e];
-          a2 += xv[e] * w2[e];
+        for (int kp = 0; kp < 5; ++kp) {
+          const float a = a_row[-2 * kp];
+          const float b0 = b_row[kp * 128], b1 = b_row[kp * 128 + 32];
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
         }
       }
-    }
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      a0 += __shfl_xor(a0, o);
-      a1 += __shfl_xor(a1, o);
-      a2 += __shfl_xor(a2, o);
-    }
-    if (live && c4 < 3) {
-      const float v = (c4 == 0 ? a0 : (c4 == 1 ? a1 : a2)) + (bias ? bias[c4] : 0.f);
-      y[(b * 3 + c4) * hw + r] = v;
-    }
-  }
-}
-
-// input gradient: dx[b][h][w][ci] = sum_{co, kh, kw} dy[b][co][h + 4 - kh][w + 4 - kw] * w[co][ci][kh][kw], then the
-// LeakyReLU(0.2) mask of the map x fed forward (mask nullable).  dy NCHW (already clamp-masked), dx NHWC.
-__global__ __launch_bounds__(256) void conv9_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                          const float* __restrict__ mask, float* __restrict__ dx, int B, int H,
-                                                          int W) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];
-  conv9_stage_w(w, wl);
-  __syncthreads();
-  const int c4 = threadIdx.x & 15;
-  const long hw = (long)H * W, npix = (long)B * hw;
-  const long pend = (npix + 15) & ~15L;
-  for (long pix0 = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix0 < pend; pix0 += (long)gridDim.x * 16) {
-    const bool live = pix0 < npix;
-    const long pix = live ? pix0 : npix - 1;
-    const long b = pix / hw, r = pix - b * hw;
-    const int h = (int)(r / W), wc = (int)(r - (long)h * W);
-    const float* db = dy + b * 3 * hw;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kh = 0; kh < K9; ++kh) {
-      const int gh = h + 4 - kh;
-      if (gh < 0 || gh >= H) continue;
-#pragma unroll
-      for (int kw = 0; kw < K9; ++kw) {
-        const int gw = wc + 4 - kw;
-        if (gw < 0 || gw >= W) continue;
-        const long at = (long)gh * W + gw;
-        const float d0 = db[at], d1 = db[hw + at], d2 = db[2 * hw + at];
-        const float* wt = wl + ((kh * K9 + kw) * 16 + c4) * 12;
-        acc += *reinterpret_cast<const f32x4*>(wt) * d0 + *reinterpret_cast<const f32x4*>(wt + 4) * d1 +
-               *reinterpret_cast<const f32x4*>(wt + 8) * d2;
-      }
-    }
-    if (live) {
+      const long row = (((long)b * H + gy) * W + tx0) * 64;
+      float m0[16], m1[16];
       if (mask) {
-        const f32x4 m = *reinterpret_cast<const f32x4*>(mask + pix * 64 + c4 * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = m[e] > 0.f ? acc[e] : 0.2f * acc[e];
+        for (int r = 0; r < 16; ++r) {
+          const int px = (r & 3) + 8 * (r >> 2) + 4 * kk;
+          const long off = row + (long)min(px, W - 1 - tx0) * 64 + li;
+          m0[r] = mask[off];
+          m1[r] = mask[off + 32];
+        }
       }
-      *reinterpret_cast<f32x4*>(dx + pix * 64 + c4 * 4) = acc;
-    }
-  }
-}
-
-// weight gradient partials: block = 256 threads = (16 tap groups) x (16 c4); tap group g owns taps g, g + 16, ... (6 slots);
-// a block walks `span` pixels and writes part[block][tap][co][ci] (ordered second stage: conv9_wgrad_reduce_kernel).
-#define W9_SLOTS 6
-__global__ __launch_bounds__(256) void conv9_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          float* __restrict__ part, int B, int H, int W, long span) {
-  const int c4 = threadIdx.x & 15, tg = threadIdx.x >> 4;
-  const long hw = (long)H * W, npix = (long)B * hw;
-  f32x4 acc[W9_SLOTS][3];
 #pragma unroll
-  for (int s = 0; s < W9_SLOTS; ++s)
-#pragma unroll
-    for (int co = 0; co < 3; ++co) acc[s][co] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum[3] = {0.f, 0.f, 0.f};
-  const long p0 = (long)blockIdx.x * span, p1 = min(p0 + span, npix);
-  for (long pix = p0; pix < p1; ++pix) {
-    const long b = pix / hw, r = pix - b * hw;
-    const int h = (int)(r / W), wc = (int)(r - (long)h * W);
-    const float* db = dy + b * 3 * hw + r;
-    const float d0 = db[0], d1 = db[hw], d2 = db[2 * hw];
-    bsum[0] += d0;
-    bsum[1] += d1;
-    bsum[2] += d2;
-    const float* xb = x + b * hw * 64 + c4 * 4;
-#pragma unroll
-    for (int s = 0; s < W9_SLOTS; ++s) {
-      const int t = tg + 16 * s;
-      if (t < T9) {
-        const int gh = h + t / K9 - 4, gw = wc + t % K9 - 4;
-        if (gh >= 0 && gh < H && gw >= 0 && gw < W) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + ((long)gh * W + gw) * 64);
-          acc[s][0] += xv * d0;
-          acc[s][1] += xv * d1;
-          acc[s][2] += xv * d2;
+      for (int r = 0; r < 16; ++r) {
+        const int px = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (tx0 + px < W) {
+          float v0 = acc0[r], v1 = acc1[r];
+          if (mask) {
+            v0 = m0[r] > 0.f ? v0 : 0.2f * v0;
+            v1 = m1[r] > 0.f ? v1 : 0.2f * v1;
+          }
+          dx[row + (long)px * 64 + li] = v0;
+          dx[row + (long)px * 64 + 32 + li] = v1;
         }
       }
     }
   }
-  float* out = part + (long)blockIdx.x * (T9 * 3 * 64 + 4);
+}
+
+// ---- weight gradient
+#define W9_TR 8
+#define W9_TC 64
+#define W9_HC (W9_TC + 8)
+#define W9_HS ((W9_TR + 8) * W9_HC)
+#define W9_PART (64 * 256 + 4)  // floats per workgroup: [ci][n = co * 81 + tap, 256 wide] + 3 bias sums
+__global__ __launch_bounds__(256) void conv9_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ part, int B, int H, int W, int tiles_w,
+                                                               int tiles_h, long ntiles) {
+  __shared__ float dyh[3 * W9_HS];
+  __shared__ float bred[3 * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kk = lane >> 5;
+  int nbase[2];
 #pragma unroll
-  for (int s = 0; s < W9_SLOTS; ++s) {
-    const int t = tg + 16 * s;
-    if (t < T9) {
+  for (int u = 0; u < 2; ++u) {
+    const int n = min((2 * wave + u) * 32 + li, 242);  // columns >= 243 are computed on a valid address and never stored
+    const int co = n / T9, tp = n - co * T9, kh = tp / 9, kw = tp - kh * 9;
+    nbase[u] = co * W9_HS + (8 - kh) * W9_HC + (8 - kw) + kk;
+  }
+  f32x16 acc[2][2];
 #pragma unroll
-      for (int co = 0; co < 3; ++co) *reinterpret_cast<f32x4*>(out + ((long)t * 3 + co) * 64 + c4 * 4) = acc[s][co];
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc[u][mt] = (f32x16){0};
+  float bs0 = 0.f, bs1 = 0.f, bs2 = 0.f;
+  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int tw = (int)(t % tiles_w);
+    const long rr = t / tiles_w;
+    const int th = (int)(rr % tiles_h), b = (int)(rr / tiles_h);
+    const int ty0 = th * W9_TR, tx0 = tw * W9_TC;
+    __syncthreads();
+    for (int i = tid; i < 3 * W9_HS; i += 256) {
+      const int co = i / W9_HS, rem = i - co * W9_HS, hr = rem / W9_HC, hc = rem - hr * W9_HC;
+      const int gy = ty0 - 4 + hr, gx = tx0 - 4 + hc;
+      const float v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? dy[(((long)b * 3 + co) * H + gy) * W + gx] : 0.f;
+      dyh[i] = v;
+      const bool own = hr >= 4 && hr < 4 + W9_TR && hc >= 4 && hc < 4 + W9_TC;  // the tile's own pixels: bias gradient
+      const float vo = own ? v : 0.f;
+      bs0 += co == 0 ? vo : 0.f;
+      bs1 += co == 1 ? vo : 0.f;
+      bs2 += co == 2 ? vo : 0.f;
+    }
+    __syncthreads();
+    const int rows = min(W9_TR, H - ty0);
+#pragma unroll 1
+    for (int py = 0; py < rows; ++py) {
+      const float* xrow = x + (((long)b * H + ty0 + py) * W) * 64 + li;
+#pragma unroll 1
+      for (int pxb = 0; pxb < W9_TC; pxb += 16) {
+        if (tx0 + pxb >= W) break;
+        float a[2][8], bq[2][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int gx = tx0 + pxb + 2 * q + kk;
+          const float* xa = xrow + (long)min(gx, W - 1) * 64;
+          const float a0 = xa[0], a1 = xa[32];
+          a[0][q] = gx < W ? a0 : 0.f;
+          a[1][q] = gx < W ? a1 : 0.f;
+          bq[0][q] = dyh[nbase[0] + py * W9_HC + pxb + 2 * q];
+          bq[1][q] = dyh[nbase[1] + py * W9_HC + pxb + 2 * q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+              acc[u][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][q], bq[u][q], acc[u][mt], 0, 0, 0);
+      }
     }
   }
-  if (threadIdx.x < 3) out[T9 * 3 * 64 + threadIdx.x] = bsum[threadIdx.x];  // every thread summed the same dy values
+  float* out = part + (long)blockIdx.x * W9_PART;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        out[ci * 256 + (2 * wave + u) * 32 + li] = acc[u][mt][r];
+      }
+  __syncthreads();
+  bred[tid] = bs0;
+  bred[256 + tid] = bs1;
+  bred[512 + tid] = bs2;
+  __syncthreads();
+  if (tid < 3) {
+    float sacc = 0.f;
+    for (int k = 0; k < 256; ++k) sacc += bred[tid * 256 + k];
+    out[64 * 256 + tid] = sacc;
+  }
 }
 
 __global__ __launch_bounds__(256) void conv9_wgrad_reduce_kernel(const float* __restrict__ part, int nparts,
                                                                  float* __restrict__ dw, float* __restrict__ db) {
-  const int stride = T9 * 3 * 64 + 4;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < T9 * 3 * 64) {
+  if (i < 64 * 243) {
+    const int ci = i / 243, n = i - ci * 243;
     float s = 0.f;
-    for (int k = 0; k < nparts; ++k) s += part[(long)k * stride + i];
-    const int ci = i & 63, co = (i >> 6) % 3, t = i / 192;
-    dw[((long)co * 64 + ci) * T9 + t] = s;
-  } else if (i < T9 * 3 * 64 + 3 && db) {
+    for (int k = 0; k < nparts; ++k) s += part[(long)k * W9_PART + ci * 256 + n];
+    const int co = n / T9, tp = n - co * T9;
+    dw[((long)co * 64 + ci) * T9 + tp] = s;
+  } else if (i < 64 * 243 + 3 && db) {
+    const int co = i - 64 * 243;
     float s = 0.f;
-    for (int k = 0; k < nparts; ++k) s += part[(long)k * stride + i];
-    db[i - T9 * 3 * 64] = s;
+    for (int k = 0; k < nparts; ++k) s += part[(long)k * W9_PART + 64 * 256 + co];
+    db[co] = s;
   }
 }
 
@@ -346,51 +461,73 @@ __global__ __launch_bounds__(256) void clamp01_kernel(const float* __restrict__ 
   }
 }
 
-#define CONV9_LDS (T9 * 16 * 12 * sizeof(float))  // 62 208 B
+
+static long conv9_fwd_tiles(int B, int H, int W, int* tiles_w) {
+  *tiles_w = (W + 23) / 24;
+  return (long)B * H * *tiles_w;
+}
 
 extern "C" int sisr_conv9_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
   if (!sisr_aligned16(x)) return SISR_ERR_ALIGN;
-  const long npix = (long)B * H * W;
-  long blocks = (npix + 15) / 16;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(conv9_fwd_kernel, dim3((unsigned)blocks), dim3(256), CONV9_LDS, (hipStream_t)stream, x, w, bias, y, B, H, W);
+  int tiles_w;
+  const long ntiles = conv9_fwd_tiles(B, H, W, &tiles_w);
+  long blocks = (ntiles + F9_WAVES - 1) / F9_WAVES;
+  if (blocks > 256) blocks = 256;  // one 8-wave workgroup per CU (107 KB of LDS)
+  const size_t lds = (F9_WZ + F9_WAVES * 32 * F9_ZLD) * sizeof(float);
+  static bool attr_set = false;  // idempotent, value never changes: raise the dynamic-LDS cap of this kernel once
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return SISR_ERR_UNSUPPORTED;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv9_fwd_mfma_kernel, dim3((unsigned)blocks), dim3(64 * F9_WAVES), lds, (hipStream_t)stream, x, w, bias, y,
+                     B, H, W, tiles_w, ntiles);
   return sisr_check_launch();
 }
 
 extern "C" int sisr_conv9_dgrad(const float* dy, const float* w, const float* leaky_mask, float* dx, int B, int H, int W,
                                 void* stream) {
   if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
-  if (!sisr_aligned16(dx) || !sisr_aligned16(leaky_mask)) return SISR_ERR_ALIGN;
-  const long npix = (long)B * H * W;
-  long blocks = (npix + 15) / 16;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(conv9_dgrad_kernel, dim3((unsigned)blocks), dim3(256), CONV9_LDS, (hipStream_t)stream, dy, w, leaky_mask,
-                     dx, B, H, W);
+  const int tiles_w = (W + 31) / 32, tiles_h = (H + D9_TR - 1) / D9_TR;
+  const long ntiles = (long)B * tiles_h * tiles_w;
+  const size_t lds = (D9_W2 + 4 + 3 * D9_HS) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_dgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return SISR_ERR_UNSUPPORTED;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv9_dgrad_mfma_kernel, dim3((unsigned)(ntiles < C9_GRID ? ntiles : C9_GRID)), dim3(256), lds,
+                     (hipStream_t)stream, dy, w, leaky_mask, dx, B, H, W, tiles_w, tiles_h, ntiles);
   return sisr_check_launch();
 }
 
-static int conv9_parts(long npix) {
-  long n = (npix + 2047) / 2048;  // >= 2048 pixels per block
-  if (n > 1024) n = 1024;
-  return (int)(n < 1 ? 1 : n);
+static long conv9_wgrad_tiles(int B, int H, int W, int* tiles_w, int* tiles_h) {
+  *tiles_w = (W + W9_TC - 1) / W9_TC;
+  *tiles_h = (H + W9_TR - 1) / W9_TR;
+  return (long)B * *tiles_h * *tiles_w;
 }
 extern "C" size_t sisr_conv9_wgrad_workspace_bytes(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  return (size_t)conv9_parts((long)B * H * W) * (T9 * 3 * 64 + 4) * sizeof(float);
+  int tw, th;
+  const long nt = conv9_wgrad_tiles(B, H, W, &tw, &th);
+  return (size_t)(nt < C9_GRID ? nt : C9_GRID) * W9_PART * sizeof(float);
 }
 extern "C" int sisr_conv9_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, size_t workspace_bytes,
                                 int B, int H, int W, void* stream) {
   if (!x || !dy || !dw || !workspace || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
   if (workspace_bytes < sisr_conv9_wgrad_workspace_bytes(B, H, W)) return SISR_ERR_ARG;
-  if (!sisr_aligned16(x) || !sisr_aligned16(workspace)) return SISR_ERR_ALIGN;
-  const long npix = (long)B * H * W;
-  const int parts = conv9_parts(npix);
-  const long span = (npix + parts - 1) / parts;
-  hipLaunchKernelGGL(conv9_wgrad_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, x, dy, workspace, B, H, W, span);
+  int tiles_w, tiles_h;
+  const long ntiles = conv9_wgrad_tiles(B, H, W, &tiles_w, &tiles_h);
+  const int parts = (int)(ntiles < C9_GRID ? ntiles : C9_GRID);
+  hipLaunchKernelGGL(conv9_wgrad_mfma_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, x, dy, workspace, B, H, W, tiles_w,
+                     tiles_h, ntiles);
   int rc = sisr_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(conv9_wgrad_reduce_kernel, dim3((T9 * 3 * 64 + 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace,
+  hipLaunchKernelGGL(conv9_wgrad_reduce_kernel, dim3((64 * 243 + 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace,
                      parts, dw, db);
   return sisr_check_launch();
 }

@@ -99,7 +99,7 @@ _SIGS.update({  # on-the-fly degradation (csrc/degrade.hip)
     "sisr_pil_resample": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
 })
 _SIGS.update({  # SFTMD pieces (csrc/sft.hip)
-    "sisr_compose_oihw2": (c_int, [P, P, P] + [c_int] * 12 + [P]),
+    "sisr_sft_compose": (c_int, [P] * 12 + [c_int, c_int, P]),
     "sisr_sft_combine_fwd": (c_int, [P, c_long, P, P, P, c_long, c_long, c_int, P]),
     "sisr_sft_combine_bwd": (c_int, [P, c_long, P, c_long, P, P, P, c_long, c_int, P]),
     "sisr_map64": (c_int, [P, c_long, P, c_long, P, c_long, c_long, c_int, P]),

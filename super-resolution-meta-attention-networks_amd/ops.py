@@ -1222,9 +1222,10 @@ def _fp32_only(what):
         raise NotImplementedError(f"{what} runs on the fp32 kernels only (SISR_PRECISION={PRECISION})")
 
 
-def _compose2(a, b, dst, cop, cip, taps, oa0, ia0, coa, cia, ob0, ib0, cob, cib, split=0):
-    hip.check(hip.lib().sisr_compose_oihw2(hip.ptr(a), hip.ptr(b), hip.ptr(dst), cop, cip, taps, oa0, ia0, coa, cia, ob0,
-                                           ib0, cob, cib, int(split), hip.stream()), "sisr_compose_oihw2")
+def _sft_compose(params, merged, M, split=0):
+    """params: the eight parameter (or gradient) tensors of a StandardSft; merged: (WA, bA, WB, bB)."""
+    hip.check(hip.lib().sisr_sft_compose(*[hip.ptr_c(t) for t in params], *[hip.ptr(t) for t in merged], int(M), int(split),
+                                         hip.stream()), "sisr_sft_compose")
 
 
 def _map64(a, a_stride, b, b_stride, out, out_stride, npix, op, a_off=0, out_off=0):
@@ -1256,10 +1257,7 @@ class _SftLayer(Function):
         bA = torch.empty(64, device=dev)
         WB = torch.empty((128, 64, 3, 3), device=dev)
         bB = torch.empty(128, device=dev)
-        _compose2(mw1.contiguous(), aw1.contiguous(), WA, 64, 128, 9, 0, 0, 32, 64 + M, 32, 0, 32, 64 + M)
-        _compose2(mb1, ab1, bA, 64, 1, 1, 0, 0, 32, 1, 32, 0, 32, 1)
-        _compose2(mw2.contiguous(), aw2.contiguous(), WB, 128, 64, 9, 0, 0, 64, 32, 64, 32, 64, 32)
-        _compose2(mb2, ab2, bB, 128, 1, 1, 0, 0, 64, 1, 64, 0, 64, 1)
+        _sft_compose((mw1, mb1, aw1, ab1, mw2, mb2, aw2, ab2), (WA, bA, WB, bB), M)
         pfA, pdA = pack_pair(WA)
         pfB, pdB = pack_pair(WB)
         t = _empty_cl(B, 64, H, W, dev)
@@ -1304,10 +1302,7 @@ class _SftLayer(Function):
                 conv_c64(dt, v64, pdA, None, (1, 64), dx, v64, B, H, W, 64, 64, res=dx0)
             g = [torch.empty(s, device=dev) for s in ((32, 64 + M, 3, 3), (32,), (32, 64 + M, 3, 3), (32,), (64, 32, 3, 3),
                                                       (64,), (64, 32, 3, 3), (64,))]
-            _compose2(g[0], g[2], dWA, 64, 128, 9, 0, 0, 32, 64 + M, 32, 0, 32, 64 + M, split=1)
-            _compose2(g[1], g[3], dbA, 64, 1, 1, 0, 0, 32, 1, 32, 0, 32, 1, split=1)
-            _compose2(g[4], g[6], dWB, 128, 64, 9, 0, 0, 64, 32, 64, 32, 64, 32, split=1)
-            _compose2(g[5], g[7], dbB, 128, 1, 1, 0, 0, 64, 1, 64, 0, 64, 1, split=1)
+            _sft_compose(g, (dWA, dbA, dWB, dbB), M, split=1)
             return (dx, None, None, None, *g)
         finally:
             IN_BACKWARD = False

@@ -12,7 +12,7 @@ Reference configuration covered: SFT_type 'standard', no q / da injection, mask_
     that produces the features writes chunk 0 in place (pixel stride 128), chunk 1 is filled by the combine kernel.
   * An SFT layer's four convs run as two MFMA convs: A = [mul_conv1 | add_conv1] merged along the outputs
     (128 -> 64, LeakyReLU 0.2 in the epilogue), B = block-diagonal [mul_conv2, add_conv2] (64 -> 128); the merged /
-    block-diagonal weights are composed per step from the four parameters (`sisr_compose_oihw2`) and their gradients
+    block-diagonal weights are composed per step from the four parameters (`sisr_sft_compose`) and their gradients
     split back.  Then one combine kernel: out = [relu](x * sigmoid(B[:64]) + B[64:]).
   * LeakyReLU is a conv epilogue (and a slope in the ReLU-mask epilogue of the input-gradient conv); the 9x9 64 -> 3 output
     conv, its two gradients and the clamp are their own kernels (csrc/sft.hip).

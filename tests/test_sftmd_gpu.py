@@ -24,9 +24,10 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("shape", [(1, 7, 9), (2, 16, 33), (1, 40, 70)])
+@pytest.mark.parametrize("shape", [(1, 7, 9), (2, 16, 33), (1, 40, 70), (1, 3, 100), (2, 264, 530)])
 def test_conv9_forward_and_gradients(shape):
-    """9x9 64 -> 3 conv + clamp (ref: SFTMD.conv_output, :159): ragged sizes smaller and larger than the 9-tap window."""
+    """9x9 64 -> 3 conv + clamp (ref: SFTMD.conv_output, :159): ragged sizes smaller and larger than the 9-tap window and
+    the kernels' tiles (24 / 32 / 64 columns, 8 rows); the last one has more tiles than the persistent grids have workgroups."""
     B, H, W = shape
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, 64, H, W, generator=g)
@@ -43,18 +44,18 @@ def test_conv9_forward_and_gradients(shape):
     hip.check(L.sisr_conv9_fwd(hip.ptr(xa), hip.ptr(wc), hip.ptr(bc), hip.ptr(pre), B, H, W, hip.stream()), "conv9")
     out = torch.empty_like(pre)
     hip.check(L.sisr_clamp01(hip.ptr(pre), None, hip.ptr(out), pre.numel(), 0, hip.stream()), "clamp")
-    np.testing.assert_allclose(out.cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(out.cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-5)  # 5184-term fp32 sums, |pre| ~ 1
     dpre = torch.empty_like(pre)
     hip.check(L.sisr_clamp01(hip.ptr(pre), hip.ptr(cot.cuda()), hip.ptr(dpre), pre.numel(), 1, hip.stream()), "clamp bwd")
     dx = torch.empty(B, 64, H, W, device=dev).contiguous(memory_format=torch.channels_last)
     hip.check(L.sisr_conv9_dgrad(hip.ptr(dpre), hip.ptr(wc), hip.ptr(xa), hip.ptr(dx), B, H, W, hip.stream()), "conv9 dgrad")
-    assert rel(dx, xr.grad) < 2e-6
+    assert rel(dx, xr.grad) < 3e-6
     dw, db = torch.empty_like(wc), torch.empty(3, device=dev)
     nbytes = L.sisr_conv9_wgrad_workspace_bytes(B, H, W)
     ws = hip.workspace(dev, nbytes)
     hip.check(L.sisr_conv9_wgrad(hip.ptr(xa), hip.ptr(dpre), hip.ptr(dw), hip.ptr(db), hip.ptr(ws), nbytes, B, H, W,
                                  hip.stream()), "conv9 wgrad")
-    assert rel(dw, w.grad) < 2e-6 and rel(db, b.grad) < 2e-6
+    assert rel(dw, w.grad) < 1e-5 and rel(db, b.grad) < 1e-5
 
 
 @pytest.mark.parametrize("relu", [False, True])
