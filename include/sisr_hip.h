@@ -308,6 +308,12 @@ int sisr_pad_oihw(const float* src, float* dst, int cout, int cin, int cout_padd
                   void* stream);
 int sisr_shuffle_rgb(const float* src, float* dst, int B, int C, int r, int H, int W, int C_padded, int adjoint,
                      void* stream);
+/* HAN's map stack (ref: advanced/architectures.py:357-362 torch.cat of the 11 intermediate maps): map [B][hw][64] -> slot k
+ * of stack [B][N][hw][64] (unstack != 0: the reverse, for the stack's gradient). */
+int sisr_stack_maps(const float* src, float* dst, int B, long hw, int N, int k, int unstack, void* stream);
+/* nn.PixelShuffle(r) on a channels-last map (ref: advanced/common.py:20-45; C = 64 upsamplers fuse it into the conv's store):
+ * src [B][H][W][C r^2] -> dst [B][rH][rW][C]; adjoint != 0: dst [B][H][W][C r^2] <- src [B][rH][rW][C]. */
+int sisr_pixel_shuffle_cl(const float* src, float* dst, int B, int H, int W, int C, int r, int adjoint, void* stream);
 
 /* ---- on-the-fly LR synthesis (online_degradations) -----------------------------------------------------------
  * ref: sr_tools/gaussian_utils.py:346-368 BatchBlur (reflection pad + per-channel l x l correlation), :52-53
@@ -348,6 +354,29 @@ size_t sisr_conv9_wgrad_workspace_bytes(int B, int H, int W);
 int sisr_conv9_wgrad(const float* x, const float* dy, float* dw, float* db, float* workspace, size_t workspace_bytes, int B,
                      int H, int W, void* stream);
 int sisr_clamp01(const float* a, const float* grad, float* out, long n, int backward, void* stream);
+
+/* ---- around the non-local attention: 1x1 projections, pooling, output projection (csrc/nonlocal.hip) ---------------
+ * ref: advanced/SAN_blocks.py:104-148 (theta / phi / g = Conv2d(64, 8, 1), phi and g through MaxPool2d(2), W = Conv2d(8, 64, 1),
+ * z = W(y) + x), :305-336 (the block applied per quadrant).  x, z, dz, dx: channels-last [npix][64]; proj, dproj:
+ * [npix][24] (theta | phi | g).  `domains`: 9 ints in host memory B, H, W, y0, x0, hq, wq, nqy, nqx = B * nqy * nqx
+ * rectangles of hq x wq positions starting at (y0, x0); domain index (b * nqy + iy) * nqx + ix, rows
+ * [domain][position][8], pooled rows [domain][(hq / 2) * (wq / 2)][8] (floor mode).
+ * sisr_nl_project_bwd: dx = dproj . Wp + dz, and part[sisr_nl_project_bwd_parts(npix)][33][64] ordered partial sums
+ *   (rows 0..23 = d(theta | phi | g weight)[n][c], row 32 = the 24 bias gradients): sum with sisr_sum_partials.
+ * sisr_nl_output_bwd: dy rows, and part[sisr_nl_output_bwd_parts(domains)][64 * 8 + 64] (dW [64][8], then db [64]). */
+int sisr_nl_project_fwd(const float* x, const float* w_theta, const float* b_theta, const float* w_phi, const float* b_phi,
+                        const float* w_g, const float* b_g, float* proj, long npix, void* stream);
+int sisr_nl_project_bwd_parts(long npix);
+int sisr_nl_project_bwd(const float* x, const float* dproj, const float* dz, const float* w_theta, const float* w_phi,
+                        const float* w_g, float* dx, float* part, long npix, void* stream);
+int sisr_nl_split_pool_fwd(const float* proj, float* theta, float* phi, float* g, const int* domains, void* stream);
+int sisr_nl_split_pool_bwd(const float* proj, const float* dtheta, const float* dphi, const float* dg, float* dproj,
+                           const int* domains, void* stream);
+int sisr_nl_output_fwd(const float* y, const float* x, const float* w, const float* bias, float* z, const int* domains,
+                       void* stream);
+int sisr_nl_output_bwd_parts(const int* domains);
+int sisr_nl_output_bwd(const float* dz, const float* y, const float* w, float* dy, float* part, const int* domains,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,6 @@ ref files: Code/SISR/models/advanced/{common,architectures}.py,
 import math
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import ops
@@ -79,7 +78,7 @@ def meta_gates(layers, attributes):
 class Upsampler(nn.Sequential):
     """ref: advanced/common.py:20-45.  conv(C -> r^2 C) + PixelShuffle(r); for n_feat = 64 the shuffle is fused
     into the conv's store (an address map) and the nn.PixelShuffle children only keep the module indices; wider
-    nets (EDSR 256) run the conv to a plain channels-last map and shuffle with torch (two launches of 34)."""
+    nets (EDSR 256) run the conv to a plain channels-last map and shuffle it with one gather kernel (ops.pixel_shuffle)."""
 
     def __init__(self, conv, scale, n_feat, bn=False, act=False, bias=True):
         if bn or act:
@@ -103,7 +102,7 @@ class Upsampler(nn.Sequential):
             if mods[i].weight.shape[0] == 64 * r * r:
                 x = _conv(mods[i], x, shuffle=r)
             else:
-                x = F.pixel_shuffle(_conv(mods[i], x), r)
+                x = ops.pixel_shuffle(_conv(mods[i], x), r)
         return x
 
 

@@ -239,3 +239,55 @@ extern "C" int sisr_shuffle_rgb(const float* src, float* dst, int B, int C, int 
                      Cp, total, adjoint);
   return sisr_check_launch();
 }
+
+// ------------------------------------------------------------------ map stacks (HAN: ref advanced/architectures.py:357-362)
+// The reference concatenates the 11 intermediate maps along channels; here they sit in one [B][N][hw][64] stack that LAM and
+// the 704 -> 64 conv read as chunks.  unstack == 0: map [B][hw][64] -> slot k of the stack; else the reverse (gradients).
+__global__ __launch_bounds__(256) void stack_maps_kernel(const float* __restrict__ src, float* __restrict__ dst, long hw16,
+                                                         int N, int k, long total, int unstack) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / hw16, r = i - b * hw16;
+    const long s = (b * N + k) * hw16 + r;
+    if (!unstack) reinterpret_cast<f32x4*>(dst)[s] = reinterpret_cast<const f32x4*>(src)[i];
+    else reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[s];
+  }
+}
+
+extern "C" int sisr_stack_maps(const float* src, float* dst, int B, long hw, int N, int k, int unstack, void* stream) {
+  if (!src || !dst || B <= 0 || hw <= 0 || N <= 0 || k < 0 || k >= N) return SISR_ERR_ARG;
+  if (!sisr_aligned16(src) || !sisr_aligned16(dst)) return SISR_ERR_ALIGN;
+  const long total = (long)B * hw * 16;
+  hipLaunchKernelGGL(stack_maps_kernel, dim3(misc_blocks(total)), dim3(256), 0, (hipStream_t)stream, src, dst, hw * 16, N, k, total,
+                     unstack);
+  return sisr_check_launch();
+}
+
+// ------------------------------------------------------------------ PixelShuffle on channels-last maps (wide upsamplers)
+// ref: advanced/common.py:20-45 Upsampler = conv(C -> r^2 C) + nn.PixelShuffle(r).  For C = 64 the shuffle is the conv's store
+// address map (View, sisr_common.h); wider maps (EDSR-256) come here: in [B][H][W][C r^2] -> out [B][rH][rW][C],
+// out[b][r h + dy][r w + dx][c] = in[b][h][w][c r^2 + dy r + dx]; adjoint != 0: the inverse gather (the gradient).
+__global__ __launch_bounds__(256) void pixel_shuffle_cl_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                                               int C, int r, long total, int adjoint) {
+  const int rr = r * r;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    // i indexes the shuffled tensor [B][rH][rW][C]
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int ow = (int)(t % ((long)r * W));
+    t /= (long)r * W;
+    const int oh = (int)(t % ((long)r * H));
+    const long b = t / ((long)r * H);
+    const int h = oh / r, dy = oh - h * r, w = ow / r, dx = ow - w * r;
+    const long j = (((b * H + h) * W + w) * C + c) * rr + dy * r + dx;
+    if (!adjoint) dst[i] = src[j];
+    else dst[j] = src[i];
+  }
+}
+
+extern "C" int sisr_pixel_shuffle_cl(const float* src, float* dst, int B, int H, int W, int C, int r, int adjoint, void* stream) {
+  if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || r < 1) return SISR_ERR_ARG;
+  const long total = (long)B * H * W * C * r * r;
+  hipLaunchKernelGGL(pixel_shuffle_cl_kernel, dim3(misc_blocks(total)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, C, r, total,
+                     adjoint);
+  return sisr_check_launch();
+}

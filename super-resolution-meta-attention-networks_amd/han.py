@@ -6,8 +6,8 @@ ref: Code/SISR/models/advanced/HAN_blocks.py (LAM_Module, CSAM_Module),
      handlers: advanced/handlers.py:42-55, attention_manipulators/handlers.py:156-171.
 
 The reference collects the 11 intermediate maps newest-first with torch.cat and concatenates CSAM / LAM
-branches along channels.  Here the maps are stacked once as [B][N][H][W][64] (a cheap gather of
-channels-last maps) and every consumer -- the LAM kernels and the 704->64 / 128->64 convolutions -- reads
+branches along channels.  Here the maps are copied once into a [B][N][H][W][64] stack (ops.stack_maps, a
+HIP gather of channels-last maps) and every consumer -- the LAM kernels and the 704->64 / 128->64 convolutions -- reads
 the stack as 64-channel chunks, so no channel concatenation is materialised.
 """
 import torch
@@ -16,11 +16,6 @@ from torch import nn
 from . import architectures as A
 from . import ops
 from .handlers import BaseModel, QModel
-
-
-def _stack_maps(maps):
-    """list of N (B,64,H,W) channels_last maps -> [B][N][H][W][64] tensor."""
-    return torch.stack([m.permute(0, 2, 3, 1) for m in maps], dim=1).contiguous()
 
 
 class LAM_Module(nn.Module):
@@ -57,10 +52,10 @@ class CSAM_Module(nn.Module):
 
 def _han_tail(net, x_head, maps):
     """Shared HAN/QHAN epilogue; ``maps`` oldest-first (group outputs + post-body conv)."""
-    stack = _stack_maps(maps[::-1])                       # newest first (ref :359-362)
+    stack = ops.stack_maps(maps[::-1])                    # newest first (ref :359-362)
     out2 = ops.conv3x3_stack(net.la.forward_stack(stack), net.last_conv.weight, net.last_conv.bias)
     out1 = net.csa(maps[-1])
-    pair = _stack_maps([out1, out2])                      # torch.cat([out1, out2], 1) as two chunks
+    pair = ops.stack_maps([out1, out2])                   # torch.cat([out1, out2], 1) as two chunks
     res = ops.conv3x3_stack(pair, net.last.weight, net.last.bias, residual=x_head)  # + x fused into the conv's store
     return A._conv(net.tail[1], net.tail[0](res))
 

@@ -85,6 +85,8 @@ _SIGS.update({  # channel padding / RGB shuffle for the SRMD widening (csrc/misc
     "sisr_nchw_to_nhwc_pad": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_pad_oihw": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_shuffle_rgb": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sisr_stack_maps": (c_int, [P, P, c_int, c_long, c_int, c_int, c_int, P]),
+    "sisr_pixel_shuffle_cl": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
 })
 _SIGS.update({  # fp32 through the bf16 matrix cores: three-way operand split, six products (csrc/conv3x3_mfma.hip)
     "sisr_pack_conv3x3_x3_both": (c_int, [P, P, P, c_int, c_int, c_int, P]),
@@ -97,6 +99,16 @@ _SIGS.update({  # fp32 through the bf16 matrix cores: three-way operand split, s
 _SIGS.update({  # on-the-fly degradation (csrc/degrade.hip)
     "sisr_blur_quant": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "sisr_pil_resample": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+})
+_SIGS.update({  # around the non-local attention (csrc/nonlocal.hip)
+    "sisr_nl_project_fwd": (c_int, [P] * 8 + [c_long, P]),
+    "sisr_nl_project_bwd_parts": (c_int, [c_long]),
+    "sisr_nl_project_bwd": (c_int, [P] * 8 + [c_long, P]),
+    "sisr_nl_split_pool_fwd": (c_int, [P, P, P, P, P, P]),
+    "sisr_nl_split_pool_bwd": (c_int, [P, P, P, P, P, P, P]),
+    "sisr_nl_output_fwd": (c_int, [P, P, P, P, P, P, P]),
+    "sisr_nl_output_bwd_parts": (c_int, [P]),
+    "sisr_nl_output_bwd": (c_int, [P, P, P, P, P, P, P]),
 })
 _SIGS.update({  # SFTMD pieces (csrc/sft.hip)
     "sisr_sft_compose": (c_int, [P] * 12 + [c_int, c_int, P]),

@@ -1756,6 +1756,70 @@ def csam(x, w, b, gamma):
     return _CSAM.apply(x, w, b, gamma)
 
 
+class _PixelShuffleCL(Function):
+    """nn.PixelShuffle(r) of a channels-last map as one gather (upsamplers wider than 64 channels; ref: advanced/common.py:20-45)."""
+
+    @staticmethod
+    def forward(ctx, x, r):
+        B, Crr, H, W = x.shape
+        C = Crr // (r * r)
+        if C * r * r != Crr:
+            raise RuntimeError(f"PixelShuffle({r}) needs a channel count divisible by {r * r}; got {Crr}")
+        y = _empty_cl(B, C, H * r, W * r, x.device)
+        hip.check(hip.lib().sisr_pixel_shuffle_cl(hip.ptr(_cl(x)), hip.ptr(y), B, H, W, C, r, 0, hip.stream()),
+                  "sisr_pixel_shuffle_cl")
+        ctx.geo = (B, C, H, W, r)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, r = ctx.geo
+        dx = _empty_cl(B, C * r * r, H, W, dy.device)
+        hip.check(hip.lib().sisr_pixel_shuffle_cl(hip.ptr(_cl(dy)), hip.ptr(dx), B, H, W, C, r, 1, hip.stream()),
+                  "sisr_pixel_shuffle_cl(adjoint)")
+        return dx, None
+
+
+def pixel_shuffle(x, r):
+    return _PixelShuffleCL.apply(x, int(r))
+
+
+class _StackMaps(Function):
+    """N channels-last (B, 64, H, W) maps -> the [B][N][H][W][64] stack LAM and the stack convs read as chunks (ref:
+    advanced/architectures.py:357-362, the torch.cat of HAN's intermediate maps); backward hands every map its slot."""
+
+    @staticmethod
+    def forward(ctx, *maps):
+        B, C, H, W = maps[0].shape
+        if C != 64:
+            raise NotImplementedError("map stacks hold 64-channel maps")
+        N = len(maps)
+        stack = torch.empty((B, N, H, W, 64), device=maps[0].device, dtype=torch.float32)
+        for k, m in enumerate(maps):
+            hip.check(hip.lib().sisr_stack_maps(hip.ptr(_cl(m)), hip.ptr(stack), B, H * W, N, k, 0, hip.stream()),
+                      "sisr_stack_maps")
+        return stack
+
+    @staticmethod
+    def backward(ctx, dstack):
+        B, N, H, W, _ = dstack.shape
+        dstack = dstack.contiguous()
+        out = []
+        for k in range(N):
+            if not ctx.needs_input_grad[k]:
+                out.append(None)
+                continue
+            g = _empty_cl(B, 64, H, W, dstack.device)
+            hip.check(hip.lib().sisr_stack_maps(hip.ptr(dstack), hip.ptr(g), B, H * W, N, k, 1, hip.stream()),
+                      "sisr_stack_maps(unstack)")
+            out.append(g)
+        return tuple(out)
+
+
+def stack_maps(maps):
+    return _StackMaps.apply(*maps)
+
+
 class _ConvStack(Function):
     """3x3 conv 64*N -> 64 reading a [B][N][H][W][64] map stack as N channel chunks (HAN last_conv /
     last, ref: advanced/architectures.py:349-350,366-371) -- torch.cat is never materialised."""
@@ -1937,6 +2001,105 @@ class _NonLocalAttention(Function):
 
 def nonlocal_attention(theta, phi, g):
     return _NonLocalAttention.apply(theta, phi, g)
+
+
+def _nl_domain_groups(B, H, W, quadrants):
+    """Attention domains of a map as groups of equal rectangles (sisr_nl_* `domains` arrays): the whole map, or the four
+    quadrants (ref: advanced/SAN_blocks.py:316-334: H // 2, W // 2 split) -- one group when they are equal."""
+    import ctypes
+    mk = lambda *v: (ctypes.c_int * 9)(*v)  # noqa: E731
+    if not quadrants:
+        return [(mk(B, H, W, 0, 0, H, W, 1, 1), B, H, W)]
+    h1, w1 = H // 2, W // 2
+    if H % 2 == 0 and W % 2 == 0:
+        return [(mk(B, H, W, 0, 0, h1, w1, 2, 2), 4 * B, h1, w1)]
+    return [(mk(B, H, W, y0, x0, hq, wq, 1, 1), B, hq, wq)
+            for y0, hq in ((0, h1), (h1, H - h1)) for x0, wq in ((0, w1), (w1, W - w1))]
+
+
+class _NonLocalBlock(Function):
+    """z = W(softmax(theta(x)^T phi(x)) g(x)) + x with phi / g max-pooled 2x2, per attention domain (ref:
+    advanced/SAN_blocks.py:104-148, :305-336).  Projections 64 -> 24 and their two gradients on the fp32 matrix cores,
+    split / pool / scatter and the 8 -> 64 output projection as streaming kernels (csrc/nonlocal.hip), the attention itself
+    csrc/san.hip; nothing here is a library call."""
+
+    @staticmethod
+    def forward(ctx, x, quadrants, wt, bt, wp, bp, wg, bg, ww, bw):
+        B, C, H, W = x.shape
+        if C != 64 or wt.shape[0] != 8 or ww.shape[0] != 64:
+            raise NotImplementedError("non-local block kernels: 64 channels, 8 embedding channels (SAN's configuration)")
+        L, dev, npix = hip.lib(), x.device, B * H * W
+        x = _cl(x)
+        wt, wp, wg, ww = (t.reshape(t.shape[0], -1).contiguous() for t in (wt, wp, wg, ww))
+        proj = torch.empty((npix, 24), device=dev)
+        hip.check(L.sisr_nl_project_fwd(hip.ptr(x), hip.ptr(wt), hip.ptr_c(bt), hip.ptr(wp), hip.ptr_c(bp), hip.ptr(wg),
+                                        hip.ptr_c(bg), hip.ptr(proj), npix, hip.stream()), "sisr_nl_project_fwd")
+        z = _empty_cl(B, 64, H, W, dev)
+        saved = []
+        for dom, nd, hq, wq in _nl_domain_groups(B, H, W, quadrants):
+            if hq < 2 or wq < 2:
+                raise RuntimeError("non-local block needs at least 2x2 positions per attention domain (MaxPool2d(2))")
+            nq, nk = hq * wq, (hq // 2) * (wq // 2)
+            theta = torch.empty((nd, nq, 8), device=dev)
+            phi, g = torch.empty((nd, nk, 8), device=dev), torch.empty((nd, nk, 8), device=dev)
+            hip.check(L.sisr_nl_split_pool_fwd(hip.ptr(proj), hip.ptr(theta), hip.ptr(phi), hip.ptr(g), dom, hip.stream()),
+                      "sisr_nl_split_pool_fwd")
+            y = torch.empty_like(theta)
+            lse = torch.empty((nd, nq), device=dev)
+            hip.check(L.sisr_nl_attn_fwd(hip.ptr(theta), hip.ptr(phi), hip.ptr(g), hip.ptr(y), hip.ptr(lse), nd, nq, nk, 8,
+                                         hip.stream()), "sisr_nl_attn_fwd")
+            hip.check(L.sisr_nl_output_fwd(hip.ptr(y), hip.ptr(x), hip.ptr(ww), hip.ptr_c(bw), hip.ptr(z), dom, hip.stream()),
+                      "sisr_nl_output_fwd")
+            saved += [theta, phi, g, y, lse]
+        ctx.save_for_backward(x, proj, wt, wp, wg, ww, *saved)
+        ctx.cfg = (B, H, W, bool(quadrants))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        B, H, W, quadrants = ctx.cfg
+        x, proj, wt, wp, wg, ww, *saved = ctx.saved_tensors
+        L, dev, npix = hip.lib(), x.device, B * H * W
+        dz = _cl(dz)
+        groups = _nl_domain_groups(B, H, W, quadrants)
+        oparts = [L.sisr_nl_output_bwd_parts(dom) for dom, _, _, _ in groups]
+        opart = torch.empty((sum(oparts), 64 * 8 + 64), device=dev)
+        dproj = torch.empty((npix, 24), device=dev)
+        row = 0
+        for k, (dom, nd, hq, wq) in enumerate(groups):
+            theta, phi, g, y, lse = saved[5 * k:5 * k + 5]
+            nq, nk = hq * wq, (hq // 2) * (wq // 2)
+            dy = torch.empty_like(y)
+            hip.check(L.sisr_nl_output_bwd(hip.ptr(dz), hip.ptr(y), hip.ptr(ww), hip.ptr(dy), hip.ptr(opart[row:]), dom,
+                                           hip.stream()), "sisr_nl_output_bwd")
+            row += oparts[k]
+            dtheta, dphi, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
+            dsum = torch.empty_like(lse)
+            hip.check(L.sisr_nl_attn_bwd(hip.ptr(theta), hip.ptr(phi), hip.ptr(g), hip.ptr(y), hip.ptr(lse), hip.ptr(dy),
+                                         hip.ptr(dtheta), hip.ptr(dphi), hip.ptr(dg), hip.ptr(dsum), nd, nq, nk, 8,
+                                         hip.stream()), "sisr_nl_attn_bwd")
+            hip.check(L.sisr_nl_split_pool_bwd(hip.ptr(proj), hip.ptr(dtheta), hip.ptr(dphi), hip.ptr(dg), hip.ptr(dproj), dom,
+                                               hip.stream()), "sisr_nl_split_pool_bwd")
+        out_g = torch.empty(64 * 8 + 64, device=dev)
+        hip.check(L.sisr_sum_partials(hip.ptr(opart), opart.shape[0], 1, 64 * 8 + 64, 1.0, hip.ptr(out_g), hip.stream()),
+                  "sisr_sum_partials")
+        pparts = L.sisr_nl_project_bwd_parts(npix)
+        ppart = torch.empty((pparts, 33 * 64), device=dev)
+        dx = _empty_cl(B, 64, H, W, dev)
+        hip.check(L.sisr_nl_project_bwd(hip.ptr(x), hip.ptr(dproj), hip.ptr(dz), hip.ptr(wt), hip.ptr(wp), hip.ptr(wg),
+                                        hip.ptr(dx), hip.ptr(ppart), npix, hip.stream()), "sisr_nl_project_bwd")
+        pg = torch.empty(33 * 64, device=dev)
+        hip.check(L.sisr_sum_partials(hip.ptr(ppart), pparts, 1, 33 * 64, 1.0, hip.ptr(pg), hip.stream()), "sisr_sum_partials")
+        pg = pg.view(33, 64)
+        dw = [pg[8 * i:8 * i + 8].reshape(8, 64, 1, 1) for i in range(3)]
+        db = [pg[32, 8 * i:8 * i + 8] for i in range(3)]
+        return (dx, None, dw[0], db[0], dw[1], db[1], dw[2], db[2], out_g[:512].view(64, 8, 1, 1), out_g[512:])
+
+
+def nonlocal_block(x, block, quadrants):
+    """block: san.NONLocalBlock2D (parameter holder)."""
+    return _NonLocalBlock.apply(x, bool(quadrants), block.theta.weight, block.theta.bias, block.phi[0].weight,
+                                block.phi[0].bias, block.g[0].weight, block.g[0].bias, block.W.weight, block.W.bias)
 
 
 class _ScaleAdd(Function):

@@ -8,10 +8,11 @@ ref: Code/SISR/models/advanced/SAN_blocks.py (NONLocalBlock2D, SOCA, Nonlocal_CA
      handlers + forward_chop: advanced/handlers.py:58-128, attention_manipulators/handlers.py:79-148.
 
 Work split: the RB / QRB residual blocks and every 3x3 conv run on the same fused MFMA operators as RCAN
-(> 97 % of the FLOPs); SOCA and the non-local attention have their own kernels (csrc/san.hip).  The four 1x1
-projections of the non-local block are plain dense GEMMs over the channels-last map ([B*H*W, 64] x [64, 24]
-and [B*H*W, 8] x [8, 64]) and go to the library GEMM (torch.addmm -> rocBLAS); the 2x2 max-pool of the
-8-channel phi / g maps is torch's.
+(> 97 % of the FLOPs); SOCA and the non-local attention have their own kernels (csrc/san.hip).  The projections
+around the attention are hand-written too (csrc/nonlocal.hip, ops.nonlocal_block): theta | phi | g as one
+[B*H*W, 64] x [64, 24] GEMM on the fp32 matrix cores with both of its gradients, the 2x2 max-pool of phi / g fused
+into the gather that lays out the attention rows per quadrant, and the 8 -> 64 output projection + skip as a
+streaming kernel.  No library GEMM or torch pooling is left on this path.
 
 Quirks of the reference that are kept because checkpoints and results depend on them:
   * NONLocalBlock2D rebinds its `sub_sample` argument to the nn.Upsample class (SAN_blocks.py:40), so phi and g
@@ -23,7 +24,6 @@ Quirks of the reference that are kept because checkpoints and results depend on 
 import time
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import architectures as A
@@ -64,58 +64,9 @@ class NONLocalBlock2D(nn.Module):
         self.theta = nn.Conv2d(in_channels, self.inter_channels, 1)
         self.phi = nn.Sequential(nn.Conv2d(in_channels, self.inter_channels, 1), nn.MaxPool2d(kernel_size=2))
 
-    def projection(self):
-        """[3*ci, C] weight and [3*ci] bias of the stacked theta | phi | g projections."""
-        ci, c = self.inter_channels, self.in_channels
-        w = torch.cat([self.theta.weight.reshape(ci, c), self.phi[0].weight.reshape(ci, c),
-                       self.g[0].weight.reshape(ci, c)], dim=0)
-        b = torch.cat([self.theta.bias, self.phi[0].bias, self.g[0].bias])
-        return w, b
-
     def forward(self, x):
         """Whole map as one attention domain (Nonlocal_CA applies the block per quadrant instead)."""
-        return _nonlocal(self, x, quadrants=False)
-
-
-def _nonlocal(block, x, quadrants):
-    B, C, H, W = x.shape
-    ci = block.inter_channels
-    if ci != 8:
-        raise NotImplementedError("non-local attention kernel is specialised for 8 embedding channels (n_feats 64)")
-    rows = ops._cl(x).permute(0, 2, 3, 1)                          # [B][H][W][C] view of the channels-last map
-    w, b = block.projection()
-    proj = torch.addmm(b, rows.reshape(-1, C), w.t()).view(B, H, W, 3 * ci)
-    if quadrants:
-        h1, w1 = H // 2, W // 2
-        cuts = [(slice(0, h1), slice(0, w1)), (slice(0, h1), slice(w1, W)),
-                (slice(h1, H), slice(0, w1)), (slice(h1, H), slice(w1, W))]
-    else:
-        cuts = [(slice(0, H), slice(0, W))]
-    if quadrants and H % 2 == 0 and W % 2 == 0:
-        # equal quadrants: fold them into the batch dimension, one attention launch
-        q = proj.view(B, 2, H // 2, 2, W // 2, 3 * ci).permute(0, 1, 3, 2, 4, 5).reshape(B * 4, H // 2, W // 2, 3 * ci)
-        y = _attend(q, ci).view(B, 2, 2, H // 2, W // 2, ci).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, ci)
-    else:
-        parts = [_attend(proj[:, hs, ws], ci) for hs, ws in cuts]
-        if quadrants:
-            y = torch.cat([torch.cat(parts[0:2], dim=2), torch.cat(parts[2:4], dim=2)], dim=1)
-        else:
-            y = parts[0]
-    z = torch.addmm(block.W.bias, y.reshape(-1, ci), block.W.weight.reshape(C, ci).t()).view(B, H, W, C) + rows
-    return z.permute(0, 3, 1, 2)                                   # logical NCHW, channels-last memory
-
-
-def _attend(proj, ci):
-    """proj [n][h][w][3*ci] (theta | phi | g) -> attention output [n][h][w][ci]; keys / values are the
-    2x2-max-pooled phi / g (floor mode, like nn.MaxPool2d(2))."""
-    n, h, w, _ = proj.shape
-    if h < 2 or w < 2:
-        raise RuntimeError("non-local block needs at least 2x2 positions per attention domain (MaxPool2d(2))")
-    theta = proj[..., :ci].reshape(n, h * w, ci)
-    pooled = F.max_pool2d(proj[..., ci:].permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)   # [n][h/2][w/2][2*ci]
-    phi = pooled[..., :ci].reshape(n, -1, ci)
-    g = pooled[..., ci:].reshape(n, -1, ci)
-    return ops.nonlocal_attention(theta, phi, g).view(n, h, w, ci)
+        return ops.nonlocal_block(x, self, quadrants=False)
 
 
 class Nonlocal_CA(nn.Module):
@@ -129,7 +80,7 @@ class Nonlocal_CA(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, x):
-        return _nonlocal(self.non_local, x, quadrants=True)
+        return ops.nonlocal_block(x, self.non_local, quadrants=True)
 
 
 class RB(nn.Module):

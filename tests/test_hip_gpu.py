@@ -380,6 +380,31 @@ def test_edsr_reduced_vs_oracle(scale):
     net_vs_oracle(net, "edsr", dict(num_blocks=2, scale=scale, res_scale=0.1), rnd(1, 3, 17, 23, seed=32, scale=0.5))
 
 
+@pytest.mark.parametrize("C,r", [(256, 2), (128, 3), (64, 2)])
+def test_pixel_shuffle_gather_and_its_adjoint(C, r):
+    """ops.pixel_shuffle (wide upsamplers, ref: advanced/common.py:20-45 nn.PixelShuffle) == torch's, bit for bit."""
+    x = rnd(2, C * r * r, 5, 7, seed=90)
+    want = torch.nn.functional.pixel_shuffle(x, r)
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = ops.pixel_shuffle(xg, r)
+    assert torch.equal(out.cpu(), want)
+    cot = rnd(*want.shape, seed=91)
+    out.backward(cot.to(DEV))
+    assert torch.equal(xg.grad.cpu(), torch.nn.functional.pixel_unshuffle(cot, r))
+
+
+def test_stack_maps_and_its_backward():
+    """ops.stack_maps (HAN's torch.cat of intermediate maps, ref: advanced/architectures.py:357-362) == torch.stack."""
+    maps = [rnd(2, 64, 6, 9, seed=92 + k).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            for k in range(3)]
+    stack = ops.stack_maps(maps)
+    assert torch.equal(stack, torch.stack([m.permute(0, 2, 3, 1) for m in maps], dim=1))
+    cot = rnd(*stack.shape, seed=99).to(DEV)
+    stack.backward(cot)
+    for k, m in enumerate(maps):
+        assert torch.equal(m.grad, cot[:, k].permute(0, 3, 1, 2))
+
+
 def test_edsr_paper_width_vs_oracle():
     """EDSR at the paper's width (n_feats = 256): multi-chunk fused ResBlock, 256 -> 1024
     upsampler convs, 256 -> 3 tail."""

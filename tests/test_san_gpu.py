@@ -84,6 +84,53 @@ def test_nonlocal_attention_kernel(nb, nq, nk):
         close(a.grad, b.grad, 1e-4, 1e-5, name)
 
 
+@pytest.mark.parametrize("shape,quadrants", [((2, 37, 51), True), ((1, 64, 96), True), ((2, 31, 30), False), ((3, 96, 128), True)])
+def test_nonlocal_block_kernels_vs_the_reference_formulation(shape, quadrants):
+    """csrc/nonlocal.hip (MFMA projections, pooled gather, output projection, every gradient) around the attention kernel
+    vs the block as the reference writes it (advanced/SAN_blocks.py:104-148, per quadrant :316-334) in float64: odd sizes
+    (unequal quadrants, floor-mode pooling leftovers, pixel counts off the 32-pixel MFMA tile) and a map large enough for
+    several partial-sum rows per parameter gradient."""
+    import torch.nn.functional as F
+    B, H, W = shape
+    blk = S.NONLocalBlock2D(64, 8, sub_sample=False, bn_layer=False)
+    g = torch.Generator().manual_seed(21)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+    x = torch.randn(B, 64, H, W, generator=g)
+    cot = torch.randn(B, 64, H, W, generator=g)
+
+    def ref_block(xq):
+        n = xq.shape[0]
+        th = F.conv2d(xq, blk.theta.weight.double(), blk.theta.bias.double()).reshape(n, 8, -1).transpose(1, 2)
+        ph = F.max_pool2d(F.conv2d(xq, blk.phi[0].weight.double(), blk.phi[0].bias.double()), 2).reshape(n, 8, -1)
+        gg = F.max_pool2d(F.conv2d(xq, blk.g[0].weight.double(), blk.g[0].bias.double()), 2).reshape(n, 8, -1).transpose(1, 2)
+        y = (torch.softmax(th @ ph, dim=-1) @ gg).transpose(1, 2).reshape(n, 8, *xq.shape[2:])
+        return F.conv2d(y, blk.W.weight.double(), blk.W.bias.double()) + xq
+
+    xr = x.double().requires_grad_(True)
+    if quadrants:
+        h1, w1 = H // 2, W // 2
+        top = torch.cat([ref_block(xr[:, :, :h1, :w1]), ref_block(xr[:, :, :h1, w1:])], 3)
+        want = torch.cat([top, torch.cat([ref_block(xr[:, :, h1:, :w1]), ref_block(xr[:, :, h1:, w1:])], 3)], 2)
+    else:
+        want = ref_block(xr)
+    want.backward(cot.double())
+    ref_g = {k: p.grad.clone() for k, p in blk.named_parameters()}
+    blk.zero_grad()
+    blk.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out = ops.nonlocal_block(xg, blk, quadrants)
+    close(out, want, 2e-4, 2e-5, "z")
+    out.backward(cot.to(DEV))
+    close(xg.grad, xr.grad, 5e-4, 5e-5, "dx")
+    for k, p in blk.named_parameters():
+        # phi's bias shifts every logit of a row alike: its exact gradient is 0, so it is compared on the scale of phi's weight
+        scale = ref_g["phi.0.weight"].norm() if k == "phi.0.bias" else ref_g[k].norm()
+        err = float((p.grad.double().cpu() - ref_g[k]).norm() / (scale + 1e-30))
+        assert err < 2e-5, (k, err)
+
+
 # ----------------------------------------------------------------------------- blocks vs the reference's own vectors
 @pytest.mark.parametrize("name", ["s1_soca", "s1_soca_odd"])
 def test_s1_soca(name):
