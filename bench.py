@@ -57,6 +57,12 @@ WORKLOADS = {
     # SAN: 20 groups x (10 RB x 2 convs + 1) = 420 body convs + head + upsampler/tail; attention FLOPs not counted
     "san": ("san", {}, 1.598),
     "qsan": ("qsan", {"metadata": ["blur_kernel"]}, 1.598),
+    # metadata-MAP models: 10 blur-kernel PCA maps at LR size beside the RGB input.
+    # SRMD: 2*9*(13*128 + 10*128*128 + 128*48) flop per LR pixel forward; SFTMD: head 151k + 16 blocks * (2 SFT layers
+    # [2*(74->32) + 2*(32->64) 3x3 convs = 159k] + 2 convs 73.7k) + SFT + conv_mid + upsampler (295k + 4*295k) + 9x9 output
+    # conv at 16 HR pixels (498k) = 9.80 Mflop per LR pixel forward; x3 for forward + both gradients, x 16384 pixels.
+    "srmd": ("srmd", {"metadata": ["blur_kernel"], "nc": 128, "nb": 12, "maps": True}, 0.152),
+    "sftmd": ("sftmd", {"metadata": ["blur_kernel"], "num_blocks": 16, "num_features": 64, "in_nc": 3, "maps": True}, 0.482),
 }
 GRAPH_MAX_BATCH = 8  # --graph auto: per-GPU batches up to this replay forward+backward from a hipGraph
 
@@ -125,6 +131,8 @@ def cpu_baseline(workload, seconds_budget=30.0):
     from oracle import sisr_oracle as O
     sisr = importlib.import_module("sisr_amd")
     name, params, _ = WORKLOADS[workload]
+    params = dict(params)
+    maps = params.pop("maps", False)
     torch.set_num_threads(min(16, os.cpu_count() or 1))  # the GPU box grants 16 host cores per GPU
     torch.manual_seed(8)
     h = sisr.available_models[name](device=torch.device("cpu"), model_save_dir="/tmp", eval_mode=False, scale=4, **params)
@@ -133,11 +141,16 @@ def cpu_baseline(workload, seconds_budget=30.0):
            "qrcan": dict(n_resgroups=10, n_resblocks=20, scale=4, style="standard", include_q_layer=True),
            "qedsr": dict(num_blocks=16, scale=4, res_scale=0.1, q_layer_nonlinearity=False),
            "han": dict(n_resgroups=10, n_resblocks=20, scale=4), "qhan": dict(n_resgroups=10, n_resblocks=20, scale=4),
-           "san": dict(n_resgroups=20, n_resblocks=10, scale=4), "qsan": dict(n_resgroups=20, n_resblocks=10, scale=4)}[name]
+           "san": dict(n_resgroups=20, n_resblocks=10, scale=4), "qsan": dict(n_resgroups=20, n_resblocks=10, scale=4),
+           "srmd": {}, "sftmd": {}}[name]
     tr = O.Trainer(name, h.net.state_dict(), lr=1e-4, **cfg)
     g = torch.Generator().manual_seed(8)
     x, y = torch.rand(1, 3, 128, 128, generator=g), torch.rand(1, 3, 512, 512, generator=g)
     md = (torch.rand(1, 10, 1, 1, generator=g) * 0.4) if name in O.META_NETS else None
+    if maps:
+        md = O.sft_channels(x, (torch.rand(1, 10, generator=g, dtype=torch.float64) * 0.4))
+        if name not in O.META_NETS:  # SRMD: the maps are concatenated to the input (ref: advanced/handlers.py:132-158)
+            x, md = torch.cat((x, md), 1), None
     tr.step(x, y, md)  # warm-up
     times = []
     t_all = time.perf_counter()
@@ -161,6 +174,8 @@ def cpu_baseline(workload, seconds_budget=30.0):
 def measure(sisr, workload, B, steps, warmup, use_graph, rank, world, local, dev, families=False, dp=False):
     """Build the handler, run warm-up + exactly `steps` timed steps (barrier + sync on both sides, max over ranks)."""
     name, params, tflop_per_patch = WORKLOADS[workload]
+    params = dict(params)
+    maps = params.pop("maps", False)
     if name not in sisr.available_models:
         raise SystemExit(f"workload {name} is not built yet")
     torch.manual_seed(8)
@@ -175,7 +190,8 @@ def measure(sisr, workload, B, steps, warmup, use_graph, rank, world, local, dev
     y = torch.rand(B, 3, 512, 512, generator=g).to(dev)
     kw = {}
     if "metadata" in params:
-        kw["extra_channels"] = (torch.rand(B, 10, 1, 1, generator=g) * 0.4).to(dev)
+        code = torch.rand(B, 10, 1, 1, generator=g) * 0.4
+        kw["extra_channels"] = (code.expand(B, 10, 128, 128).contiguous() if maps else code).to(dev)
 
     def sync():
         torch.cuda.synchronize()

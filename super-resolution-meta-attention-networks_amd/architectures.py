@@ -60,6 +60,8 @@ def meta_gates(layers, attributes):
     if not layers:
         return []
     first = layers[0]
+    if any(lay.num_layers != 2 for lay in layers):
+        return [lay.gate(attributes) for lay in layers]
     def sig(lay):
         a, b = (lay.attribute_integrator[i] for i in lay.fc_index)
         return (tuple(a.weight.shape), tuple(b.weight.shape), lay.nonlinearity, a.bias is not None, b.bias is not None)
@@ -252,13 +254,24 @@ class ParaCALayer(nn.Module):
         layers.append(nn.Sigmoid())
         self.attribute_integrator = nn.Sequential(*layers)
         self.nonlinearity = bool(nonlinearity)
-        if num_layers != 2:
-            raise NotImplementedError("the meta-gate kernel implements the reference's default num_layers=2")
+        self.num_layers = num_layers
+        if not 1 <= num_layers <= 4:
+            raise NotImplementedError("meta-attention gate kernels: 1 to 4 FC layers (the reference's default is 2)")
 
     def gate(self, attributes):
-        """(B,M,1,1) -> (B,C) sigmoid gate (the only part that depends on parameters)."""
-        a, b = (self.attribute_integrator[i] for i in self.fc_index)
-        return ops.meta_gate(attributes, a.weight, a.bias, b.weight, b.bias, self.nonlinearity)
+        """(B,M,1,1) -> (B,C) sigmoid gate (the only part that depends on parameters).  Two layers (the reference's
+        default and every published config): the dedicated meta-gate kernel; 1, 3 or 4: the generic gate MLP."""
+        fcs = [self.attribute_integrator[i] for i in self.fc_index]
+        if self.num_layers == 2:
+            a, b = fcs
+            return ops.meta_gate(attributes, a.weight, a.bias, b.weight, b.bias, self.nonlinearity)
+        n = len(fcs)
+        spec = ([(0, 0, 2 if k == n - 1 else int(self.nonlinearity)) for k in range(n)], 0)
+        params = []
+        for c in fcs:
+            params += [c.weight, c.bias]
+        B = attributes.shape[0]
+        return ops._GateMlp.apply(attributes.detach(), attributes.detach(), None, spec, *params).reshape(B, -1)
 
     def forward(self, x, attributes):
         return ops.gate_mul(x, self.gate(attributes))

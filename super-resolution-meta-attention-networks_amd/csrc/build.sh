@@ -14,14 +14,14 @@ build() {  # $1 = output, $2 = object dir, $3... = extra flags / sources
   local flags=() srcs=()
   for a in "$@"; do case "$a" in -D*) flags+=("$a");; *) srcs+=("$a");; esac; done
   local newest
-  newest=$(ls -t "${srcs[@]}" sisr_common.h ca_gate.h build.sh | head -1)
+  newest=$(ls -t "${srcs[@]}" sisr_common.h ca_gate.h conv_rgb_out.h build.sh | head -1)
   if [ -f "$out" ] && [ "$out" -nt "$newest" ]; then return 0; fi
   mkdir -p "$odir"
   local objs=() pids=()
   for s in "${srcs[@]}"; do
     local o=$odir/${s%.hip}.o
     objs+=("$o")
-    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ sisr_common.h -nt "$o" ] || [ ca_gate.h -nt "$o" ] || [ build.sh -nt "$o" ]; then
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ sisr_common.h -nt "$o" ] || [ ca_gate.h -nt "$o" ] || [ conv_rgb_out.h -nt "$o" ] || [ build.sh -nt "$o" ]; then
       "$HIPCC" -O3 -std=c++17 --offload-arch=gfx950 -fPIC "${flags[@]}" -c "$s" -o "$o" &
       pids+=($!)
     fi

@@ -8,11 +8,13 @@
 //                   input gradient of the head conv.
 //   corr3x3_c3    : out[a][tap][c] = sum_{b,p} P[b][a][p+off(tap)] * Q[b][p][c], P planar 3-channel,
 //                   Q chunked NHWC -- the weight gradient of both of the above (+ bias sums).
-// K = 27 (or N = 3): far too thin for the matrix cores; these are HBM-bound streaming kernels
+// K = 27 (or N = 3): too thin for the matrix cores as they stand -- except 64 -> 3, which conv_rgb_out.h widens to 27
+// columns (output row, channel, kw) and runs on them; the rest are HBM-bound streaming kernels
 // (the 512x512x64 map at the tail is the largest tensor in the network), written for coalesced
 // 256-B pixel rows.  Weights are addressed through generic (so, si, flip) strides so the same kernel
 // serves a forward pass (OIHW as stored) and a gradient pass (roles swapped, taps flipped).
 #include "sisr_common.h"
+#include "conv_rgb_out.h"
 
 static View view_from(const int64_t* v) {
   View r;
@@ -362,6 +364,23 @@ extern "C" int sisr_conv3x3_cout3(const float* x, const int64_t* xview, const fl
   p.H = H;
   p.W = W;
   p.cin_chunks = cin / 64;
+  if (cin == 64) {  // one chunk: the matrix-core kernel (conv_rgb_out.h); wider inputs stay on the streaming kernel below
+    RgbOutParams q = {};
+    q.x = x;
+    q.sB = p.xv.sB;
+    q.sH = p.xv.sH;
+    q.sW = p.xv.sW;
+    q.w = w;
+    q.so = so;
+    q.si = si;
+    q.flip = flip_taps;
+    q.bias = bias;
+    q.y = y;
+    q.B = B;
+    q.H = H;
+    q.W = W;
+    return rgb_out_launch<3, 3>(q, stream);
+  }
   const long npix = (long)B * H * W;
   long blocks = (npix + 15) / 16;
   if (blocks > 8192) blocks = 8192;

@@ -12,6 +12,7 @@
 //                   weight / bias gradient (ordered two-stage sum), and the clamp's forward / backward
 // All HBM- / VALU-bound and small next to the network's 3x3 convs; written for clarity, coalesced 256-B rows.
 #include "sisr_common.h"
+#include "conv_rgb_out.h"
 
 __device__ __forceinline__ float sft_sigmoid(float z) { return 1.f / (1.f + expf(-z)); }
 
@@ -180,9 +181,8 @@ extern "C" int sisr_map64(const float* a, long a_stride, const float* b, long b_
 
 // ------------------------------------------------------------------ 9x9 output conv, 64 -> 3 (OIHW weight [3][64][9][9])
 // All three directions run on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate) with the 3-channel side staged in LDS:
-//   forward  Z[q][(co, kw)] = sum_{kh, ci} x[q + (kh - 4) rows][ci] w[co][ci][kh][kw]   (M = 32 pixels of a row, N = 27 -> 32,
-//            K = 9 x 64), then y[co][p] = b[co] + sum_kw Z[p + kw - 4][(co, kw)] through LDS: the 3 output channels alone
-//            would leave 29 of the 32 MFMA columns empty, (co, kw) fills 27 of them; 24 of a tile's 32 columns are outputs.
+//   forward  conv_rgb_out.h (shared with the 3x3 64 -> 3 tail conv): Z[q][(co, kw)] = sum_{kh, ci} x[q + (kh - 4) rows][ci]
+//            w[co][ci][kh][kw] (M = 32 pixels of a row, N = 27 -> 32, K = 9 x 64), then y[co][p] = b[co] + sum_kw Z[p + kw - 4][(co, kw)]
 //   dgrad    dx[p][ci] = sum_{n = (co, kh, kw)} dy[co][p + 4 - (kh, kw)] w[n][ci]        (M = pixels, N = 64, K = 243 -> 270:
 //            kw padded to 10 so that the two K-halves of a lane pair are neighbouring columns), LeakyReLU' mask epilogue
 //   wgrad    dw[ci][n] = sum_p x[p][ci] dy[co][p + 4 - (kh, kw)]                         (M = 64, N = 243 -> 256, K = pixels),
@@ -191,76 +191,6 @@ extern "C" int sisr_map64(const float* a, long a_stride, const float* b, long b_
 // j = lane & 31, k = lane >> 5), D register r = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of column lane & 31.
 #define T9 81
 #define C9_GRID 512  // persistent grid (2 workgroups per CU); fixed, so the summation order does not depend on the device
-
-__device__ __forceinline__ float f4_at(f32x4 v, int e) { return v[e]; }
-
-// ---- forward
-#define F9_WAVES 8
-#define F9_ZLD 33
-#define F9_WZ (9 * 8 * 2 * 32 * 4)  // floats: [kh][octet j][k][n][e] = w[co(n)][8j + 4k + e][kh][kw(n)]
-__global__ __launch_bounds__(64 * F9_WAVES) void conv9_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                       const float* __restrict__ bias, float* __restrict__ y,
-                                                                       int B, int H, int W, int tiles_w, long ntiles) {
-  extern __shared__ __attribute__((aligned(16))) float lds9[];
-  float* wz = lds9;
-  float* zt = lds9 + F9_WZ + (threadIdx.x >> 6) * (32 * F9_ZLD);
-  for (int i = threadIdx.x; i < F9_WZ; i += 64 * F9_WAVES) {
-    const int e = i & 3, n = (i >> 2) & 31, k = (i >> 7) & 1, j = (i >> 8) & 7, kh = i >> 11;
-    const int co = n / 9, kw = n - co * 9, ci = 8 * j + 4 * k + e;
-    wz[i] = n < 27 ? w[((long)co * 64 + ci) * T9 + kh * 9 + kw] : 0.f;
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 31, kk = lane >> 5;
-  // wave tile = 24 output columns of one row; tiles are dealt to (workgroup, wave) in a fixed order
-  for (long t = (long)blockIdx.x * F9_WAVES + wave; t < ntiles; t += (long)gridDim.x * F9_WAVES) {
-    const int tw = (int)(t % tiles_w);
-    const long rr = t / tiles_w;
-    const int gy = (int)(rr % H), b = (int)(rr / H);
-    const int ox0 = tw * 24, qx = ox0 - 4 + li;
-    const bool colok = qx >= 0 && qx < W;
-    const float* xp = x + (((long)b * H) * W + min(max(qx, 0), W - 1)) * 64 + 4 * kk;
-    f32x16 acc = {0};
-    f32x4 cur[8], nxt[8];
-    int kh = max(0, 4 - gy);
-    const int kh_end = min(9, H + 4 - gy);  // rows gy + kh - 4 inside the image
-#pragma unroll
-    for (int j = 0; j < 8; ++j) cur[j] = *reinterpret_cast<const f32x4*>(xp + (long)(gy + kh - 4) * W * 64 + 8 * j);
-    for (; kh < kh_end; ++kh) {
-      const int khn = min(kh + 1, kh_end - 1);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) nxt[j] = *reinterpret_cast<const f32x4*>(xp + (long)(gy + khn - 4) * W * 64 + 8 * j);
-      const float* wk = wz + kh * 2048 + kk * 128 + li * 4;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const f32x4 a = sisr_keep_if(cur[j], colok);
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(wk + j * 256);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bb[e], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
-    }
-    // Z tile -> LDS (row = tile column i, column = n), then y[co][o] = b[co] + sum_kw Z[o + kw][co * 9 + kw]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zt[((r & 3) + 8 * (r >> 2) + 4 * kk) * F9_ZLD + li] = acc[r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed (one wave owns zt)
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int idx = lane + 64 * u;
-      if (idx < 72) {
-        const int co = idx / 24, o = idx - co * 24;
-        float v = bias ? bias[co] : 0.f;
-#pragma unroll
-        for (int kw = 0; kw < 9; ++kw) v += zt[(o + kw) * F9_ZLD + co * 9 + kw];
-        if (ox0 + o < W) y[(((long)b * 3 + co) * H + gy) * W + ox0 + o] = v;
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-  }
-}
 
 // ---- input gradient
 #define D9_TR 8
@@ -462,29 +392,23 @@ __global__ __launch_bounds__(256) void clamp01_kernel(const float* __restrict__ 
 }
 
 
-static long conv9_fwd_tiles(int B, int H, int W, int* tiles_w) {
-  *tiles_w = (W + 23) / 24;
-  return (long)B * H * *tiles_w;
-}
-
 extern "C" int sisr_conv9_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
   if (!sisr_aligned16(x)) return SISR_ERR_ALIGN;
-  int tiles_w;
-  const long ntiles = conv9_fwd_tiles(B, H, W, &tiles_w);
-  long blocks = (ntiles + F9_WAVES - 1) / F9_WAVES;
-  if (blocks > 256) blocks = 256;  // one 8-wave workgroup per CU (107 KB of LDS)
-  const size_t lds = (F9_WZ + F9_WAVES * 32 * F9_ZLD) * sizeof(float);
-  static bool attr_set = false;  // idempotent, value never changes: raise the dynamic-LDS cap of this kernel once
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return SISR_ERR_UNSUPPORTED;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(conv9_fwd_mfma_kernel, dim3((unsigned)blocks), dim3(64 * F9_WAVES), lds, (hipStream_t)stream, x, w, bias, y,
-                     B, H, W, tiles_w, ntiles);
-  return sisr_check_launch();
+  RgbOutParams p = {};
+  p.x = x;
+  p.sB = (long)H * W * 64;
+  p.sH = (long)W * 64;
+  p.sW = 64;
+  p.w = w;
+  p.so = 64 * T9;
+  p.si = T9;
+  p.bias = bias;
+  p.y = y;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  return rgb_out_launch<9, 1>(p, stream);
 }
 
 extern "C" int sisr_conv9_dgrad(const float* dy, const float* w, const float* leaky_mask, float* dx, int B, int H, int W,

@@ -223,9 +223,12 @@ def test_conv_pixelshuffle_fused(r):
         close(got.grad, want.grad, 2e-4, 2e-5, "d" + nm)
 
 
+@pytest.mark.parametrize("shape", [(2, 11, 19), (1, 1, 1), (1, 2, 31), (3, 64, 95), (1, 7, 61), (2, 200, 333)])
 @pytest.mark.parametrize("cin,cout", [(3, 64), (64, 3)])
-def test_rgb_side_convs(cin, cout):
-    B, H, W = 2, 11, 19
+def test_rgb_side_convs(cin, cout, shape):
+    """Head / tail convs and their gradients; 64 -> 3 (forward, and the head's input gradient with flipped role-swapped
+    weights) runs on the matrix cores in tiles of 3 rows x 30 columns (csrc/conv_rgb_out.h): sizes off both tile edges."""
+    B, H, W = shape
     x = rnd(B, cin, H, W, seed=14).requires_grad_(True)
     w = (rnd(cout, cin, 3, 3, seed=15) * 0.1).requires_grad_(True)
     b = (rnd(cout, seed=16) * 0.1).requires_grad_(True)
@@ -378,6 +381,29 @@ def test_edsr_reduced_vs_oracle(scale):
     torch.manual_seed(8)
     net = A.EDSR(net_features=64, num_blocks=2, scale=scale, res_scale=0.1)
     net_vs_oracle(net, "edsr", dict(num_blocks=2, scale=scale, res_scale=0.1), rnd(1, 3, 17, 23, seed=32, scale=0.5))
+
+
+@pytest.mark.parametrize("L,M,nl", [(1, 10, 1), (3, 10, 1), (3, 20, 0), (4, 1, 1), (4, 20, 1)])
+def test_paraca_other_depths(L, M, nl):
+    """ParaCALayer with 1 / 3 / 4 FC layers (ref: attention_manipulators/q_layer.py:12-31; the published configs use 2) on the
+    generic gate-MLP kernel vs the same nn.Sequential run by torch on the CPU (the reference's own formulation)."""
+    torch.manual_seed(30 + L)
+    mod = A.ParaCALayer(64, M, nonlinearity=bool(nl), num_layers=L)
+    x, md = rnd(2, 64, 9, 11, seed=31), torch.rand(2, M, 1, 1, generator=torch.Generator().manual_seed(32))
+    cot = rnd(2, 64, 9, 11, seed=33)
+    xr = x.clone().requires_grad_(True)
+    want = xr * mod.attribute_integrator(md)
+    want.backward(cot)
+    ref_g = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    mod.zero_grad()
+    mod.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out = mod(xg, md.to(DEV))
+    close(out, want, 1e-5, 1e-6)
+    out.backward(cot.to(DEV))
+    close(xg.grad, xr.grad, 1e-5, 1e-6)
+    for k, p in mod.named_parameters():
+        close(p.grad, ref_g[k], 2e-4, 1e-5 * float(ref_g[k].abs().max()) + 1e-9, k)
 
 
 @pytest.mark.parametrize("C,r", [(256, 2), (128, 3), (64, 2)])
