@@ -82,7 +82,10 @@ typedef struct {
 } sisr_ca_tail;
 size_t sisr_ca_tail_bytes(void);
 /* select: 0 (= 4) issue-lean kernel, tile height chosen by grid size, general kernel as fallback; 5 / 6 the same with
- * the 4-row / 2-row tile forced (bit-identical results; A/B measurements and tests); 2 general kernel only. */
+ * the 4-row / 2-row tile forced (bit-identical results; A/B measurements and tests); 2 general kernel only.
+ * 8 / 9: the caller asserts structural zeros in the packed weight (SFTMD's merged convs) and the kernel skips them:
+ *   8  64 -> 128 block-diagonal (output chunk q contracts input channels 32q .. 32q+31 only), plain epilogue;
+ *   9  128 -> 64 whose input channels >= 80 are zero (second chunk: first 16 channels only), LeakyReLU epilogue. */
 /* gate_add / gate_out / dot (all nullable; 64 -> 64, x and y in one layout) fuse the gated-residual chain of
  * RCAB / QRCAB stacks (ref: advanced/architectures.py:68-71, :107-110) into the neighbouring convs:
  *   gate_add + gate_out : the conv reads  x * in_scale[b,c] + gate_add  (the previous block's `res * y + x`) and
@@ -98,7 +101,11 @@ int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const float* dy, con
                       const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so, int64_t si,
                       int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n, int in_perm_q, float* dbias,
                       int bias_n, int bias_q, float* workspace, size_t workspace_bytes, int B, int H, int W, int cin,
-                      int cout, void* stream);
+                      int cout, unsigned long long active_units, void* stream);
+/* active_units: 0 = the whole gradient.  Otherwise bit ((cin_chunk * cout_chunks + cout_chunk) * 4 + ci_half * 2 + co_half)
+ * selects the 32 x 32-channel blocks (x 9 taps) to compute; the others are neither computed nor written (a caller whose
+ * weight is structurally sparse -- SFTMD's merged convs -- never reads them).  At most 64 blocks; every bias half needs
+ * one active block. */
 
 /* ---- RGB-side 3x3 convolutions (fp32 VALU, HBM-bound) ------------------------------------------
  * ref: head = default_conv(3, n_feats), tail[-1] = default_conv(n_feats, 3)

@@ -23,6 +23,7 @@
 #include "ca_gate.h"
 #include <string.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #define TH 4
 #define TW 32
@@ -282,7 +283,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
 // input -- saving that block's separate reduction pass over two maps.
 // LEAKY (SFTMD, csrc/sft.hip): without MASK the activation is LeakyReLU(0.2) (p.relu == 2); with MASK the mask is that
 // activation's derivative (slope 0.2 where the masking map is <= 0) instead of ReLU's.
-template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false, bool LEAKY = false>
+// KSEL (SFTMD's merged convs, whose weights are structurally sparse; every other caller: 0 = the dense code path, untouched):
+//   1  block-diagonal 64 -> 128: output chunk q contracts input channels 32q .. 32q+31 only (4 of 8 octets per tap)
+//   2  128 -> 64 whose second input chunk carries at most 16 channels (2 of 8 octets per tap)
+// The skipped products are exact zeros, so results are those of the dense kernel on the zero-padded weights.  (The
+// transpose of 1 -- input chunk c feeds output channels 32c .. 32c+31 only -- was tried as "the other two waves skip the
+// chunk": a wave-uniform branch around the unrolled K loop cost 118 spilled VGPRs; it stays on the dense kernel.)
+template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false, bool LEAKY = false, int KSEL = 0>
 __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(ConvParams p) {
   constexpr int THv = 2 * MT, HHv = THv + 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
   for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      aoff[kw][j] = ((MT * ph) * HALO_W + n + kw) * 64 + (((2 * j + hh) ^ ((n + kw) & 15)) << 2);
+      aoff[kw][j] = ((MT * ph) * HALO_W + n + kw) * 64 + (((2 * (KSEL == 1 ? (j & 3) + 4 * q : j) + hh) ^ ((n + kw) & 15)) << 2);
   const unsigned boff = hh * 256 + co * 4;
 
   for (int c = 0; c < p.cin_chunks; ++c) {
@@ -402,6 +409,49 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
 
     // ---- K loop, fully unrolled: 72 steps x 8 MFMAs; every address is lane constant + immediate
     const float* wq = p.w + ((long)q * p.cin_chunks + c) * (9 * 64 * 64);  // scalar
+    if constexpr (KSEL != 0) {
+      // NJ octets per tap starting at octet J0 (KSEL 1: J0 = 4q, folded into aoff and the weight base); same pipeline
+      auto kloop = [&](auto nj_tag, const float* wb) {
+        constexpr int NJ = decltype(nj_tag)::value, NS = 9 * NJ;
+        auto ldb = [&](int s) { return *reinterpret_cast<const f32x4*>(wb + ((s / NJ) * 8 + (s % NJ)) * 512 + boff); };
+        auto lda = [&](int m, int s) {
+          return *reinterpret_cast<const f32x4*>(lds + (((s / NJ) / 3 + m) * (HALO_W * 64)) + aoff[(s / NJ) % 3][s % NJ]);
+        };
+        f32x4 bq[8];
+        f32x4 aq[4][2];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) bq[s] = ldb(s);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          aq[s][0] = lda(0, s);
+          if (MT == 2) aq[s][1] = lda(1, s);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          if (s + 6 < NS) bq[(s + 6) & 7] = ldb(s + 6);
+          if (s + 2 < NS) {
+            aq[(s + 2) & 3][0] = lda(0, s + 2);
+            if (MT == 2) aq[(s + 2) & 3][1] = lda(1, s + 2);
+          }
+          const f32x4 bb = bq[s & 7];
+          const f32x4 a0 = aq[s & 3][0];
+          const f32x4 a1 = aq[s & 3][1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bb[e], acc0, 0, 0, 0);
+            if (MT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bb[e], acc1, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if constexpr (KSEL == 1) {
+        kloop(std::integral_constant<int, 4>{}, wq + (long)q * (4 * 512));
+      } else {
+        if (c == 0) kloop(std::integral_constant<int, 8>{}, wq);
+        else kloop(std::integral_constant<int, 2>{}, wq);
+      }
+    } else {
 #define V4_LOAD_B(s) (*reinterpret_cast<const f32x4*>(wq + (s) * 512 + boff))
 #define V4_LOAD_A(m, s) \
   (*reinterpret_cast<const f32x4*>(lds + ((((s) >> 3) / 3 + (m)) * (HALO_W * 64)) + aoff[((s) >> 3) % 3][(s) & 7]))
@@ -434,6 +484,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
     }
 #undef V4_LOAD_A
 #undef V4_LOAD_B
+    }
   }
 
   // ---- epilogue
@@ -1712,7 +1763,10 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   // select (per call; the library keeps no state): 0 / 4 = issue-lean kernel, tile height by grid size, general kernel
   // as fallback; 5 / 6 = the same with the 4-row / 2-row tile forced (A/B measurements, bit-identical results);
   // 2 = general kernel only.  Diagnostic builds (-DSISR_DIAG) add 13 / 16.
-  const int variant = select == 0 ? 4 : select;
+  // 8 / 9 = structurally sparse weights (SFTMD's merged convs; KSEL 1 / 2 of conv3x3_c64_v4_kernel): the caller asserts
+  // that the skipped blocks of the packed weight are zero
+  const int ksel = (select == 8 || select == 9) ? select - 7 : 0;
+  const int variant = (select == 0 || ksel) ? 4 : select;
 #ifdef SISR_DIAG
   if (variant != 4 && variant != 5 && variant != 6 && variant != 2 && variant != 13 &&
       variant != 16)
@@ -1720,6 +1774,10 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
 #else
   if (variant != 4 && variant != 5 && variant != 6 && variant != 2) return SISR_ERR_ARG;
 #endif
+  if (ksel) {
+    const bool shape_ok = ksel == 1 ? (cin == 64 && cout == 128) : (cin == 128 && cout == 64);
+    if (!shape_ok || ca_tail || gate_add || gate_out || dot || in_scale || in_shift || out_scale || res) return SISR_ERR_UNSUPPORTED;
+  }
   if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
   if (!sisr_aligned16(x) || !sisr_aligned16(wpacked) || !sisr_aligned16(in_scale) || !sisr_aligned16(in_shift))
     return SISR_ERR_ALIGN;
@@ -1806,6 +1864,24 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   if (variant == 4 || variant == 5 || variant == 6) {
     const bool aff = in_scale != nullptr, msk = mask != nullptr, rs = res != nullptr;
     hipStream_t st = (hipStream_t)stream;
+    if (ksel) {
+      // 1: plain (bias only); 2: LeakyReLU epilogue -- the forms SFTMD needs
+      const bool form_ok = ksel == 1 ? (!msk && p.relu == 0) : (!msk && p.relu == 2);
+      if (!form_ok) return SISR_ERR_UNSUPPORTED;
+      const bool small = nblk * p.cout_chunks < SMALL_GRID_BLOCKS;
+      dim3 g = grid;
+      size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
+      if (small) {
+        p.tiles_h = (H + 1) / 2;
+        g = dim3((unsigned)((long)p.tiles_w * p.tiles_h * B), p.cout_chunks);
+        lb = 4 * HALO_W * 64 * sizeof(float);
+      }
+#define V4K(MK, MTV, LK, KS) hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, MK, false, MTV, false, false, LK, KS>), g, dim3(256), lb, st, p)
+      if (ksel == 1) { if (small) V4K(false, 1, false, 1); else V4K(false, 2, false, 1); }
+      else { if (small) V4K(false, 1, true, 2); else V4K(false, 2, true, 2); }
+#undef V4K
+      return sisr_check_launch();
+    }
     if (!(in_shift && !in_scale) && !(aff && !msk) && !(msk && rs)) {
       // Grids with fewer 4-row workgroups than CUs (a single 128x128 sample) leave half the chip idle: halve the tile.  Variant 5 / 6 force
       // the 4-row / 2-row kernel (A/B measurements); results are bit-identical either way.

@@ -30,6 +30,7 @@
 #define LDS_X (WH_H * WH_W * WSTR)                // floats
 #define LDS_Y (WT_H * WT_W * WSTR)
 #define SLAB (9 * 16 * 64)                        // floats per workgroup slab: 9216
+#define WG_MAX_UNITS 64                           // (cin / 64) * (cout / 64) * 4 quadrants of a maskable launch
 
 struct WgradParams {
   const float* x;
@@ -39,8 +40,12 @@ struct WgradParams {
   const float* dy_scale;
   const float* dy_shift;
   float* slabs;      // [S][gridDim.y][SLAB]
-  float* bias_slabs; // [S][cout_chunks*2][32] (written by ci-quadrant 0 of cin chunk 0) or null
+  float* bias_slabs; // [S][cout_chunks*2][32] (written by the first active unit of each (cout chunk, co half)) or null
   int B, H, W, cin_chunks, cout_chunks, tiles_w, tiles_h, S;
+  // active units (blockIdx.y -> unit); all of them unless the caller knows blocks of the gradient to be unused
+  int mapped;
+  unsigned char unit_map[WG_MAX_UNITS];
+  unsigned long long bias_units;  // bit blockIdx.y: this workgroup row also sums dY for the bias gradient
 };
 
 __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) {
@@ -48,13 +53,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) {
   float* ldx = lds;
   float* ldy = lds + LDS_X;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int unit = blockIdx.y;
+  const int unit = p.mapped ? p.unit_map[blockIdx.y] : (int)blockIdx.y;
   const int quad = unit & 3, pair = unit >> 2;
   const int cq = pair % p.cout_chunks, cc = pair / p.cout_chunks;
   const int cih = quad >> 1, coh = quad & 1;
   const int i = lane & 31, kk = lane >> 5;
   const int H = p.H, W = p.W;
-  const bool do_bias = p.bias_slabs && cc == 0 && cih == 0;
+  const bool do_bias = p.bias_slabs && (p.mapped ? (int)((p.bias_units >> blockIdx.y) & 1) : (cc == 0 && cih == 0));
   const int Cout = p.cout_chunks * 64;
 
   f32x16 acc[9];
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) {
   if (do_bias) *reinterpret_cast<f32x4*>(red + SLAB + tid * 4) = bsum;
   __syncthreads();
   if (wave == 0) {
-    float* out = p.slabs + ((long)blockIdx.x * gridDim.y + unit) * SLAB;
+    float* out = p.slabs + ((long)blockIdx.x * gridDim.y + blockIdx.y) * SLAB;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -638,6 +643,8 @@ struct ReduceParams {
   long so, si;
   float alpha;
   int S, units, cin_chunks, cout_chunks, flip, on, oq, in_, iq, bias_n, bias_q;
+  int mapped;                             // != 0: slab row r holds unit unit_map[r] (launch with an active-unit mask)
+  unsigned char unit_map[WG_MAX_UNITS];
 };
 
 // blockDim = (64, RG): x = element within a 64-run (coalesced across slabs), y = slab group (S split RG ways, up to
@@ -674,8 +681,9 @@ __global__ __launch_bounds__(64 * RG) void wgrad_reduce_kernel(ReduceParams p) {
 #pragma unroll
   for (int g = 1; g < RG; ++g) s += red[g][threadIdx.x];
   if (is_w) {
-    const int unit = (int)(gid / SLAB);
-    const int e = (int)(gid - (long)unit * SLAB);
+    const int urow = (int)(gid / SLAB);
+    const int e = (int)(gid - (long)urow * SLAB);
+    const int unit = p.mapped ? p.unit_map[urow] : urow;
     const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
     const int quad = unit & 3, pair = unit >> 2;
     const int cq = pair % p.cout_chunks, cc = pair / p.cout_chunks;
@@ -713,14 +721,16 @@ extern "C" size_t sisr_wgrad3x3_c64_workspace_bytes(int B, int H, int W, int cin
   if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
   const int units = (cin / 64) * (cout / 64) * 4;
   const int S = wgrad_split(B, H, W, units);
-  return ((size_t)S * units * SLAB + (size_t)S * cout) * sizeof(float);
+  // bias slabs sized for the finest split a masked launch can take (one active unit: S = 512)
+  return ((size_t)(S * units > 512 ? S * units : 512) * SLAB + (size_t)512 * cout) * sizeof(float);
 }
 
 extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
                                  const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so,
                                  int64_t si, int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n,
                                  int in_perm_q, float* dbias, int bias_n, int bias_q, float* workspace,
-                                 size_t workspace_bytes, int B, int H, int W, int cin, int cout, void* stream) {
+                                 size_t workspace_bytes, int B, int H, int W, int cin, int cout,
+                                 unsigned long long active_units, void* stream) {
   if (!x || !dy || !dw || !xview || !dyview || !workspace || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
   if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
   if (workspace_bytes < sisr_wgrad3x3_c64_workspace_bytes(B, H, W, cin, cout)) return SISR_ERR_ARG;
@@ -743,7 +753,32 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   p.cout_chunks = cout / 64;
   p.tiles_w = (W + WT_W - 1) / WT_W;
   p.tiles_h = (H + WT_H - 1) / WT_H;
-  const int units = p.cin_chunks * p.cout_chunks * 4;
+  // Units = (cin chunk, cout chunk, ci half, co half) blocks of the gradient, bit ((cc * cout_chunks + cq) * 4 + cih * 2 + coh)
+  // of active_units (0 = all).  A caller whose weight is structurally sparse (SFTMD's merged convs) masks the blocks it
+  // never reads: they are neither computed nor written, and the K-slices of the launch go to the rest.
+  const int all_units = p.cin_chunks * p.cout_chunks * 4;
+  if (active_units && all_units > WG_MAX_UNITS) return SISR_ERR_UNSUPPORTED;
+  ReduceParams r;
+  int units = all_units;
+  p.bias_units = 0;
+  if (active_units) {
+    units = 0;
+    unsigned seen_bias = 0;  // bit (cq * 2 + coh): a unit already sums this bias half
+    for (int u = 0; u < all_units; ++u) {
+      if (!((active_units >> u) & 1)) continue;
+      p.unit_map[units] = r.unit_map[units] = (unsigned char)u;
+      const int cq = (u >> 2) % p.cout_chunks, coh = u & 1;
+      if (!((seen_bias >> (cq * 2 + coh)) & 1)) {
+        p.bias_units |= 1ull << units;
+        seen_bias |= 1u << (cq * 2 + coh);
+      }
+      ++units;
+    }
+    if (units == 0 || (all_units < 64 && (active_units >> all_units) != 0)) return SISR_ERR_ARG;
+    if (dbias && seen_bias != (1u << (p.cout_chunks * 2)) - 1) return SISR_ERR_ARG;  // a bias half nobody would sum
+  }
+  p.mapped = active_units != 0;
+  r.mapped = active_units != 0;
   p.S = wgrad_split(B, H, W, units);
   p.slabs = workspace;
   p.bias_slabs = dbias ? workspace + (size_t)p.S * units * SLAB : nullptr;
@@ -752,7 +787,6 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(p.S, units), dim3(256), lds_bytes, (hipStream_t)stream, p);
   int rc = sisr_check_launch();
   if (rc) return rc;
-  ReduceParams r;
   r.slabs = p.slabs;
   r.bias_slabs = p.bias_slabs;
   r.dw = dw;
@@ -829,6 +863,7 @@ extern "C" int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, cons
   int rc = sisr_check_launch();
   if (rc) return rc;
   ReduceParams r;
+  r.mapped = 0;
   r.slabs = p.slabs;
   r.bias_slabs = p.bias_slabs;
   r.dw = dw;
@@ -905,6 +940,7 @@ extern "C" int sisr_wgrad3x3_c64_x3(const float* x, const int64_t* xview, const 
   int rc = sisr_check_launch();
   if (rc) return rc;
   ReduceParams r;
+  r.mapped = 0;
   r.slabs = p.slabs;
   r.bias_slabs = p.bias_slabs;
   r.dw = dw;

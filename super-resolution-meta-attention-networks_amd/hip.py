@@ -25,7 +25,7 @@ _SIGS = {
     "sisr_ca_tail_bytes": (c_size_t, []),
     "sisr_wgrad3x3_c64_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "sisr_wgrad3x3_c64": (c_int, [P, P, P, P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
-                                  c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+                                  c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, P]),
     "sisr_conv3x3_cin3": (c_int, [P, P, c_int64, c_int64, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
     "sisr_conv3x3_cout3": (c_int, [P, P, P, c_int64, c_int64, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "sisr_corr3x3_c3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -295,20 +295,24 @@ def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=
     hip.check(rc, name)
 
 
-def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_scale=None, dy_shift=None, shuffle=1):
+def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_scale=None, dy_shift=None, shuffle=1,
+              active_units=0):
+    """active_units (fp32 kernel): bit mask of the 32 x 32-channel blocks of the gradient to compute (0 = all)."""
     L = hip.lib()
+    fp32 = False
     if PRECISION == "bf16x3" and X3_WGRAD:
         size_fn, fn, name = L.sisr_wgrad3x3_c64_x3_workspace_bytes, L.sisr_wgrad3x3_c64_x3, "sisr_wgrad3x3_c64_x3"
     elif PRECISION == "bf16":
         size_fn, fn, name = L.sisr_wgrad3x3_c64_bf16_workspace_bytes, L.sisr_wgrad3x3_c64_bf16, "sisr_wgrad3x3_c64_bf16"
     else:
-        size_fn, fn, name = L.sisr_wgrad3x3_c64_workspace_bytes, L.sisr_wgrad3x3_c64, "sisr_wgrad3x3_c64"
+        size_fn, fn, name, fp32 = L.sisr_wgrad3x3_c64_workspace_bytes, L.sisr_wgrad3x3_c64, "sisr_wgrad3x3_c64", True
     nbytes = size_fn(B, H, W, cin, cout)
     ws = hip.workspace(x.device, nbytes)
     rr = shuffle * shuffle
     on, oq = (rr, 1) if shuffle > 1 else (1, 64)
-    rc = fn(hip.ptr(x), xview, hip.ptr(dy), dyview, hip.ptr(dy_scale), hip.ptr(dy_shift), float(alpha), hip.ptr(dw),
-            cin * 9, 9, 0, on, oq, 1, 64, hip.ptr(db), on, oq, hip.ptr(ws), nbytes, B, H, W, cin, cout, hip.stream())
+    args = (hip.ptr(x), xview, hip.ptr(dy), dyview, hip.ptr(dy_scale), hip.ptr(dy_shift), float(alpha), hip.ptr(dw),
+            cin * 9, 9, 0, on, oq, 1, 64, hip.ptr(db), on, oq, hip.ptr(ws), nbytes, B, H, W, cin, cout)
+    rc = fn(*args, int(active_units), hip.stream()) if fp32 else fn(*args, hip.stream())
     hip.check(rc, name)
 
 
@@ -1215,6 +1219,7 @@ def shuffle_rgb(y, channels, r):
 
 # ----------------------------------------------------------------------------- SFTMD (csrc/sft.hip)
 LEAKY, LEAKY_MASK = 2, 4  # `relu` codes of sisr_conv3x3_c64: LeakyReLU(0.2) epilogue / the mask is its derivative
+SPARSE_BLOCK_DIAGONAL, SPARSE_SECOND_CHUNK = 8, 9  # `select` codes: structural zeros of the merged SFT weights are skipped
 
 
 def _fp32_only(what):
@@ -1261,9 +1266,11 @@ class _SftLayer(Function):
         pfA, pdA = pack_pair(WA)
         pfB, pdB = pack_pair(WB)
         t = _empty_cl(B, 64, H, W, dev)
-        conv_c64(cat, hip.view_plain(H, W, 128), pfA, bA, (1, 64), t, hip.view_plain(H, W, 64), B, H, W, 128, 64, relu=LEAKY)
+        conv_c64(cat, hip.view_plain(H, W, 128), pfA, bA, (1, 64), t, hip.view_plain(H, W, 64), B, H, W, 128, 64, relu=LEAKY,
+                 select=SPARSE_SECOND_CHUNK if M <= 16 else 0)
         y2 = _empty_cl(B, 128, H, W, dev)
-        conv_c64(t, hip.view_plain(H, W, 64), pfB, bB, (1, 64), y2, hip.view_plain(H, W, 128), B, H, W, 64, 128)
+        conv_c64(t, hip.view_plain(H, W, 64), pfB, bB, (1, 64), y2, hip.view_plain(H, W, 128), B, H, W, 64, 128,
+                 select=SPARSE_BLOCK_DIAGONAL)
         out = _empty_cl(B, 64, H, W, dev)
         hip.check(hip.lib().sisr_sft_combine_fwd(hip.ptr(cat), 128, hip.ptr(y2), None, hip.ptr(out), 64, npix, int(relu),
                                                  hip.stream()), "sisr_sft_combine_fwd")
@@ -1289,12 +1296,13 @@ class _SftLayer(Function):
                                                      hip.ptr(dy2), npix, relu, hip.stream()), "sisr_sft_combine_bwd")
             dWB = torch.empty((128, 64, 3, 3), device=dev)
             dbB = torch.empty(128, device=dev)
-            wgrad_c64(t, v64, dy2, v128, dWB, dbB, B, H, W, 64, 128)
+            wgrad_c64(t, v64, dy2, v128, dWB, dbB, B, H, W, 64, 128, active_units=0xC3)  # the two diagonal 64 x 32 blocks
             dt = _empty_cl(B, 64, H, W, dev)
             conv_c64(dy2, v128, pdB, None, (1, 64), dt, v64, B, H, W, 128, 64, mask=t, relu=LEAKY_MASK)
             dWA = torch.empty((64, 128, 3, 3), device=dev)
             dbA = torch.empty(64, device=dev)
-            wgrad_c64(cat, v128, dt, v64, dWA, dbA, B, H, W, 128, 64)
+            # input channels >= 96 are padding when M <= 32: the last ci half of the second chunk is never read back
+            wgrad_c64(cat, v128, dt, v64, dWA, dbA, B, H, W, 128, 64, active_units=0x3F if M <= 32 else 0)
             dx = None
             if ctx.needs_input_grad[0]:
                 # input gradient of A for the 64 feature channels only (output chunk 0 of the packing) + the direct term

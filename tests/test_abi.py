@@ -50,7 +50,7 @@ def test_pure_host_queries():
     L = sisr_amd.hip.lib()
     assert L.sisr_conv3x3_c64_gap_parts(128, 128) == 32 * 4 * 2
     assert L.sisr_conv3x3_c64_gap_parts(57, 86) == 15 * 3 * 2
-    assert L.sisr_wgrad3x3_c64_workspace_bytes(4, 128, 128, 64, 64) == (128 * 4 * 9216 + 128 * 64) * 4
+    assert L.sisr_wgrad3x3_c64_workspace_bytes(4, 128, 128, 64, 64) == (128 * 4 * 9216 + 512 * 64) * 4  # 512 K-slices x units; bias slabs for the finest masked split
     assert L.sisr_wgrad3x3_c64_workspace_bytes(4, 128, 128, 60, 64) == 0
     assert L.sisr_l1_loss_workspace_bytes() == 2048
     assert L.sisr_gate_dg_parts(128 * 128) == 32

@@ -87,6 +87,65 @@ def test_sft_layer_matches_the_four_conv_formulation(relu, M):
         assert rel(p.grad, ref_g[k]) < 5e-6, k
 
 
+@pytest.mark.parametrize("shape", [(2, 10, 37), (4, 64, 64)])
+def test_sparse_select_codes_equal_the_dense_kernel(shape):
+    """`select` 8 / 9 skip structural zeros of the merged SFT weights: the remaining products are accumulated in the dense
+    kernel's order, so the outputs are bit-identical; the masked weight gradient (other K-slice split) agrees to rounding.
+    Both tile heights (small and large grids)."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    cl = torch.channels_last
+    # 64 -> 128 block-diagonal
+    wb = torch.zeros(128, 64, 3, 3)
+    wb[:64, :32] = torch.randn(64, 32, 3, 3, generator=g) * 0.1
+    wb[64:, 32:] = torch.randn(64, 32, 3, 3, generator=g) * 0.1
+    wb, bias = wb.cuda(), (torch.randn(128, generator=g) * 0.1).cuda()
+    t = torch.randn(B, 64, H, W, generator=g).cuda().contiguous(memory_format=cl)
+    pf, _ = ops.pack_pair(wb)
+    outs = []
+    for sel in (0, ops.SPARSE_BLOCK_DIAGONAL):
+        y = torch.empty(B, 128, H, W, device="cuda").contiguous(memory_format=cl)
+        ops.conv_c64(t, hip.view_plain(H, W, 64), pf, bias, (1, 64), y, hip.view_plain(H, W, 128), B, H, W, 64, 128, select=sel)
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    # 128 -> 64, input channels >= 80 zero, LeakyReLU epilogue
+    wa = torch.zeros(64, 128, 3, 3)
+    wa[:, :80] = torch.randn(64, 80, 3, 3, generator=g) * 0.1
+    wa = wa.cuda()
+    cat = torch.randn(B, 128, H, W, generator=g).cuda().contiguous(memory_format=cl)
+    pa, _ = ops.pack_pair(wa)
+    outs = []
+    for sel in (0, ops.SPARSE_SECOND_CHUNK):
+        y = torch.empty(B, 64, H, W, device="cuda").contiguous(memory_format=cl)
+        ops.conv_c64(cat, hip.view_plain(H, W, 128), pa, None, (1, 64), y, hip.view_plain(H, W, 64), B, H, W, 128, 64,
+                     relu=ops.LEAKY, select=sel)
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    # masked weight gradients vs the full ones on the blocks that are read back
+    dy2 = torch.randn(B, 128, H, W, generator=g).cuda().contiguous(memory_format=cl)
+    full, part = torch.empty(128, 64, 3, 3, device="cuda"), torch.full((128, 64, 3, 3), float("nan"), device="cuda")
+    bf, bp = torch.empty(128, device="cuda"), torch.empty(128, device="cuda")
+    ops.wgrad_c64(t, hip.view_plain(H, W, 64), dy2, hip.view_plain(H, W, 128), full, bf, B, H, W, 64, 128)
+    ops.wgrad_c64(t, hip.view_plain(H, W, 64), dy2, hip.view_plain(H, W, 128), part, bp, B, H, W, 64, 128, active_units=0xC3)
+    assert rel(part[:64, :32], full[:64, :32]) < 1e-6 and rel(part[64:, 32:], full[64:, 32:]) < 1e-6 and rel(bp, bf) < 1e-6
+    assert torch.isnan(part[:64, 32:]).all() and torch.isnan(part[64:, :32]).all()  # skipped blocks are not written
+    dt = torch.randn(B, 64, H, W, generator=g).cuda().contiguous(memory_format=cl)
+    full, part = torch.empty(64, 128, 3, 3, device="cuda"), torch.full((64, 128, 3, 3), float("nan"), device="cuda")
+    bf, bp = torch.empty(64, device="cuda"), torch.empty(64, device="cuda")
+    ops.wgrad_c64(cat, hip.view_plain(H, W, 128), dt, hip.view_plain(H, W, 64), full, bf, B, H, W, 128, 64)
+    ops.wgrad_c64(cat, hip.view_plain(H, W, 128), dt, hip.view_plain(H, W, 64), part, bp, B, H, W, 128, 64, active_units=0x3F)
+    assert rel(part[:, :96], full[:, :96]) < 1e-6 and rel(bp, bf) < 1e-6 and torch.isnan(part[:, 96:]).all()
+
+
+def test_sparse_select_codes_refuse_other_shapes():
+    x = torch.zeros(1, 64, 8, 32, device="cuda").contiguous(memory_format=torch.channels_last)
+    pf, _ = ops.pack_pair(torch.zeros(64, 64, 3, 3, device="cuda"))
+    for sel in (ops.SPARSE_BLOCK_DIAGONAL, ops.SPARSE_SECOND_CHUNK):
+        with pytest.raises(RuntimeError, match="unsupported"):
+            ops.conv_c64(x, hip.view_plain(8, 32, 64), pf, None, (1, 64), torch.empty_like(x), hip.view_plain(8, 32, 64), 1, 8, 32,
+                         64, 64, select=sel)
+
+
 def test_leaky_codes_are_refused_off_the_fp32_kernels():
     x = torch.zeros(1, 64, 8, 32, device="cuda").contiguous(memory_format=torch.channels_last)
     w = torch.zeros(64, 64, 3, 3, device="cuda")
