@@ -117,13 +117,7 @@ static int rgb_out_launch(RgbOutParams p, void* stream) {
   const int per_cu = lds > 80 * 1024 ? 1 : 2;
   long blocks = (p.ntiles + RGBO_WAVES - 1) / RGBO_WAVES;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
-  static bool attr_set = false;  // per instantiation; idempotent and constant: raises the kernel's dynamic-LDS cap once
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rgb_out_mfma_kernel<KS, OR>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return SISR_ERR_UNSUPPORTED;
-    attr_set = true;
-  }
+  SISR_ALLOW_LDS((rgb_out_mfma_kernel<KS, OR>), lds);
   hipLaunchKernelGGL((rgb_out_mfma_kernel<KS, OR>), dim3((unsigned)blocks), dim3(64 * RGBO_WAVES), lds, (hipStream_t)stream, p);
   return sisr_check_launch();
 }

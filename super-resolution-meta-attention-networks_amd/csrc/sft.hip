@@ -417,13 +417,7 @@ extern "C" int sisr_conv9_dgrad(const float* dy, const float* w, const float* le
   const int tiles_w = (W + 31) / 32, tiles_h = (H + D9_TR - 1) / D9_TR;
   const long ntiles = (long)B * tiles_h * tiles_w;
   const size_t lds = (D9_W2 + 4 + 3 * D9_HS) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv9_dgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return SISR_ERR_UNSUPPORTED;
-    attr_set = true;
-  }
+  SISR_ALLOW_LDS(conv9_dgrad_mfma_kernel, lds);
   hipLaunchKernelGGL(conv9_dgrad_mfma_kernel, dim3((unsigned)(ntiles < C9_GRID ? ntiles : C9_GRID)), dim3(256), lds,
                      (hipStream_t)stream, dy, w, leaky_mask, dx, B, H, W, tiles_w, tiles_h, ntiles);
   return sisr_check_launch();
