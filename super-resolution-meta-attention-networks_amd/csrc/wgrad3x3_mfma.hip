@@ -17,6 +17,7 @@
 // into the OIHW gradient.  Splitting the OUTPUT four ways instead of giving each wave a quadrant
 // cuts the slab traffic 4x (36.9 KB per workgroup) at the price of re-reading the inputs from L2.
 #include "sisr_common.h"
+#include <stdlib.h>
 
 #define WT_H 8
 #define WT_W 32
@@ -712,6 +713,9 @@ static View view_from(const int64_t* v) {
 static int wgrad_split(int B, int H, int W, int units) {
   const long tiles = (long)B * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
   long S = 512 / units;  // two workgroups per CU resident across the whole grid
+#ifdef SISR_DIAG
+  if (const char* e = getenv("SISR_DIAG_WGRAD_WGS")) S = atol(e) / units;  // A/B of the K-split (tools/kbench.py)
+#endif
   if (S < 1) S = 1;
   if (S > tiles) S = tiles;
   return (int)S;
