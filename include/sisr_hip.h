@@ -343,7 +343,8 @@ int sisr_pil_resample(const unsigned char* in, void* out, const int* bounds, con
  *   from the layer's eight parameters; split != 0: the reverse copy (gradients).  M = metadata maps (<= 64).
  * sisr_sft_combine_fwd: out = [relu](x * sigmoid(y2[:, :64]) + y2[:, 64:]); x / out with pixel strides (floats), y2
  *   [npix][128]; md (nullable) [npix][64] is copied into out's second 64-channel chunk.  _bwd: dx [npix][64], dy2.
- * sisr_map64: 64-channel maps with pixel strides: op 0 copy, 1 a + b, 2 LeakyReLU(a), 3 b * LeakyReLU'(a).
+ * sisr_map64: 64-channel maps with pixel strides: op 0 copy, 1 a + b, 2 LeakyReLU(a), 3 b * LeakyReLU'(a), 4 a * b,
+ *   5 ReLU(a), 6 b * ReLU'(a), 7 a * (b's channel 0, broadcast).
  * sisr_conv9_*: 9x9 conv 64 -> 3 (OIHW weight), x NHWC [B][H][W][64], y NCHW; dgrad optionally masked by LeakyReLU'
  *   of `leaky_mask` (the activated map that fed the conv); wgrad: ordered two-stage sums (dw OIHW, db).
  * sisr_clamp01: backward == 0: out = clamp(a, 0, 1); else out = grad * [0 <= a <= 1]. */

@@ -650,25 +650,44 @@ class Trainer:
 
 
 # ----------------------------------------------------------------------------- SFTMD (second half)
-def _sft_standard(sd, key, feat, para):
-    """StandardSft.  ref: SFTMD_variants/architectures.py:25-56 (mask_para False, repeats None)."""
-    cat = torch.cat((feat, para), dim=1)
+def _sft_standard(sd, key, feat, para, mask_para=False, repeats=None):
+    """StandardSft.  ref: SFTMD_variants/architectures.py:25-56."""
+    if repeats is not None:
+        para = para.repeat(1, repeats, 1, 1)
+    cat = feat if mask_para else torch.cat((feat, para), dim=1)
     mul = torch.sigmoid(conv(sd, key + ".mul_conv2", F.leaky_relu(conv(sd, key + ".mul_conv1", cat), 0.2)))
     add = conv(sd, key + ".add_conv2", F.leaky_relu(conv(sd, key + ".add_conv1", cat), 0.2))
     return feat * mul + add
 
 
-def sftmd(sd, x, para_maps, num_blocks=16, scale=4):
-    """ref: SFTMD_variants/architectures.py:110-176 (SFT_type 'standard', no q-injection); para_maps (B, M, H, W)."""
+def _sft_layer(sd, key, feat, para, sft_type, mask_para, repeats):
+    """SFT_Layer.  ref: SFTMD_variants/architectures.py:8-22 (ConcatSft, WeakSft), :59-77."""
+    if sft_type == "standard":
+        return _sft_standard(sd, key + ".sft_module", feat, para, mask_para, repeats)
+    if sft_type == "concat":
+        return conv(sd, key + ".sft_module.conv", torch.cat((feat, para), dim=1))
+    if sft_type == "weak":
+        return feat * para
+    if sft_type == "none":
+        return feat
+    raise ValueError(sft_type)
+
+
+def sftmd(sd, x, para_maps, num_blocks=16, scale=4, sft_type="standard", mask_para=False, repeats=None, q_injection=False,
+          q_layers=2):
+    """ref: SFTMD_variants/architectures.py:110-176; para_maps (B, M, H, W), or (B, M, 1, 1) vectors with q_injection
+    (SFTMD_variants/handlers.py:19-22, :35-41)."""
     lr = lambda t: F.leaky_relu(t, 0.2)  # noqa: E731
+    sft = lambda key, t: _sft_layer(sd, key, t, para_maps, sft_type, mask_para, repeats)  # noqa: E731
+    inject = (lambda key, t: para_ca_layer(sd, key, t, para_maps, True, q_layers)) if q_injection else (lambda key, t: t)
     bef = conv(sd, "conv3", lr(conv(sd, "conv2", lr(conv(sd, "conv1", x)))))
     fea = bef
     for i in range(num_blocks):
         k = f"SFT-residual{i + 1}"
-        f1 = F.relu(_sft_standard(sd, k + ".sft1.sft_module", fea, para_maps))
-        f2 = F.relu(_sft_standard(sd, k + ".sft2.sft_module", conv(sd, k + ".conv1", f1), para_maps))
+        f1 = inject(k + ".q_1", F.relu(sft(k + ".sft1", fea)))
+        f2 = inject(k + ".q_2", F.relu(sft(k + ".sft2", conv(sd, k + ".conv1", f1))))
         fea = fea + conv(sd, k + ".conv2", f2)
-    fin = _sft_standard(sd, "sft.sft_module", fea + bef, para_maps)
+    fin = inject("final_injection", sft("sft", fea + bef))
     up = conv(sd, "conv_mid", fin)
     if scale == 4:
         up = lr(F.pixel_shuffle(conv(sd, "upscale.0", up), 2))

@@ -147,6 +147,10 @@ extern "C" int sisr_sft_combine_bwd(const float* dout, long dout_stride, const f
 // op 1: out = a + b                  (fea_mid + fea_bef; gradient sums)
 // op 2: out = leaky(a)               (a > 0 ? a : 0.2 a)
 // op 3: out = b * (a > 0 ? 1 : 0.2)  (LeakyReLU backward: a = the activation's output, b = incoming gradient)
+// op 4: out = a * b                  (WeakSft with as many maps as features, and its input gradient)
+// op 5: out = relu(a)
+// op 6: out = a > 0 ? b : 0          (ReLU backward: a = the activation's output)
+// op 7: out = a * b[channel 0]       (WeakSft with one map: b's first channel broadcast over the 64 features)
 __global__ __launch_bounds__(256) void map64_kernel(const float* a, long as, const float* b, long bs,
                                                     float* out, long os, long npix, int op) {
   const long total = npix * 16;
@@ -164,6 +168,17 @@ __global__ __launch_bounds__(256) void map64_kernel(const float* a, long as, con
       const f32x4 bv = *reinterpret_cast<const f32x4*>(b + p * bs + c4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = av[e] > 0.f ? bv[e] : 0.2f * bv[e];
+    } else if (op == 4) {
+      o = av * *reinterpret_cast<const f32x4*>(b + p * bs + c4);
+    } else if (op == 5) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(av[e], 0.f);
+    } else if (op == 6) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(b + p * bs + c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = av[e] > 0.f ? bv[e] : 0.f;
+    } else if (op == 7) {
+      o = av * b[p * bs];
     }
     *reinterpret_cast<f32x4*>(out + p * os + c4) = o;
   }
@@ -171,7 +186,7 @@ __global__ __launch_bounds__(256) void map64_kernel(const float* a, long as, con
 
 extern "C" int sisr_map64(const float* a, long a_stride, const float* b, long b_stride, float* out, long out_stride, long npix,
                           int op, void* stream) {
-  if (!a || !out || npix <= 0 || op < 0 || op > 3 || ((op == 1 || op == 3) && !b)) return SISR_ERR_ARG;
+  if (!a || !out || npix <= 0 || op < 0 || op > 7 || ((op == 1 || op == 3 || op == 4 || op == 6 || op == 7) && !b)) return SISR_ERR_ARG;
   if ((a_stride & 3) || (out_stride & 3) || (b && (b_stride & 3)) || a_stride < 64 || out_stride < 64) return SISR_ERR_ARG;
   if (!sisr_aligned16(a) || !sisr_aligned16(b) || !sisr_aligned16(out)) return SISR_ERR_ALIGN;
   hipLaunchKernelGGL(map64_kernel, dim3(sft_blocks(npix * 16)), dim3(256), 0, (hipStream_t)stream, a, a_stride, b, b_stride, out,

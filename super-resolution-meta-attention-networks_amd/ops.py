@@ -1322,6 +1322,100 @@ def sft_layer(x, md, module, relu):
     return _SftLayer.apply(x, md, bool(relu), int(M), *module.params())
 
 
+class _Map64(Function):
+    """Elementwise pieces of the non-default SFT types on channels-last 64-channel maps (csrc/sft.hip map64):
+    mode 'relu': relu(x); 'mul': x * md (WeakSft, 64 maps); 'mul0': x * md[:, 0:1] (WeakSft, one map).  md has no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, md, mode):
+        B, C, H, W = x.shape
+        if C != 64:
+            raise NotImplementedError("64-channel maps")
+        x = _cl(x)
+        out = _empty_cl(B, 64, H, W, x.device)
+        npix = B * H * W
+        if mode == "relu":
+            _map64(x, 64, None, 0, out, 64, npix, 5)
+            ctx.save_for_backward(out)
+        else:
+            md = _cl(md)
+            _map64(x, 64, md, 64, out, 64, npix, 4 if mode == "mul" else 7)
+            ctx.save_for_backward(md)
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (t,) = ctx.saved_tensors
+        B, C, H, W = dy.shape
+        dy = _cl(dy)
+        dx = _empty_cl(B, 64, H, W, dy.device)
+        if ctx.mode == "relu":
+            _map64(t, 64, dy, 64, dx, 64, B * H * W, 6)
+        else:
+            _map64(dy, 64, t, 64, dx, 64, B * H * W, 4 if ctx.mode == "mul" else 7)
+        return dx, None, None
+
+
+class _ConcatSft(Function):
+    """conv3x3(cat(x, maps)) (ref: SFTMD_variants/architectures.py:8-14) as one 128 -> 64 MFMA conv over the (features | maps)
+    map, weight zero-padded per call; only the feature half of the input gradient is computed."""
+
+    @staticmethod
+    def forward(ctx, x, md, w, b):
+        _fp32_only("SFT layer")
+        B, C, H, W = x.shape
+        M = w.shape[1] - 64
+        if C != 64 or tuple(w.shape) != (64, 64 + M, 3, 3) or not 0 <= M <= 64:
+            raise NotImplementedError("ConcatSft: 64 features, at most 64 metadata maps")
+        dev, npix = x.device, B * H * W
+        cat = _empty_cl(B, 128, H, W, dev)
+        _map64(_cl(x), 64, None, 0, cat, 128, npix, 0)
+        _map64(_cl(md), 64, None, 0, cat, 128, npix, 0, out_off=64)
+        pf, pd = pack_pair(_pad_oihw(w, 64, 128))
+        y = _empty_cl(B, 64, H, W, dev)
+        conv_c64(cat, hip.view_plain(H, W, 128), pf, b, (1, 64), y, hip.view_plain(H, W, 64), B, H, W, 128, 64)
+        ctx.save_for_backward(cat)
+        ctx.pd, ctx.cfg = pd, (B, H, W, tuple(w.shape), b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        global IN_BACKWARD
+        IN_BACKWARD = True
+        try:
+            (cat,) = ctx.saved_tensors
+            B, H, W, wshape, has_b = ctx.cfg
+            dev = dy.device
+            dy = _cl(dy)
+            v64, v128 = hip.view_plain(H, W, 64), hip.view_plain(H, W, 128)
+            dwp = torch.empty((64, 128, 3, 3), device=dev)
+            db = torch.empty(64, device=dev) if has_b else None
+            wgrad_c64(cat, v128, dy, v64, dwp, db, B, H, W, 128, 64)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = _empty_cl(B, 64, H, W, dev)
+                conv_c64(dy, v64, ctx.pd, None, (1, 64), dx, v64, B, H, W, 64, 64)  # output chunk 0 of the packing = d features
+            return dx, None, _crop_oihw(dwp, wshape), db
+        finally:
+            IN_BACKWARD = False
+
+
+def sft_apply(x, md, layer, relu):
+    """One SFT_Layer (sftmd.SFT_Layer: 'standard' / 'concat' / 'weak' / 'none', ref: SFTMD_variants/architectures.py:59-77)
+    followed by the block's F.relu when `relu`."""
+    kind = layer.kind
+    if kind == "standard":
+        return sft_layer(x, md, layer.sft_module, relu)
+    if kind == "concat":
+        y = _ConcatSft.apply(x, md, layer.sft_module.conv.weight, layer.sft_module.conv.bias)
+    elif kind == "weak":
+        y = _Map64.apply(x, md, "mul0" if layer.maps == 1 else "mul")
+    else:
+        y = x
+    return _Map64.apply(y, None, "relu") if relu else y
+
+
 class _SftmdHead(Function):
     """fea_bef = conv3(leaky(conv2(leaky(conv1(x))))) (ref: SFTMD_variants/architectures.py:162): x NCHW RGB."""
 
@@ -1479,21 +1573,36 @@ class _SftmdTail(Function):
 
 
 def sftmd_forward(net, x, metadata):
-    """The whole SFTMD network (sftmd.SFTMD holds the parameters; ref: SFTMD_variants/architectures.py:161-176)."""
+    """The whole SFTMD network (sftmd.SFTMD holds the parameters; ref: SFTMD_variants/architectures.py:161-176).  metadata:
+    (B, M, H, W) maps -- or, with q_injection, the (B, M, 1, 1) vectors the reference's handler then supplies (:19-22)."""
     _fp32_only("SFTMD")
     B, _, H, W = x.shape
-    if metadata.dim() != 4 or metadata.shape[0] != B or metadata.shape[1] != net.para or tuple(metadata.shape[2:]) != (H, W):
-        raise RuntimeError(f"SFTMD: metadata maps must be (B, {net.para}, H, W); got {tuple(metadata.shape)}")
-    md = nchw_to_nhwc_pad(metadata.detach().float(), 64)
+    if net.uses_maps:
+        if metadata.dim() != 4 or metadata.shape[0] != B or metadata.shape[1] != net.para or tuple(metadata.shape[2:]) != (H, W):
+            raise RuntimeError(f"SFTMD: metadata maps must be (B, {net.para}, H, W); got {tuple(metadata.shape)}")
+        maps = metadata.detach().float()
+        if net.repeats is not None:
+            maps = maps.repeat(1, net.repeats, 1, 1)  # input formatting (ref: StandardSft.forward :46-47)
+        md = nchw_to_nhwc_pad(maps, 64)
+    else:  # the SFT layers never look at the maps: a zero map stands in for the (all-zero-weight) metadata chunk
+        md = _empty_cl(B, 64, H, W, x.device).zero_()
+    q = net.q_injection
+    if q and (metadata.dim() != 4 or tuple(metadata.shape[1:]) != (net.para, 1, 1)):
+        raise RuntimeError(f"SFTMD with q_injection: metadata must be (B, {net.para}, 1, 1) vectors; got {tuple(metadata.shape)}")
     fea_bef = _SftmdHead.apply(x, net.conv1.weight, net.conv1.bias, net.conv2.weight, net.conv2.bias, net.conv3.weight,
                                net.conv3.bias)
     fea = fea_bef
     for blk in net.blocks():
-        f1 = sft_layer(fea, md, blk.sft1.sft_module, True)
-        c1 = conv3x3(f1, blk.conv1.weight, blk.conv1.bias)
-        f2 = sft_layer(c1, md, blk.sft2.sft_module, True)
+        f1 = sft_apply(fea, md, blk.sft1, True)
+        if q:
+            f1 = gate_mul(f1, blk.q_1.gate(metadata))
+        f2 = sft_apply(conv3x3(f1, blk.conv1.weight, blk.conv1.bias), md, blk.sft2, True)
+        if q:
+            f2 = gate_mul(f2, blk.q_2.gate(metadata))
         fea = conv3x3(f2, blk.conv2.weight, blk.conv2.bias, residual=fea)
-    fea_fin = sft_layer(add_residual(fea, fea_bef), md, net.sft.sft_module, False)
+    fea_fin = sft_apply(add_residual(fea, fea_bef), md, net.sft, False)
+    if q:
+        fea_fin = gate_mul(fea_fin, net.final_injection.gate(metadata))
     convs = [m for m in net.upscale if isinstance(m, torch.nn.Conv2d)]
     params = [net.conv_mid.weight, net.conv_mid.bias]
     for c in convs:

@@ -4,6 +4,7 @@ Fixtures: tools/make_fixtures_sftmd.py ran the reference (SFTMD_variants/archite
 SFTMD_variants/handlers.py:6-60): f1 reduced net (weights = seed-8 init, pinned by digest), f2 full-depth init digest +
 Set5 run_eval, f3 five run_train steps."""
 import numpy as np
+import pytest
 import torch
 
 import sisr_amd
@@ -80,3 +81,44 @@ def test_f3_oracle_trajectory_matches_the_reference():
         assert abs(loss - step["loss"]) < 2e-6 and abs(gn / step["grad_norm"] - 1) < 2e-4
         assert abs(float(out.mean()) - step["out_mean"]) < 1e-5 and abs(tr.lr - step["lr_after"]) < 1e-12
     assert abs(float(sum(v.double().sum() for v in tr.sd.values())) - ref["final_param_sum"]) < 1e-3
+
+
+VARIANTS = {  # tools/make_fixtures_sftmd.py VARIANTS: SFTMD kwargs, metadata as vectors (q_injection) instead of maps
+    "concat": (dict(SFT_type="concat", input_para=10), False),
+    "weak1": (dict(SFT_type="weak", input_para=1), False),
+    "none_q": (dict(SFT_type="none", q_injection=True, q_layers=2, input_para=10), True),
+    "maskpara_q3": (dict(mask_para=True, q_injection=True, q_layers=3, input_para=10), True),
+    "repeats3": (dict(repeats=3, input_para=10), False),
+}
+
+
+def variant_net(name):
+    kw, vector = VARIANTS[name]
+    torch.manual_seed(8)
+    return sisr_amd.sftmd.SFTMD(in_nc=3, num_features=64, num_blocks=2, scale=2, **kw), kw, vector
+
+
+def variant_inputs(a, name, vector):
+    x, md = torch.from_numpy(a[f"{name}/in0"]), torch.from_numpy(a[f"{name}/in1"])
+    return x, (md if vector else md.expand(-1, -1, x.shape[2], x.shape[3]).contiguous())
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_f4_non_default_options_oracle_and_init(name):
+    """SFT_type 'concat' / 'weak' / 'none', mask_para, repeats, q_injection (ref: SFTMD_variants/architectures.py:8-22, :25-56,
+    :80-107, :130-136): same seed-8 weights as the reference, and the oracle reproduces its output and gradients."""
+    a = np.load(f"{sisr_amd.__path__[0]}/../tests/golden/f4_sftmd_variants.npz")
+    net, kw, vector = variant_net(name)
+    assert digest(net.state_dict()) == str(a[f"{name}/sd_sha256"]), "seed-8 init differs from the reference's"
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    x, md = variant_inputs(a, name, vector)
+    cfg = {k: v for k, v in kw.items() if k != "input_para"}
+    cfg["sft_type"] = cfg.pop("SFT_type", "standard")
+    out = O.sftmd(sd, x, md, num_blocks=2, scale=2, **cfg)
+    np.testing.assert_allclose(out.detach().numpy(), a[f"{name}/out"], rtol=1e-5, atol=1e-6)
+    out.backward(torch.from_numpy(a[f"{name}/cot"]))
+    keys = [k[len(name) + 5:] for k in a.files if k.startswith(name + "/pgn/")]
+    assert keys and all(sd[k].grad is not None for k in keys)
+    for k in keys:
+        gn = float(a[f"{name}/pgn/{k}"])
+        assert abs(float(sd[k].grad.double().norm()) - gn) <= 1e-4 * gn + 1e-12, k

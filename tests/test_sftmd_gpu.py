@@ -9,7 +9,7 @@ import sisr_amd
 from sisr_amd import hip, ops
 from conftest import golden_json, load_golden
 from test_init_parity import set5
-from test_oracle_sftmd import PARAMS, reduced_net
+from test_oracle_sftmd import PARAMS, VARIANTS, reduced_net, variant_inputs, variant_net
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(ops.PRECISION != "fp32", reason="SFTMD runs on the fp32 kernels only (SISR_PRECISION is set)")]
@@ -195,6 +195,33 @@ def test_other_scales_vs_oracle(scale):
     out.backward(cot.cuda())
     for k, p in net.named_parameters():
         assert rel(p.grad, sd[k].grad) < 5e-5, k
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_f4_non_default_options_vs_reference(name):
+    """SFT_type 'concat' / 'weak' / 'none', mask_para, repeats, q_injection with 2 and 3 FC layers (fixture f4: the reference's
+    output and per-parameter gradient norms / leading values on reduced x2 nets).
+
+    'weak1' is compared at 1e-3: one of the 59 904 pre-activations of the upscale stage's LeakyReLU lies within 2.3e-7 of zero
+    (|x| up to 0.24) and the MFMA conv's summation order lands on the other side of it than the reference's (measured: 1 sign
+    flip vs a float64 evaluation, torch fp32 0; the kernels fed the reference's own activations agree to 2e-7).  With 74 % of
+    the outputs clamped the gradient is sparse, and that single mask element moves every upstream gradient by 2e-3."""
+    tol = 1e-3 if name == "weak1" else 2e-4
+    a = np.load(f"{sisr_amd.__path__[0]}/../tests/golden/f4_sftmd_variants.npz")
+    net, kw, vector = variant_net(name)
+    net.to("cuda:0")
+    x, md = variant_inputs(a, name, vector)
+    out = net(x.cuda(), md.cuda())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), a[f"{name}/out"], rtol=2e-4, atol=2e-5)
+    out.backward(torch.from_numpy(a[f"{name}/cot"]).cuda())
+    named = dict(net.named_parameters())
+    keys = [k[len(name) + 5:] for k in a.files if k.startswith(name + "/pgn/")]
+    assert sorted(keys) == sorted(k for k, p in named.items() if p.grad is not None)
+    for k in keys:
+        gn = float(a[f"{name}/pgn/{k}"])
+        assert abs(float(named[k].grad.double().norm()) - gn) <= tol * gn + 1e-10, k
+        np.testing.assert_allclose(named[k].grad.reshape(-1)[:8].cpu().numpy(), a[f"{name}/pg8/{k}"], rtol=25 * tol,
+                                   atol=25 * tol * gn / np.sqrt(named[k].numel()) + 1e-9, err_msg=k)
 
 
 def test_f2_set5_forward_psnr_parity_with_reference():

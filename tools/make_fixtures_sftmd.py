@@ -8,6 +8,8 @@ f1  reduced net (2 blocks, seed-8 init -- the weights are NOT stored: the builde
     norm and its first 32 values
 f2  full-depth (16 blocks) seed-8 init digest + handler.run_eval on two Set5 images with their blur-kernel metadata
 f3  five handler.run_train steps
+f4  the non-default options on reduced nets (2 blocks, x2): SFT_type 'concat' / 'weak' / 'none' + q_injection, mask_para +
+    q_injection, repeats -- output and per-parameter gradient norms (+ leading values)
 """
 import json
 import os
@@ -97,8 +99,47 @@ def make_f3():
     return {"steps": steps, "final_param_sum": float(sum(v.double().sum() for v in sdv.values())), **sched}
 
 
+VARIANTS = {  # name: (SFTMD kwargs, metadata is per-sample vectors (q_injection) instead of maps)
+    "concat": (dict(SFT_type="concat", input_para=10), False),
+    "weak1": (dict(SFT_type="weak", input_para=1), False),
+    "none_q": (dict(SFT_type="none", q_injection=True, q_layers=2, input_para=10), True),
+    "maskpara_q3": (dict(mask_para=True, q_injection=True, q_layers=3, input_para=10), True),
+    "repeats3": (dict(repeats=3, input_para=10), False),
+}
+
+
+def make_f4():
+    blob = {}
+    for name, (kw, vector) in VARIANTS.items():
+        torch.manual_seed(8)
+        net = SFTMD(in_nc=3, num_features=64, num_blocks=2, scale=2, **kw)
+        M = kw["input_para"]
+        x = rnd(2, 3, 9, 13, seed=91, scale=0.3, grad=False) + 0.5
+        md = rnd(2, M, 1, 1, seed=92, scale=0.3, grad=False) + (1.0 if name == "weak1" else 0.0)
+        if not vector:
+            md = md.expand(2, M, 9, 13).contiguous()
+        out = net(x, md)
+        cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(93))
+        out.backward(cot)
+        blob[f"{name}/out"], blob[f"{name}/cot"] = _np(out), _np(cot)
+        blob[f"{name}/in0"], blob[f"{name}/in1"] = _np(x), _np(md[:, :, :1, :1])  # maps are the vector, expanded
+        blob[f"{name}/sd_sha256"] = np.array(MF.sd_digest(net.state_dict()))
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                continue
+            blob[f"{name}/pgn/{k}"] = np.array(float(p.grad.double().norm()))
+            blob[f"{name}/pg8/{k}"] = _np(p.grad.reshape(-1)[:8])
+        print("f4", name, "out", tuple(out.shape), "params with grad", sum(p.grad is not None for p in net.parameters()),
+              "clamped", float(((out <= 0) | (out >= 1)).float().mean()))
+    np.savez_compressed(os.path.join(OUT, "f4_sftmd_variants.npz"), **blob)
+
+
 if __name__ == "__main__":
+    if "--variants-only" in sys.argv:
+        make_f4()
+        sys.exit(0)
     make_f1()
+    make_f4()
     doc = {"full_depth": make_f2(), "train_steps": make_f3(), "params": PARAMS}
     with open(os.path.join(OUT, "f_sftmd.json"), "w") as f:
         json.dump(doc, f, indent=1)
