@@ -265,6 +265,12 @@ def view_plain(H, W, C, sB=None):
     return v
 
 
+def view_pair(H, W, second_offset):
+    """Two 64-channel NHWC tensors of identical layout read as ONE 128-channel map: chunk 0 at the base pointer, chunk 1
+    `second_offset` floats away (a multiple of 4; the tensors may be separate allocations) -- torch.cat without the copy."""
+    return (c_int64 * 6)(H * W * 64, W * 64, 64, second_offset, 0, 1)
+
+
 def view_maps(H, W, nmaps, sB=None):
     """[B][nmaps][H][W][64] stack read as an NHWC tensor with nmaps*64 channels (chunk q = map q)."""
     key = ("m", H, W, nmaps, sB)

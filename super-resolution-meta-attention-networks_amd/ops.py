@@ -1245,7 +1245,8 @@ class _SftLayer(Function):
     SFT_Residual_Block.forward :100-102 folded in).  Two MFMA convs instead of four: A = [mul_conv1 | add_conv1] merged
     along the outputs (128 -> 64, LeakyReLU epilogue), B = block-diagonal [mul_conv2, add_conv2] (64 -> 128); the merged
     weights are composed per call from the four parameters and their gradients split back.  md: channels-last
-    [B, 64, H, W], the M metadata maps zero-padded (no gradient)."""
+    [B, 64, H, W], the M metadata maps zero-padded (no gradient); torch.cat((x, maps)) is never materialised: conv A and its
+    weight gradient read the pair through a view whose second chunk points at md (hip.view_pair)."""
 
     @staticmethod
     def forward(ctx, x, md, relu, M, mw1, mb1, aw1, ab1, mw2, mb2, aw2, ab2):
@@ -1255,9 +1256,12 @@ class _SftLayer(Function):
             raise NotImplementedError("SFT layer: 64 features, 32 hidden channels, at most 64 metadata maps")
         dev, npix = x.device, B * H * W
         x, md = _cl(x), _cl(md)
-        cat = _empty_cl(B, 128, H, W, dev)
-        _map64(x, 64, None, 0, cat, 128, npix, 0)
-        _map64(md, 64, None, 0, cat, 128, npix, 0, out_off=64)
+        # cat(x, maps) is never built: the conv reads chunk 0 from x and chunk 1 from the (shared) metadata map through the
+        # view's chunk offset -- two allocations, one logical 128-channel input
+        diff = md.data_ptr() - x.data_ptr()
+        if diff % 16:
+            raise RuntimeError("SFT layer: feature and metadata maps must be 16-byte aligned relative to each other")
+        vcat = hip.view_pair(H, W, diff // 4)
         WA = torch.empty((64, 128, 3, 3), device=dev)
         bA = torch.empty(64, device=dev)
         WB = torch.empty((128, 64, 3, 3), device=dev)
@@ -1266,15 +1270,15 @@ class _SftLayer(Function):
         pfA, pdA = pack_pair(WA)
         pfB, pdB = pack_pair(WB)
         t = _empty_cl(B, 64, H, W, dev)
-        conv_c64(cat, hip.view_plain(H, W, 128), pfA, bA, (1, 64), t, hip.view_plain(H, W, 64), B, H, W, 128, 64, relu=LEAKY,
+        conv_c64(x, vcat, pfA, bA, (1, 64), t, hip.view_plain(H, W, 64), B, H, W, 128, 64, relu=LEAKY,
                  select=SPARSE_SECOND_CHUNK if M <= 16 else 0)
         y2 = _empty_cl(B, 128, H, W, dev)
         conv_c64(t, hip.view_plain(H, W, 64), pfB, bB, (1, 64), y2, hip.view_plain(H, W, 128), B, H, W, 64, 128,
                  select=SPARSE_BLOCK_DIAGONAL)
         out = _empty_cl(B, 64, H, W, dev)
-        hip.check(hip.lib().sisr_sft_combine_fwd(hip.ptr(cat), 128, hip.ptr(y2), None, hip.ptr(out), 64, npix, int(relu),
+        hip.check(hip.lib().sisr_sft_combine_fwd(hip.ptr(x), 64, hip.ptr(y2), None, hip.ptr(out), 64, npix, int(relu),
                                                  hip.stream()), "sisr_sft_combine_fwd")
-        ctx.save_for_backward(cat, t, y2)
+        ctx.save_for_backward(x, md, t, y2)
         ctx.packs = (pdA, pdB)
         ctx.cfg = (B, H, W, int(relu), M)
         return out
@@ -1284,15 +1288,16 @@ class _SftLayer(Function):
         global IN_BACKWARD
         IN_BACKWARD = True
         try:
-            cat, t, y2 = ctx.saved_tensors
+            x, md, t, y2 = ctx.saved_tensors
             pdA, pdB = ctx.packs
             B, H, W, relu, M = ctx.cfg
+            vcat = hip.view_pair(H, W, (md.data_ptr() - x.data_ptr()) // 4)
             dev, npix = dout.device, B * H * W
             dout = _cl(dout)
             v64, v128 = hip.view_plain(H, W, 64), hip.view_plain(H, W, 128)
             dx0 = _empty_cl(B, 64, H, W, dev)
             dy2 = _empty_cl(B, 128, H, W, dev)
-            hip.check(hip.lib().sisr_sft_combine_bwd(hip.ptr(dout), 64, hip.ptr(cat), 128, hip.ptr(y2), hip.ptr(dx0),
+            hip.check(hip.lib().sisr_sft_combine_bwd(hip.ptr(dout), 64, hip.ptr(x), 64, hip.ptr(y2), hip.ptr(dx0),
                                                      hip.ptr(dy2), npix, relu, hip.stream()), "sisr_sft_combine_bwd")
             dWB = torch.empty((128, 64, 3, 3), device=dev)
             dbB = torch.empty(128, device=dev)
@@ -1302,7 +1307,7 @@ class _SftLayer(Function):
             dWA = torch.empty((64, 128, 3, 3), device=dev)
             dbA = torch.empty(64, device=dev)
             # input channels >= 96 are padding when M <= 32: the last ci half of the second chunk is never read back
-            wgrad_c64(cat, v128, dt, v64, dWA, dbA, B, H, W, 128, 64, active_units=0x3F if M <= 32 else 0)
+            wgrad_c64(x, vcat, dt, v64, dWA, dbA, B, H, W, 128, 64, active_units=0x3F if M <= 32 else 0)
             dx = None
             if ctx.needs_input_grad[0]:
                 # input gradient of A for the 64 feature channels only (output chunk 0 of the packing) + the direct term
@@ -1368,14 +1373,15 @@ class _ConcatSft(Function):
         M = w.shape[1] - 64
         if C != 64 or tuple(w.shape) != (64, 64 + M, 3, 3) or not 0 <= M <= 64:
             raise NotImplementedError("ConcatSft: 64 features, at most 64 metadata maps")
-        dev, npix = x.device, B * H * W
-        cat = _empty_cl(B, 128, H, W, dev)
-        _map64(_cl(x), 64, None, 0, cat, 128, npix, 0)
-        _map64(_cl(md), 64, None, 0, cat, 128, npix, 0, out_off=64)
+        dev = x.device
+        x, md = _cl(x), _cl(md)
+        diff = md.data_ptr() - x.data_ptr()
+        if diff % 16:
+            raise RuntimeError("ConcatSft: feature and metadata maps must be 16-byte aligned relative to each other")
         pf, pd = pack_pair(_pad_oihw(w, 64, 128))
         y = _empty_cl(B, 64, H, W, dev)
-        conv_c64(cat, hip.view_plain(H, W, 128), pf, b, (1, 64), y, hip.view_plain(H, W, 64), B, H, W, 128, 64)
-        ctx.save_for_backward(cat)
+        conv_c64(x, hip.view_pair(H, W, diff // 4), pf, b, (1, 64), y, hip.view_plain(H, W, 64), B, H, W, 128, 64)
+        ctx.save_for_backward(x, md)
         ctx.pd, ctx.cfg = pd, (B, H, W, tuple(w.shape), b is not None)
         return y
 
@@ -1384,14 +1390,14 @@ class _ConcatSft(Function):
         global IN_BACKWARD
         IN_BACKWARD = True
         try:
-            (cat,) = ctx.saved_tensors
+            x, md = ctx.saved_tensors
             B, H, W, wshape, has_b = ctx.cfg
             dev = dy.device
             dy = _cl(dy)
-            v64, v128 = hip.view_plain(H, W, 64), hip.view_plain(H, W, 128)
+            v64 = hip.view_plain(H, W, 64)
             dwp = torch.empty((64, 128, 3, 3), device=dev)
             db = torch.empty(64, device=dev) if has_b else None
-            wgrad_c64(cat, v128, dy, v64, dwp, db, B, H, W, 128, 64)
+            wgrad_c64(x, hip.view_pair(H, W, (md.data_ptr() - x.data_ptr()) // 4), dy, v64, dwp, db, B, H, W, 128, 64)
             dx = None
             if ctx.needs_input_grad[0]:
                 dx = _empty_cl(B, 64, H, W, dev)
