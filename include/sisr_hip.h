@@ -83,9 +83,10 @@ typedef struct {
 size_t sisr_ca_tail_bytes(void);
 /* select: 0 (= 4) issue-lean kernel, tile height chosen by grid size, general kernel as fallback; 5 / 6 the same with
  * the 4-row / 2-row tile forced (bit-identical results; A/B measurements and tests); 2 general kernel only.
- * 8 / 9: the caller asserts structural zeros in the packed weight (SFTMD's merged convs) and the kernel skips them:
+ * 8 / 9 / 10: the caller asserts structural zeros in the packed weight (SFTMD's merged convs) and the kernel skips them:
  *   8  64 -> 128 block-diagonal (output chunk q contracts input channels 32q .. 32q+31 only), plain epilogue;
- *   9  128 -> 64 whose input channels >= 80 are zero (second chunk: first 16 channels only), LeakyReLU epilogue. */
+ *   9  128 -> 64 whose input channels >= 80 are zero (second chunk: first 16 channels only), LeakyReLU epilogue;
+ *  10  128 -> 64, the transpose of 8 (input chunk c feeds output channels 32c .. 32c+31 only), LeakyReLU' mask, no bias. */
 /* gate_add / gate_out / dot (all nullable; 64 -> 64, x and y in one layout) fuse the gated-residual chain of
  * RCAB / QRCAB stacks (ref: advanced/architectures.py:68-71, :107-110) into the neighbouring convs:
  *   gate_add + gate_out : the conv reads  x * in_scale[b,c] + gate_add  (the previous block's `res * y + x`) and

@@ -286,11 +286,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
 // KSEL (SFTMD's merged convs, whose weights are structurally sparse; every other caller: 0 = the dense code path, untouched):
 //   1  block-diagonal 64 -> 128: output chunk q contracts input channels 32q .. 32q+31 only (4 of 8 octets per tap)
 //   2  128 -> 64 whose second input chunk carries at most 16 channels (2 of 8 octets per tap)
-// The skipped products are exact zeros, so results are those of the dense kernel on the zero-padded weights.  (The
-// transpose of 1 -- input chunk c feeds output channels 32c .. 32c+31 only -- was tried as "the other two waves skip the
-// chunk": a wave-uniform branch around the unrolled K loop cost 118 spilled VGPRs; it stays on the dense kernel.)
+//   3  the transpose of 1, 128 -> 64: input chunk c feeds output channels 32c .. 32c+31 only.  2-row tiles (MT = 1) with
+//      BOTH chunks' halos resident (2 x 34.8 KB): wave (row, half) runs one K loop over its own half's chunk -- no
+//      branch ("the other two waves skip the chunk" was a wave-uniform branch around the unrolled K loop: 118 spilled VGPRs)
+// The skipped products are exact zeros, so results are those of the dense kernel on the zero-padded weights.
 template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false, bool LEAKY = false, int KSEL = 0>
-__global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x3_c64_v4_kernel(ConvParams p) {
   constexpr int THv = 2 * MT, HHv = THv + 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -323,11 +324,42 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
   for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      aoff[kw][j] = ((MT * ph) * HALO_W + n + kw) * 64 + (((2 * (KSEL == 1 ? (j & 3) + 4 * q : j) + hh) ^ ((n + kw) & 15)) << 2);
+      aoff[kw][j] = ((MT * ph) * HALO_W + n + kw) * 64 + (((2 * (KSEL == 1 ? (j & 3) + 4 * q : j) + hh) ^ ((n + kw) & 15)) << 2) +
+                    (KSEL == 3 ? ch * (HHv * HALO_W * 64) : 0);
   const unsigned boff = hh * 256 + co * 4;
 
-  for (int c = 0; c < p.cin_chunks; ++c) {
-    if (c) __syncthreads();
+  int c_begin = 0;
+  if constexpr (KSEL == 3) {
+    // chunk 0's halo goes to LDS here, chunk 1's in the (single) pass of the loop below into the second half: then one
+    // barrier and one K loop per wave, over the chunk of its own channel half
+    const int c4 = tid & 15, pcol = tid >> 4;
+    const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(0);
+    f32x4 v[HHv][3];
+#pragma unroll
+    for (int r = 0; r < HHv; ++r) {
+      const float* xrow = xb + (long)min(max(h0 - 1 + r, 0), H - 1) * p.xv.sH;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int gw = w0 - 1 + pcol + 16 * k;
+        if (k < 2 || pcol < 2) v[r][k] = *reinterpret_cast<const f32x4*>(xrow + (long)min(max(gw, 0), W - 1) * p.xv.sW + c4 * 4);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < HHv; ++r) {
+      const int gh = h0 - 1 + r;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int col = pcol + 16 * k, gw = w0 - 1 + col;
+        if (k < 2 || pcol < 2)
+          *reinterpret_cast<f32x4*>(lds + r * (HALO_W * 64) + col * 64 + ((c4 ^ (col & 15)) << 2)) =
+              sisr_keep_if(v[r][k], gh >= 0 && gh < H && gw >= 0 && gw < W);
+      }
+    }
+    c_begin = 1;
+  }
+  for (int c = c_begin; c < p.cin_chunks; ++c) {
+    if (KSEL != 3 && c) __syncthreads();
+    float* ldsc = lds + (KSEL == 3 ? c * (HHv * HALO_W * 64) : 0);  // KSEL 3: both chunks' halos are resident
     {  // ---- halo staging: thread = (chunk c4, column pcol + {0,16,32}), rows 0..5
       int tl = tid;
       asm volatile("" : "+v"(tl));  // keep the per-chunk address math out of the K loop's live ranges
@@ -367,7 +399,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
             if (k < 2 || pcol < 2) {
               f32x4 t = v[r][k];
               if (AFFINE) t = t * s4 + t4;
-              *reinterpret_cast<f32x4*>(lds + r * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
+              *reinterpret_cast<f32x4*>(ldsc + r * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
             }
         }
       } else {  // y = t * gate + skip on the fly; rows in batches of HHv / 2 (two operand tensors in flight)
@@ -447,6 +479,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void conv3x3_c64_v4_kernel(Co
       };
       if constexpr (KSEL == 1) {
         kloop(std::integral_constant<int, 4>{}, wq + (long)q * (4 * 512));
+      } else if constexpr (KSEL == 3) {
+        kloop(std::integral_constant<int, 8>{}, p.w + ((long)q * p.cin_chunks + ch) * (9 * 64 * 64));
       } else {
         if (c == 0) kloop(std::integral_constant<int, 8>{}, wq);
         else kloop(std::integral_constant<int, 2>{}, wq);
@@ -1763,9 +1797,9 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   // select (per call; the library keeps no state): 0 / 4 = issue-lean kernel, tile height by grid size, general kernel
   // as fallback; 5 / 6 = the same with the 4-row / 2-row tile forced (A/B measurements, bit-identical results);
   // 2 = general kernel only.  Diagnostic builds (-DSISR_DIAG) add 13 / 16.
-  // 8 / 9 = structurally sparse weights (SFTMD's merged convs; KSEL 1 / 2 of conv3x3_c64_v4_kernel): the caller asserts
-  // that the skipped blocks of the packed weight are zero
-  const int ksel = (select == 8 || select == 9) ? select - 7 : 0;
+  // 8 / 9 / 10 = structurally sparse weights (SFTMD's merged convs; KSEL 1 / 2 / 3 of conv3x3_c64_v4_kernel): the caller
+  // asserts that the skipped blocks of the packed weight are zero
+  const int ksel = (select >= 8 && select <= 10) ? select - 7 : 0;
   const int variant = (select == 0 || ksel) ? 4 : select;
 #ifdef SISR_DIAG
   if (variant != 4 && variant != 5 && variant != 6 && variant != 2 && variant != 13 &&
@@ -1865,9 +1899,17 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
     const bool aff = in_scale != nullptr, msk = mask != nullptr, rs = res != nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (ksel) {
-      // 1: plain (bias only); 2: LeakyReLU epilogue -- the forms SFTMD needs
-      const bool form_ok = ksel == 1 ? (!msk && p.relu == 0) : (!msk && p.relu == 2);
+      // 1: plain (bias only); 2: LeakyReLU epilogue; 3: LeakyReLU' mask -- the forms SFTMD needs
+      const bool form_ok = ksel == 1 ? (!msk && p.relu == 0) : (ksel == 2 ? (!msk && p.relu == 2) : (msk && p.mask_leaky && p.relu == 0 && !p.bias));
       if (!form_ok) return SISR_ERR_UNSUPPORTED;
+      if (ksel == 3) {  // always the 2-row tile, both input chunks resident in LDS
+        p.tiles_h = (H + 1) / 2;
+        const dim3 g3((unsigned)((long)p.tiles_w * p.tiles_h * B), 1);
+        const size_t lb3 = 2 * 4 * HALO_W * 64 * sizeof(float);
+        SISR_ALLOW_LDS((conv3x3_c64_v4_kernel<false, true, false, 1, false, false, true, 3>), lb3);
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, true, false, 1, false, false, true, 3>), g3, dim3(256), lb3, st, p);
+        return sisr_check_launch();
+      }
       const bool small = nblk * p.cout_chunks < SMALL_GRID_BLOCKS;
       dim3 g = grid;
       size_t lb = HALO_H * HALO_W * 64 * sizeof(float);

@@ -1219,7 +1219,7 @@ def shuffle_rgb(y, channels, r):
 
 # ----------------------------------------------------------------------------- SFTMD (csrc/sft.hip)
 LEAKY, LEAKY_MASK = 2, 4  # `relu` codes of sisr_conv3x3_c64: LeakyReLU(0.2) epilogue / the mask is its derivative
-SPARSE_BLOCK_DIAGONAL, SPARSE_SECOND_CHUNK = 8, 9  # `select` codes: structural zeros of the merged SFT weights are skipped
+SPARSE_BLOCK_DIAGONAL, SPARSE_SECOND_CHUNK, SPARSE_HALVES = 8, 9, 10  # `select` codes: structural zeros of the merged SFT weights are skipped
 
 
 def _fp32_only(what):
@@ -1303,7 +1303,7 @@ class _SftLayer(Function):
             dbB = torch.empty(128, device=dev)
             wgrad_c64(t, v64, dy2, v128, dWB, dbB, B, H, W, 64, 128, active_units=0xC3)  # the two diagonal 64 x 32 blocks
             dt = _empty_cl(B, 64, H, W, dev)
-            conv_c64(dy2, v128, pdB, None, (1, 64), dt, v64, B, H, W, 128, 64, mask=t, relu=LEAKY_MASK)
+            conv_c64(dy2, v128, pdB, None, (1, 64), dt, v64, B, H, W, 128, 64, mask=t, relu=LEAKY_MASK, select=SPARSE_HALVES)
             dWA = torch.empty((64, 128, 3, 3), device=dev)
             dbA = torch.empty(64, device=dev)
             # input channels >= 96 are padding when M <= 32: the last ci half of the second chunk is never read back

@@ -88,7 +88,7 @@ def test_sft_layer_matches_the_four_conv_formulation(relu, M):
         assert rel(p.grad, ref_g[k]) < 5e-6, k
 
 
-@pytest.mark.parametrize("shape", [(2, 10, 37), (4, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 10, 37), (4, 64, 64), (1, 7, 33)])
 def test_sparse_select_codes_equal_the_dense_kernel(shape):
     """`select` 8 / 9 skip structural zeros of the merged SFT weights: the remaining products are accumulated in the dense
     kernel's order, so the outputs are bit-identical; the masked weight gradient (other K-slice split) agrees to rounding.
@@ -122,6 +122,16 @@ def test_sparse_select_codes_equal_the_dense_kernel(shape):
                      relu=ops.LEAKY, select=sel)
         outs.append(y)
     assert torch.equal(outs[0], outs[1])
+    # 128 -> 64, the transpose of the block-diagonal form (B's input gradient): LeakyReLU' mask epilogue
+    _, pdb = ops.pack_pair(wb)
+    dy2g = torch.randn(B, 128, H, W, generator=g).cuda().contiguous(memory_format=cl)
+    outs = []
+    for sel in (0, ops.SPARSE_HALVES):
+        y = torch.empty(B, 64, H, W, device="cuda").contiguous(memory_format=cl)
+        ops.conv_c64(dy2g, hip.view_plain(H, W, 128), pdb, None, (1, 64), y, hip.view_plain(H, W, 64), B, H, W, 128, 64, mask=t,
+                     relu=ops.LEAKY_MASK, select=sel)
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
     # masked weight gradients vs the full ones on the blocks that are read back
     dy2 = torch.randn(B, 128, H, W, generator=g).cuda().contiguous(memory_format=cl)
     full, part = torch.empty(128, 64, 3, 3, device="cuda"), torch.full((128, 64, 3, 3), float("nan"), device="cuda")
@@ -141,7 +151,7 @@ def test_sparse_select_codes_equal_the_dense_kernel(shape):
 def test_sparse_select_codes_refuse_other_shapes():
     x = torch.zeros(1, 64, 8, 32, device="cuda").contiguous(memory_format=torch.channels_last)
     pf, _ = ops.pack_pair(torch.zeros(64, 64, 3, 3, device="cuda"))
-    for sel in (ops.SPARSE_BLOCK_DIAGONAL, ops.SPARSE_SECOND_CHUNK):
+    for sel in (ops.SPARSE_BLOCK_DIAGONAL, ops.SPARSE_SECOND_CHUNK, ops.SPARSE_HALVES):
         with pytest.raises(RuntimeError, match="unsupported"):
             ops.conv_c64(x, hip.view_plain(8, 32, 64), pf, None, (1, 64), torch.empty_like(x), hip.view_plain(8, 32, 64), 1, 8, 32,
                          64, 64, select=sel)
