@@ -351,6 +351,10 @@ int sisr_pil_resample(const unsigned char* in, void* out, const int* bounds, con
  * sisr_clamp01: backward == 0: out = clamp(a, 0, 1); else out = grad * [0 <= a <= 1]. */
 int sisr_sft_compose(float* mul_w1, float* mul_b1, float* add_w1, float* add_b1, float* mul_w2, float* mul_b2, float* add_w2,
                      float* add_b2, float* WA, float* bA, float* WB, float* bB, int M, int split, void* stream);
+/* all SFT layers of a network in one launch: table = n records of 12 device pointers (the arguments of sisr_sft_compose in
+ * order) + int M + int pad, sisr_sft_compose_record_bytes() each, in device memory */
+size_t sisr_sft_compose_record_bytes(void);
+int sisr_sft_compose_many(const void* table, int n, void* stream);
 int sisr_sft_combine_fwd(const float* x, long x_stride, const float* y2, const float* md, float* out, long out_stride,
                          long npix, int relu, void* stream);
 int sisr_sft_combine_bwd(const float* dout, long dout_stride, const float* x, long x_stride, const float* y2, float* dx,

@@ -59,6 +59,45 @@ __global__ __launch_bounds__(256) void sft_compose_kernel(SftCompose c) {
   }
 }
 
+// every SFT layer of a network in one launch (once per training step, before the one-launch weight packing): table =
+// n SftCompose records in device memory, blockIdx.y = layer
+__global__ __launch_bounds__(256) void sft_compose_many_kernel(const SftCompose* __restrict__ table) {
+  const SftCompose c = table[blockIdx.y];
+  constexpr int NA = 64 * 128 * 9, NB = 128 * 64 * 9;
+  const int cin = 64 + c.M;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < NA + NB + 64 + 128; i += gridDim.x * 256) {
+    float *merged, *part = nullptr;
+    if (i < NA) {
+      const int t = i % 9, r = i / 9, o = r >> 7, ci = r & 127;
+      merged = c.WA + i;
+      if (ci < cin) part = (o < 32 ? c.mw1 : c.aw1) + ((long)(o & 31) * cin + ci) * 9 + t;
+    } else if (i < NA + NB) {
+      const int k = i - NA, t = k % 9, r = k / 9, o = r >> 6, ci = r & 63;
+      merged = c.WB + k;
+      if ((o < 64) == (ci < 32)) part = (o < 64 ? c.mw2 : c.aw2) + ((long)(o & 63) * 32 + (ci & 31)) * 9 + t;
+    } else if (i < NA + NB + 64) {
+      const int o = i - NA - NB;
+      merged = c.bA + o;
+      part = (o < 32 ? c.mb1 : c.ab1) + (o & 31);
+    } else {
+      const int o = i - NA - NB - 64;
+      merged = c.bB + o;
+      part = (o < 64 ? c.mb2 : c.ab2) + (o & 63);
+    }
+    *merged = part ? *part : 0.f;
+  }
+}
+
+extern "C" size_t sisr_sft_compose_record_bytes(void) { return sizeof(SftCompose); }
+
+// table: n records {mul_w1, mul_b1, add_w1, add_b1, mul_w2, mul_b2, add_w2, add_b2, WA, bA, WB, bB (device pointers), int M,
+// int split (ignored: always composes)} in device memory
+extern "C" int sisr_sft_compose_many(const void* table, int n, void* stream) {
+  if (!table || n <= 0 || n > 65535) return SISR_ERR_ARG;
+  hipLaunchKernelGGL(sft_compose_many_kernel, dim3(72, n), dim3(256), 0, (hipStream_t)stream, static_cast<const SftCompose*>(table));
+  return sisr_check_launch();
+}
+
 extern "C" int sisr_sft_compose(float* mw1, float* mb1, float* aw1, float* ab1, float* mw2, float* mb2, float* aw2, float* ab2,
                                 float* WA, float* bA, float* WB, float* bB, int M, int split, void* stream) {
   if (!mw1 || !mb1 || !aw1 || !ab1 || !mw2 || !mb2 || !aw2 || !ab2 || !WA || !bA || !WB || !bB || M < 0 || M > 64)

@@ -112,6 +112,8 @@ _SIGS.update({  # around the non-local attention (csrc/nonlocal.hip)
 })
 _SIGS.update({  # SFTMD pieces (csrc/sft.hip)
     "sisr_sft_compose": (c_int, [P] * 12 + [c_int, c_int, P]),
+    "sisr_sft_compose_record_bytes": (c_size_t, []),
+    "sisr_sft_compose_many": (c_int, [P, c_int, P]),
     "sisr_sft_combine_fwd": (c_int, [P, c_long, P, P, P, c_long, c_long, c_int, P]),
     "sisr_sft_combine_bwd": (c_int, [P, c_long, P, c_long, P, P, P, c_long, c_int, P]),
     "sisr_map64": (c_int, [P, c_long, P, c_long, P, c_long, c_long, c_int, P]),

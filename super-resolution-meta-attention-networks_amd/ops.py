@@ -201,11 +201,67 @@ class _PackPlan:
             _STEP_PACKS[id(w)] = (w, r, PRECISION, pf, pd)
 
 
+_SFT_STEP = {}  # id(mul_conv1.weight) -> (that weight, WA, bA, WB, bB): merged SFT weights composed for this step
+
+
+class _SftComposePlan:
+    """Merged weights of every StandardSft of a network, composed in one launch (sisr_sft_compose_many) into persistent
+    buffers; their MFMA packings then ride along in the network's one-launch weight packing."""
+
+    def __init__(self, mods, device):
+        import numpy as np
+        self.mods = mods
+        self.merged = [(torch.empty((64, 128, 3, 3), device=device), torch.empty(64, device=device),
+                        torch.empty((128, 64, 3, 3), device=device), torch.empty(128, device=device)) for _ in mods]
+        rec = np.zeros(len(mods), dtype=[("p", "<u8", (12,)), ("M", "<i4"), ("split", "<i4")])
+        assert rec.dtype.itemsize == hip.lib().sisr_sft_compose_record_bytes()
+        self.ptrs = []
+        for k, m in enumerate(mods):
+            ps = [t.data_ptr() for t in m.params()] + [t.data_ptr() for t in self.merged[k]]
+            rec[k] = (ps, m.mul_conv1.weight.shape[1] - 64, 0)
+            self.ptrs.append(ps[:8])
+        self.table = torch.from_numpy(rec.view(np.uint8)).to(device)
+
+    def valid(self):
+        return all(all(t.data_ptr() == q and t.is_contiguous() for t, q in zip(m.params(), ps))
+                   for m, ps in zip(self.mods, self.ptrs))
+
+    def run(self):
+        hip.check(hip.lib().sisr_sft_compose_many(self.table.data_ptr(), len(self.mods), hip.stream()), "sisr_sft_compose_many")
+        for m, mg in zip(self.mods, self.merged):
+            w = m.mul_conv1.weight
+            _SFT_STEP[id(w)] = (w, *mg)
+
+    def weights(self):
+        out = []
+        for WA, _, WB, _ in self.merged:
+            out += [(WA, 1), (WB, 1)]
+        return out
+
+
+def _sft_plan(net):
+    mods = [m for m in net.modules() if type(m).__name__ == "StandardSft" and m.mul_conv1.weight.is_cuda]
+    if not mods or PRECISION != "fp32" or not all(t.is_contiguous() for m in mods for t in m.params()):
+        return None
+    plan = getattr(net, "_sisr_sft_plan", None)
+    if plan is None or not plan.valid():
+        plan = _SftComposePlan(mods, mods[0].mul_conv1.weight.device)
+        net._sisr_sft_plan = plan
+        net._sisr_pack_plan = None  # the merged buffers are new tensors: rebuild the packing plan around them
+    return plan
+
+
 def pack_all(net, weights_fn):
-    """Repack every 64-multiple 3x3 conv weight of `net` in one launch; weights_fn(net) -> [(weight, shuffle)]."""
+    """Repack every 64-multiple 3x3 conv weight of `net` in one launch; weights_fn(net) -> [(weight, shuffle)].  SFT layers:
+    their merged weights are composed first (one launch for all of them) and packed in the same launch as the rest."""
+    sft = _sft_plan(net)
+    if sft is not None:
+        sft.run()
     plan = getattr(net, "_sisr_pack_plan", None)
     if plan is None or not plan.valid():
         ws = [(w, r) for w, r in weights_fn(net) if w.is_cuda and w.is_contiguous()]
+        if sft is not None:
+            ws += sft.weights()
         if not ws:
             return
         plan = _PackPlan(ws, ws[0][0].device)
@@ -215,6 +271,7 @@ def pack_all(net, weights_fn):
 
 def invalidate_packs():
     _STEP_PACKS.clear()
+    _SFT_STEP.clear()
 
 
 def _step_pack(w, shuffle):
@@ -1262,11 +1319,15 @@ class _SftLayer(Function):
         if diff % 16:
             raise RuntimeError("SFT layer: feature and metadata maps must be 16-byte aligned relative to each other")
         vcat = hip.view_pair(H, W, diff // 4)
-        WA = torch.empty((64, 128, 3, 3), device=dev)
-        bA = torch.empty(64, device=dev)
-        WB = torch.empty((128, 64, 3, 3), device=dev)
-        bB = torch.empty(128, device=dev)
-        _sft_compose((mw1, mb1, aw1, ab1, mw2, mb2, aw2, ab2), (WA, bA, WB, bB), M)
+        hit = _SFT_STEP.get(id(mw1))
+        if hit is not None and hit[0] is mw1:  # composed (and packed) once for the whole step by pack_all
+            WA, bA, WB, bB = hit[1:]
+        else:
+            WA = torch.empty((64, 128, 3, 3), device=dev)
+            bA = torch.empty(64, device=dev)
+            WB = torch.empty((128, 64, 3, 3), device=dev)
+            bB = torch.empty(128, device=dev)
+            _sft_compose((mw1, mb1, aw1, ab1, mw2, mb2, aw2, ab2), (WA, bA, WB, bB), M)
         pfA, pdA = pack_pair(WA)
         pfB, pdB = pack_pair(WB)
         t = _empty_cl(B, 64, H, W, dev)

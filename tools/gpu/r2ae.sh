@@ -1,7 +1,7 @@
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2ae; mkdir -p $O
 cd $R
-timeout -k 10 600 python -m pytest tests/test_sftmd_gpu.py tests/test_hip_gpu.py -m gpu -q --capture=sys -x > $O/t.log 2>&1 || { tail -60 $O/t.log; exit 1; }
+timeout -k 10 600 python -m pytest tests/test_sftmd_gpu.py tests/test_srmd_gpu.py -m gpu -q --capture=sys -x > $O/t.log 2>&1 || { tail -60 $O/t.log; exit 1; }
 tail -2 $O/t.log
 python tools/sftmd_bench.py > $O/sftmd.json 2>/dev/null
 python -c "
