@@ -107,6 +107,23 @@ int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const float* dy, con
  * selects the 32 x 32-channel blocks (x 9 taps) to compute; the others are neither computed nor written (a caller whose
  * weight is structurally sparse -- SFTMD's merged convs -- never reads them).  At most 64 blocks; every bias half needs
  * one active block. */
+/* Several 64 -> 64 weight gradients of ONE geometry in one launch (plain OIHW dw [64][64][3][3], db [64], alpha 1): at a few
+ * tiles per GPU a single gradient's launch is mostly ramp, slab epilogue and drain; batched, every workgroup walks a long
+ * run of tiles of its own job.  jobs: HOST array of njobs <= sisr_wgrad3x3_c64_batch_max() records
+ * { x, dy, dy_scale (nullable), dy_shift (nullable), dw, dbias (nullable) } of device pointers, all with the views given. */
+typedef struct {
+  const float* x;
+  const float* dy;
+  const float* dy_scale;
+  const float* dy_shift;
+  float* dw;
+  float* dbias;
+} sisr_wgrad_job;
+size_t sisr_wgrad_job_bytes(void);
+int sisr_wgrad3x3_c64_batch_max(void);
+size_t sisr_wgrad3x3_c64_batch_workspace_bytes(int njobs, int B, int H, int W);
+int sisr_wgrad3x3_c64_batch(const void* jobs, int njobs, const int64_t* xview, const int64_t* dyview, float* workspace,
+                            size_t workspace_bytes, int B, int H, int W, void* stream);
 
 /* ---- RGB-side 3x3 convolutions (fp32 VALU, HBM-bound) ------------------------------------------
  * ref: head = default_conv(3, n_feats), tail[-1] = default_conv(n_feats, 3)

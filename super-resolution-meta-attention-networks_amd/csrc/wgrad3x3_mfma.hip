@@ -17,6 +17,7 @@
 // into the OIHW gradient.  Splitting the OUTPUT four ways instead of giving each wave a quadrant
 // cuts the slab traffic 4x (36.9 KB per workgroup) at the price of re-reading the inputs from L2.
 #include "sisr_common.h"
+#include <string.h>
 #include <stdlib.h>
 
 #define WT_H 8
@@ -49,7 +50,7 @@ struct WgradParams {
   unsigned long long bias_units;  // bit blockIdx.y: this workgroup row also sums dY for the bias gradient
 };
 
-__global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) {
+static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ldx = lds;
   float* ldy = lds + LDS_X;
@@ -183,6 +184,18 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) {
     p.bias_slabs[((long)blockIdx.x * p.cout_chunks * 2 + cq * 2 + coh) * 32 + tid] = s;
   }
 }
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) { wgrad3x3_c64_body(p); }
+
+// Several weight gradients of one geometry in ONE launch (blockIdx.z = job).  At a few tiles per GPU a single gradient has
+// two tiles per workgroup: slab epilogue, ramp and drain are as long as the work.  Eight of them share the 512 resident
+// workgroups instead -- every workgroup walks 16 tiles of its own job, as at batch 32 -- and the second stage adds 16 slabs
+// per job instead of 128.  Per-job results are those of a single launch with the same K-split (same kernel body).
+#define WG_BATCH 8
+struct WgradBatch {
+  WgradParams job[WG_BATCH];
+};
+__global__ __launch_bounds__(256, 2) void wgrad3x3_c64_batch_kernel(WgradBatch bt) { wgrad3x3_c64_body(bt.job[blockIdx.z]); }
 
 // ------------------------------------------------------------------ bf16 matrix-core weight gradient
 // Operands rounded to bf16 (RNE) as they are staged into LDS, products exact, fp32 accumulation; the bias
@@ -653,7 +666,7 @@ struct ReduceParams {
 // group sums are added in group order through LDS.  Latency-bound (5.5 us stand-alone for 18.9 MB of slabs), so the
 // point of RG is parallelism.
 #define RG 16
-__global__ __launch_bounds__(64 * RG) void wgrad_reduce_kernel(ReduceParams p) {
+static __device__ __forceinline__ void wgrad_reduce_body(const ReduceParams& p) {
   __shared__ float red[RG][64];
   const long total = (long)p.units * SLAB;
   const long gid = (long)blockIdx.x * 64 + threadIdx.x;
@@ -698,6 +711,12 @@ __global__ __launch_bounds__(64 * RG) void wgrad_reduce_kernel(ReduceParams p) {
     p.db[(long)co * p.bias_n + (long)cq * p.bias_q] = s * p.alpha;
   }
 }
+
+__global__ __launch_bounds__(64 * RG) void wgrad_reduce_kernel(ReduceParams p) { wgrad_reduce_body(p); }
+struct ReduceBatch {
+  ReduceParams job[WG_BATCH];
+};
+__global__ __launch_bounds__(64 * RG) void wgrad_reduce_batch_kernel(ReduceBatch bt) { wgrad_reduce_body(bt.job[blockIdx.y]); }
 
 static View view_from(const int64_t* v) {
   View r;
@@ -811,6 +830,95 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   r.bias_q = bias_q;
   const long total = (long)units * SLAB + (dbias ? cout : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, RG), 0, (hipStream_t)stream, r);
+  return sisr_check_launch();
+}
+
+// ---- batched launch: njobs (<= 8) 64 -> 64 weight gradients of one (B, H, W), plain OIHW outputs
+struct sisr_wgrad_job_host {
+  const float* x;
+  const float* dy;
+  const float* dy_scale;
+  const float* dy_shift;
+  float* dw;
+  float* dbias;
+};
+static int wgrad_batch_split(int njobs, int B, int H, int W) {
+  const long tiles = (long)B * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+  long S = 512 / (4 * njobs);  // 4 units per job; two workgroups per CU resident across the whole grid
+  if (S < 1) S = 1;
+  if (S > tiles) S = tiles;
+  return (int)S;
+}
+extern "C" size_t sisr_wgrad_job_bytes(void) { return sizeof(sisr_wgrad_job_host); }
+extern "C" int sisr_wgrad3x3_c64_batch_max(void) { return WG_BATCH; }
+extern "C" size_t sisr_wgrad3x3_c64_batch_workspace_bytes(int njobs, int B, int H, int W) {
+  if (njobs <= 0 || njobs > WG_BATCH || B <= 0 || H <= 0 || W <= 0) return 0;
+  const int S = wgrad_batch_split(njobs, B, H, W);
+  return (size_t)njobs * ((size_t)S * 4 * SLAB + (size_t)S * 64) * sizeof(float);
+}
+extern "C" int sisr_wgrad3x3_c64_batch(const void* jobs_host, int njobs, const int64_t* xview, const int64_t* dyview,
+                                       float* workspace, size_t workspace_bytes, int B, int H, int W, void* stream) {
+  if (!jobs_host || !xview || !dyview || !workspace || njobs <= 0 || njobs > WG_BATCH || B <= 0 || H <= 0 || W <= 0)
+    return SISR_ERR_ARG;
+  if (workspace_bytes < sisr_wgrad3x3_c64_batch_workspace_bytes(njobs, B, H, W) || !sisr_aligned16(workspace)) return SISR_ERR_ARG;
+  const sisr_wgrad_job_host* jobs = static_cast<const sisr_wgrad_job_host*>(jobs_host);
+  const int S = wgrad_batch_split(njobs, B, H, W);
+  const size_t per_job = (size_t)S * 4 * SLAB + (size_t)S * 64;
+  WgradBatch wb;
+  ReduceBatch rb;
+  memset(&wb, 0, sizeof(wb));
+  memset(&rb, 0, sizeof(rb));
+  for (int k = 0; k < njobs; ++k) {
+    const sisr_wgrad_job_host& j = jobs[k];
+    if (!j.x || !j.dy || !j.dw) return SISR_ERR_ARG;
+    if (!sisr_aligned16(j.x) || !sisr_aligned16(j.dy) || !sisr_aligned16(j.dy_scale) || !sisr_aligned16(j.dy_shift))
+      return SISR_ERR_ALIGN;
+    WgradParams& p = wb.job[k];
+    p.x = j.x;
+    p.xv = view_from(xview);
+    p.dy = j.dy;
+    p.yv = view_from(dyview);
+    if ((p.xv.sB | p.xv.sH | p.xv.sW | p.xv.chi | p.xv.clo | p.yv.sB | p.yv.sH | p.yv.sW | p.yv.chi | p.yv.clo) & 3)
+      return SISR_ERR_ALIGN;
+    p.dy_scale = j.dy_scale;
+    p.dy_shift = j.dy_shift;
+    p.B = B;
+    p.H = H;
+    p.W = W;
+    p.cin_chunks = p.cout_chunks = 1;
+    p.tiles_w = (W + WT_W - 1) / WT_W;
+    p.tiles_h = (H + WT_H - 1) / WT_H;
+    p.S = S;
+    p.slabs = workspace + (size_t)k * per_job;
+    p.bias_slabs = j.dbias ? p.slabs + (size_t)S * 4 * SLAB : nullptr;
+    p.mapped = 0;
+    ReduceParams& r = rb.job[k];
+    r.slabs = p.slabs;
+    r.bias_slabs = p.bias_slabs;
+    r.dw = j.dw;
+    r.db = j.dbias;
+    r.so = 64 * 9;
+    r.si = 9;
+    r.alpha = 1.f;
+    r.S = S;
+    r.units = 4;
+    r.cin_chunks = r.cout_chunks = 1;
+    r.flip = 0;
+    r.on = 1;
+    r.oq = 64;
+    r.in_ = 1;
+    r.iq = 64;
+    r.bias_n = 1;
+    r.bias_q = 64;
+    r.mapped = 0;
+  }
+  const size_t lds_bytes = (size_t)(LDS_X + LDS_Y) * sizeof(float);
+  SISR_ALLOW_LDS(wgrad3x3_c64_batch_kernel, lds_bytes);
+  hipLaunchKernelGGL(wgrad3x3_c64_batch_kernel, dim3(S, 4, njobs), dim3(256), lds_bytes, (hipStream_t)stream, wb);
+  int rc = sisr_check_launch();
+  if (rc) return rc;
+  const long total = 4L * SLAB + 64;  // bias rows past the weights; jobs without a bias skip them inside (db == null)
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((total + 63) / 64), njobs), dim3(64, RG), 0, (hipStream_t)stream, rb);
   return sisr_check_launch();
 }
 

@@ -26,6 +26,10 @@ _SIGS = {
     "sisr_wgrad3x3_c64_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "sisr_wgrad3x3_c64": (c_int, [P, P, P, P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
                                   c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, P]),
+    "sisr_wgrad_job_bytes": (c_size_t, []),
+    "sisr_wgrad3x3_c64_batch_max": (c_int, []),
+    "sisr_wgrad3x3_c64_batch_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "sisr_wgrad3x3_c64_batch": (c_int, [P, c_int, P, P, P, c_size_t, c_int, c_int, c_int, P]),
     "sisr_conv3x3_cin3": (c_int, [P, P, c_int64, c_int64, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
     "sisr_conv3x3_cout3": (c_int, [P, P, P, c_int64, c_int64, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "sisr_corr3x3_c3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -143,6 +147,11 @@ class GateMlpDesc(ctypes.Structure):
     _fields_ = [("w", c_void_p * GM_MAXL), ("b", c_void_p * GM_MAXL), ("nin", c_int * GM_MAXL), ("nout", c_int * GM_MAXL),
                 ("cat", c_int * GM_MAXL), ("relu_in", c_int * GM_MAXL), ("act", c_int * GM_MAXL), ("L", c_int),
                 ("M", c_int), ("C", c_int), ("final_mode", c_int)]
+
+
+class WgradJob(ctypes.Structure):
+    """Host mirror of sisr_wgrad_job (include/sisr_hip.h)."""
+    _fields_ = [(n, c_void_p) for n in ("x", "dy", "dy_scale", "dy_shift", "dw", "dbias")]
 
 
 class CaTail(ctypes.Structure):

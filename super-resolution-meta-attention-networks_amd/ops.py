@@ -373,6 +373,47 @@ def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_sc
     hip.check(rc, name)
 
 
+# Weight gradients of one geometry are launched eight at a time while a launch is small (<= BATCH_WGRAD_MAX_PIXELS pixels per
+# map: up to 8 tiles of 128 x 128 per GPU -- BASELINE config 4 has 4): see csrc/wgrad3x3_mfma.hip wgrad3x3_c64_batch_kernel.
+BATCH_WGRAD = os.environ.get("SISR_BATCH_WGRAD", "1") != "0"
+BATCH_WGRAD_MAX_PIXELS = int(os.environ.get("SISR_BATCH_WGRAD_MAX_PIXELS", 8 * 128 * 128))
+
+
+class WgradQueue:
+    """64 -> 64 weight gradients of one (B, H, W) queued by a backward pass and launched in batches (flush() before the
+    gradients leave the autograd node).  Holds references to every operand until its launch has been issued."""
+
+    def __init__(self, B, H, W, device):
+        self.geo, self.device, self.jobs = (B, H, W), device, []
+        self.max = hip.lib().sisr_wgrad3x3_c64_batch_max()
+
+    @staticmethod
+    def wanted(B, H, W):
+        return BATCH_WGRAD and PRECISION == "fp32" and B * H * W <= BATCH_WGRAD_MAX_PIXELS
+
+    def add(self, x, dy, dw, db, dy_scale=None, dy_shift=None):
+        self.jobs.append((x, dy, dy_scale, dy_shift, dw, db))
+        if len(self.jobs) == self.max:
+            self.flush()
+
+    def flush(self):
+        if not self.jobs:
+            return
+        B, H, W = self.geo
+        L, n = hip.lib(), len(self.jobs)
+        arr = (hip.WgradJob * n)()
+        for k, (x, dy, sc, sh, dw, db) in enumerate(self.jobs):
+            arr[k].x, arr[k].dy, arr[k].dy_scale, arr[k].dy_shift = hip.ptr(x), hip.ptr(dy), hip.ptr(sc), hip.ptr(sh)
+            arr[k].dw, arr[k].dbias = hip.ptr(dw), hip.ptr(db)
+        nbytes = L.sisr_wgrad3x3_c64_batch_workspace_bytes(n, B, H, W)
+        ws = hip.workspace(self.device, nbytes)
+        v = hip.view_plain(H, W, 64)
+        import ctypes
+        hip.check(L.sisr_wgrad3x3_c64_batch(ctypes.addressof(arr), n, v, v, hip.ptr(ws), nbytes, B, H, W, hip.stream()),
+                  "sisr_wgrad3x3_c64_batch")
+        self.jobs = []
+
+
 def gap_parts(H, W):
     return hip.lib().sisr_conv3x3_c64_gap_parts(H, W)
 
@@ -973,9 +1014,14 @@ class _GatedGroup(Function):
                 blocks.append((sv_all[pos:pos + cnt], has_m, s1, s2))
                 pos += cnt
             side = _side_ok(wt, *(t for blk in blocks for t in blk[0][1:3]))
+            # small launches: the group's 2n + 1 weight gradients go out eight to a launch (WgradQueue) instead of one by one
+            queue = WgradQueue(B, H, W, dev) if WgradQueue.wanted(B, H, W) else None
             # tail conv: weight gradient from (u_n, dout); dU_n = convT(dout), with sum(dU_n * t2_n) on the side
             dwt, dbt = _grad_buf(wt), torch.empty(64, device=dev)
-            run(lambda: wgrad_c64(un, v, dout, v, dwt, dbt, B, H, W, 64, 64), (un, dout, dwt, dbt))
+            if queue is not None:
+                queue.add(un, dout, dwt, dbt)
+            else:
+                run(lambda: wgrad_c64(un, v, dout, v, dwt, dbt, B, H, W, 64, 64), (un, dout, dwt, dbt))
             tails = _use_ca_tail(B, H, W)
 
             def gate_bwd_out(k):
@@ -1015,13 +1061,19 @@ class _GatedGroup(Function):
                               "sisr_ca_gate_bwd")
                 dw2, db2 = _grad_buf(w2), torch.empty(64, device=dev)
                 dw1, db1 = _grad_buf(w1), torch.empty(64, device=dev)
-                run(lambda t1=t1, dy=dy, dw2=dw2, db2=db2, g=g, shift=shift:
-                    wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, dy_scale=g, dy_shift=shift),
-                    (t1, dy, g, shift, dw2, db2))
+                if queue is not None:
+                    queue.add(t1, dy, dw2, db2, dy_scale=g, dy_shift=shift)
+                else:
+                    run(lambda t1=t1, dy=dy, dw2=dw2, db2=db2, g=g, shift=shift:
+                        wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, dy_scale=g, dy_shift=shift),
+                        (t1, dy, g, shift, dw2, db2))
                 dt1 = _empty_cl(B, 64, H, W, dev)
                 conv_c64(dy, v, pd2, None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1, in_scale=g, in_shift=shift)
-                run(lambda xk=xk, dt1=dt1, dw1=dw1, db1=db1: wgrad_c64(xk, v, dt1, v, dw1, db1, B, H, W, 64, 64),
-                    (xk, dt1, dw1, db1))
+                if queue is not None:
+                    queue.add(xk, dt1, dw1, db1)
+                else:
+                    run(lambda xk=xk, dt1=dt1, dw1=dw1, db1=db1: wgrad_c64(xk, v, dt1, v, dw1, db1, B, H, W, 64, 64),
+                        (xk, dt1, dw1, db1))
                 dprev = _empty_cl(B, 64, H, W, dev)
                 if k > 0:
                     dgp = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
@@ -1034,6 +1086,8 @@ class _GatedGroup(Function):
                 grads[k * _GatedGroup.PER:(k + 1) * _GatedGroup.PER] = [dw1, db1, dw2, db2, dcaw1, dcab1, dcaw2, dcab2,
                                                                        dmv if has_m else None]
             dx = _affine(dy, None, None, dout, B, H, W, 64) if ctx.needs_input_grad[0] else None
+            if queue is not None:
+                queue.flush()  # before the gradients leave the node (reducer hooks may read them right after)
             return (dx, None, *grads, dwt, dbt)
         finally:
             IN_BACKWARD = False
