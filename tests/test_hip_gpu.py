@@ -383,6 +383,41 @@ def test_edsr_reduced_vs_oracle(scale):
     net_vs_oracle(net, "edsr", dict(num_blocks=2, scale=scale, res_scale=0.1), rnd(1, 3, 17, 23, seed=32, scale=0.5))
 
 
+@pytest.mark.parametrize("shape,njobs", [((4, 128, 128), 8), ((2, 37, 45), 5), ((1, 16, 32), 1), ((3, 9, 70), 3)])
+def test_batched_weight_gradients_equal_single_launches(shape, njobs):
+    """ops.WgradQueue (eight 64 -> 64 weight gradients of one geometry per launch, csrc/wgrad3x3_mfma.hip
+    wgrad3x3_c64_batch_kernel): every job equals its own single launch -- bit for bit when the K-split is the same (one job),
+    to summation-order rounding otherwise; jobs with and without the dY * scale + shift rebuild and with / without a bias."""
+    B, H, W = shape
+    dev = torch.device(DEV)
+    cl = torch.channels_last
+    hip = sisr_amd.hip
+    v = hip.view_plain(H, W, 64)
+    jobs, want = [], []
+    for k in range(njobs):
+        x = rnd(B, 64, H, W, seed=300 + k).to(dev).contiguous(memory_format=cl)
+        dy = rnd(B, 64, H, W, seed=400 + k).to(dev).contiguous(memory_format=cl)
+        sc = (torch.rand(B, 64, generator=torch.Generator().manual_seed(500 + k)) + 0.5).to(dev) if k % 2 else None
+        sh = rnd(B, 64, seed=600 + k, scale=0.1).to(dev) if k % 2 else None
+        has_b = k % 3 != 2
+        dw1, db1 = torch.empty(64, 64, 3, 3, device=dev), (torch.empty(64, device=dev) if has_b else None)
+        ops.wgrad_c64(x, v, dy, v, dw1, db1, B, H, W, 64, 64, dy_scale=sc, dy_shift=sh)
+        want.append((dw1, db1))
+        jobs.append((x, dy, sc, sh, torch.full((64, 64, 3, 3), float("nan"), device=dev),
+                     torch.full((64,), float("nan"), device=dev) if has_b else None))
+    q = ops.WgradQueue(B, H, W, dev)
+    for x, dy, sc, sh, dw, db in jobs:
+        q.add(x, dy, dw, db, dy_scale=sc, dy_shift=sh)
+    q.flush()
+    for (x, dy, sc, sh, dw, db), (dw1, db1) in zip(jobs, want):
+        if njobs == 1:
+            assert torch.equal(dw, dw1) and torch.equal(db, db1)
+        else:
+            close(dw, dw1, 2e-5, 2e-6, "dw")
+            if db is not None:
+                close(db, db1, 2e-5, 2e-6, "db")
+
+
 @pytest.mark.parametrize("L,M,nl", [(1, 10, 1), (3, 10, 1), (3, 20, 0), (4, 1, 1), (4, 20, 1)])
 def test_paraca_other_depths(L, M, nl):
     """ParaCALayer with 1 / 3 / 4 FC layers (ref: attention_manipulators/q_layer.py:12-31; the published configs use 2) on the
