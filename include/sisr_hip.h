@@ -149,6 +149,12 @@ int sisr_ca_gate_bwd(const float* dg_partial, int parts, int B, float inv_hw, co
                      int channels, int hidden, const float* s, const float* hid, const float* ca, const float* mul,
                      float* shift, float* dmul, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
                      unsigned* counter, void* stream);
+/* dw1 = db1 = dw2 = db2 = NULL (counter may be NULL too): only the per-sample part (shift, dmul, dz2 / dz1 into the
+ * workspace); the parameter gradients of up to sisr_ca_gate_bwd_params_batch_max() such calls are then taken in ONE launch.
+ * jobs: HOST array of { that call's workspace, hid, s, dw1, db1, dw2, db2 } (sisr_ca_param_job_bytes() each). */
+int sisr_ca_gate_bwd_params_batch_max(void);
+size_t sisr_ca_param_job_bytes(void);
+int sisr_ca_gate_bwd_params_batch(const void* jobs, int njobs, int B, int hidden, void* stream);
 /* counter: one zero-initialised device word owned by the caller and reused across calls on a stream (the kernel
  * returns it to zero): the sample blocks count themselves on it and the last one sums the parameter gradients,
  * so the whole gate backward is ONE launch on the block's serial backward chain. */

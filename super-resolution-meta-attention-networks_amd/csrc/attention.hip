@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void ca_gate_bwd_kernel(const float* __restric
   __shared__ __attribute__((aligned(16))) float red[16 * 64];
   __shared__ int is_last;
   ca_gate_bwd_sample<false>(dgpart, parts, inv_hw, blockIdx.x, w1, w2, R, hid, ca_in, mul, shift, dmul, dz2_out, dz1_out, red);
+  if (!dw1) return;  // parameter gradients deferred to sisr_ca_gate_bwd_params_batch (dz2 / dz1 stay in the workspace)
   __threadfence();  // this block's dz2 / dz1 are visible device-wide before it is counted
   __syncthreads();
   if (threadIdx.x == 0) is_last = atomicAdd(counter, 1u) == (unsigned)(B - 1);
@@ -52,6 +53,22 @@ __global__ __launch_bounds__(256) void ca_gate_bwd_kernel(const float* __restric
   __threadfence();
   if (threadIdx.x == 0) *counter = 0u;
   ca_gate_bwd_params(dz2_out, dz1_out, hid, s_in, R, B, dw1, db1, dw2, db2);
+}
+
+// Parameter gradients of up to CA_PB gates in one launch (blockIdx.x = job): the chain kernel above then only produces what
+// the next conv waits for (shift, dz2 / dz1), and a residual group's 20 gates pay one launch for their weight gradients.
+// Same ca_gate_bwd_params code, so the sums are those of the in-kernel form.
+#define CA_PB 32
+struct CaParamJob {
+  const float *dz, *hid, *s;  // dz: [B][80] workspace of that gate (dz2 [B][64], then dz1 [B][R])
+  float *dw1, *db1, *dw2, *db2;
+};
+struct CaParamBatch {
+  CaParamJob job[CA_PB];
+};
+__global__ __launch_bounds__(256) void ca_gate_bwd_params_batch_kernel(CaParamBatch bt, int B, int R) {
+  const CaParamJob& j = bt.job[blockIdx.x];
+  ca_gate_bwd_params(j.dz, j.dz + (long)B * 64, j.hid, j.s, R, B, j.dw1, j.db1, j.dw2, j.db2);
 }
 
 // ---------------------------------------------------------------- meta gate (ParaCALayer) forward / backward
@@ -604,15 +621,31 @@ extern "C" int sisr_ca_gate_bwd(const float* dg_partial, int parts, int B, float
                                 const float* w2, int channels, int hidden, const float* s, const float* hid,
                                 const float* ca, const float* mul, float* shift, float* dmul, float* dw1, float* db1,
                                 float* dw2, float* db2, float* workspace, unsigned* counter, void* stream) {
-  if (!dg_partial || !w1 || !w2 || !s || !hid || !ca || !shift || !dw1 || !db1 || !dw2 || !db2 || !workspace || !counter ||
-      B <= 0 || parts <= 0)
-    return SISR_ERR_ARG;
+  const bool defer = !dw1 && !db1 && !dw2 && !db2;  // parameter gradients later, by sisr_ca_gate_bwd_params_batch
+  if (!dg_partial || !w1 || !w2 || !s || !hid || !ca || !shift || !workspace || B <= 0 || parts <= 0) return SISR_ERR_ARG;
+  if (!defer && (!dw1 || !db1 || !dw2 || !db2 || !counter)) return SISR_ERR_ARG;
   if (mul && !dmul) return SISR_ERR_ARG;
   if (channels != 64 || hidden < 1 || hidden > 16) return SISR_ERR_UNSUPPORTED;
   float* dz2 = workspace;
   float* dz1 = workspace + (size_t)B * 64;
   hipLaunchKernelGGL(ca_gate_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dg_partial, parts, inv_hw, w1, w2,
                      hidden, s, hid, ca, mul, shift, dmul, dz2, dz1, dw1, db1, dw2, db2, counter, B);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_ca_gate_bwd_params_batch_max(void) { return CA_PB; }
+extern "C" size_t sisr_ca_param_job_bytes(void) { return sizeof(CaParamJob); }
+// jobs: HOST array of njobs records { workspace of that gate's sisr_ca_gate_bwd call, hid, s, dw1, db1, dw2, db2 }
+extern "C" int sisr_ca_gate_bwd_params_batch(const void* jobs_host, int njobs, int B, int hidden, void* stream) {
+  if (!jobs_host || njobs <= 0 || njobs > CA_PB || B <= 0 || hidden < 1 || hidden > 16) return SISR_ERR_ARG;
+  CaParamBatch bt;
+  memset(&bt, 0, sizeof(bt));
+  const CaParamJob* jobs = static_cast<const CaParamJob*>(jobs_host);
+  for (int k = 0; k < njobs; ++k) {
+    if (!jobs[k].dz || !jobs[k].hid || !jobs[k].s || !jobs[k].dw1 || !jobs[k].db1 || !jobs[k].dw2 || !jobs[k].db2) return SISR_ERR_ARG;
+    bt.job[k] = jobs[k];
+  }
+  hipLaunchKernelGGL(ca_gate_bwd_params_batch_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, bt, B, hidden);
   return sisr_check_launch();
 }
 

@@ -38,6 +38,9 @@ _SIGS = {
     "sisr_ca_gate_fwd": (c_int, [P, c_int, c_int, c_float, P, P, P, P, c_int, c_int, P, P, P, P, P, P]),
     "sisr_ca_gate_bwd_workspace_bytes": (c_size_t, [c_int]),
     "sisr_ca_gate_bwd": (c_int, [P, c_int, c_int, c_float, P, P, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "sisr_ca_gate_bwd_params_batch_max": (c_int, []),
+    "sisr_ca_param_job_bytes": (c_size_t, []),
+    "sisr_ca_gate_bwd_params_batch": (c_int, [P, c_int, c_int, c_int, P]),
     "sisr_meta_gate_fwd": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P]),
     "sisr_meta_gate_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "sisr_meta_gate_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, P]),
@@ -147,6 +150,11 @@ class GateMlpDesc(ctypes.Structure):
     _fields_ = [("w", c_void_p * GM_MAXL), ("b", c_void_p * GM_MAXL), ("nin", c_int * GM_MAXL), ("nout", c_int * GM_MAXL),
                 ("cat", c_int * GM_MAXL), ("relu_in", c_int * GM_MAXL), ("act", c_int * GM_MAXL), ("L", c_int),
                 ("M", c_int), ("C", c_int), ("final_mode", c_int)]
+
+
+class CaParamJob(ctypes.Structure):
+    """Host mirror of the records of sisr_ca_gate_bwd_params_batch (include/sisr_hip.h)."""
+    _fields_ = [(n, c_void_p) for n in ("dz", "hid", "s", "dw1", "db1", "dw2", "db2")]
 
 
 class WgradJob(ctypes.Structure):

@@ -1016,6 +1016,7 @@ class _GatedGroup(Function):
             side = _side_ok(wt, *(t for blk in blocks for t in blk[0][1:3]))
             # small launches: the group's 2n + 1 weight gradients go out eight to a launch (WgradQueue) instead of one by one
             queue = WgradQueue(B, H, W, dev) if WgradQueue.wanted(B, H, W) else None
+            gate_jobs = []
             # tail conv: weight gradient from (u_n, dout); dU_n = convT(dout), with sum(dU_n * t2_n) on the side
             dwt, dbt = _grad_buf(wt), torch.empty(64, device=dev)
             if queue is not None:
@@ -1053,7 +1054,16 @@ class _GatedGroup(Function):
                 pd1, pd2 = ctx.packs[k]
                 R = caw1c.shape[0]
                 shift, dmv, dcaw1, dcab1, dcaw2, dcab2 = (go[key] for key in ("shift", "dmv", "dcaw1", "dcab1", "dcaw2", "dcab2"))
-                if not tails:
+                if not tails and queue is not None:
+                    # small launches: the chain kernel only produces what the next conv waits for; the gates' parameter
+                    # gradients of the whole group are one launch at the end (their dz2 / dz1 wait in per-gate workspaces)
+                    dzw = torch.empty((B, 80), device=dev)
+                    hip.check(L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
+                                                 hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
+                                                 hip.ptr(dmv), None, None, None, None, hip.ptr(dzw), None, hip.stream()),
+                              "sisr_ca_gate_bwd")
+                    gate_jobs.append((dzw, hid, s, dcaw1, dcab1, dcaw2, dcab2, R))
+                elif not tails:
                     hip.check(L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
                                                  hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
                                                  hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
@@ -1088,6 +1098,16 @@ class _GatedGroup(Function):
             dx = _affine(dy, None, None, dout, B, H, W, 64) if ctx.needs_input_grad[0] else None
             if queue is not None:
                 queue.flush()  # before the gradients leave the node (reducer hooks may read them right after)
+                import ctypes
+                cap = L.sisr_ca_gate_bwd_params_batch_max()
+                for i0 in range(0, len(gate_jobs), cap):
+                    chunk = gate_jobs[i0:i0 + cap]
+                    arr = (hip.CaParamJob * len(chunk))()
+                    for k, (dzw, hid, s, a1, c1, a2, c2, _) in enumerate(chunk):
+                        arr[k].dz, arr[k].hid, arr[k].s = hip.ptr(dzw), hip.ptr(hid), hip.ptr(s)
+                        arr[k].dw1, arr[k].db1, arr[k].dw2, arr[k].db2 = hip.ptr(a1), hip.ptr(c1), hip.ptr(a2), hip.ptr(c2)
+                    hip.check(L.sisr_ca_gate_bwd_params_batch(ctypes.addressof(arr), len(chunk), B, chunk[0][7], hip.stream()),
+                              "sisr_ca_gate_bwd_params_batch")
             return (dx, None, *grads, dwt, dbt)
         finally:
             IN_BACKWARD = False
