@@ -13,6 +13,14 @@ Operators
   meta_gate      ParaCALayer FC stack -> per-(b,c) gate (ref: attention_manipulators/q_layer.py:4-43)
   ca_layer / gate_mul   stand-alone CALayer / x*gate (ref: advanced/architectures.py:13-32)
   l1_loss        nn.L1Loss(mean) (ref: SISR/models/__init__.py:268)
+  gated_group    a whole ResidualGroup / QResidualGroup as ONE node (GATE / DOT conv hooks; its weight gradients and gate
+                 parameter gradients go out in batches while launches are small: WgradQueue)
+  qca_gate       the metadata-mixing QCALayer styles' FC stacks (ref: attention_manipulators/architectures.py:105-127)
+  conv_chain / nchw_to_nhwc_pad / shuffle_rgb       SRMD (ref: advanced/architectures.py:380-425)
+  sft_layer / sft_apply / sftmd_forward             SFTMD (ref: SFTMD_variants/architectures.py:8-176)
+  lam / csam / conv3x3_stack / stack_maps           HAN (ref: advanced/HAN_blocks.py, advanced/architectures.py:314-377)
+  soca / nonlocal_block / nonlocal_attention        SAN (ref: advanced/SAN_blocks.py, advanced/mpncov.py)
+  pixel_shuffle  nn.PixelShuffle on channels-last maps wider than 64 channels (64-wide: fused into the conv's store)
 """
 import os
 
