@@ -69,7 +69,12 @@ int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked,
  * from gap_partial -- sisr_ca_gate_fwd's outputs) or into the gate's backward (backward = 1: from the `dot` partial sums
  * -- sisr_ca_gate_bwd's outputs; the last sample's finisher sums the parameter gradients over the batch).  Same
  * arithmetic and summation order as those two entry points.  counter: B + 1 zero-initialised device words, returned to
- * zero; workspace (backward): B * 80 floats. */
+ * zero; workspace (backward): B * 80 floats.
+ * head != 0 turns the same record into a gate HEAD: the launch that CONSUMES a gate computes it first -- every workgroup for
+ * its own sample, from the partial sums a previous launch wrote (head_part [B][head_parts][64]) -- instead of a gate launch of
+ * its own between the two convs: backward = 0 on a gate_add / gate_out launch (in_scale must be g_out: it is filled here, with
+ * s_out / hid_out / ca_out), backward = 1 on an in_scale + in_shift + mask launch (in_shift must be `shift`: filled here, with
+ * dmul and the workspace; parameter gradients: sisr_ca_gate_bwd_params_batch).  counter and dw / db fields unused. */
 typedef struct {
   int backward, hidden;
   float inv_hw;
@@ -79,6 +84,8 @@ typedef struct {
   float *shift, *dmul, *dw1, *db1, *dw2, *db2;   /* backward outputs */
   float* workspace;
   unsigned* counter;
+  const float* head_part;
+  int head_parts, head;
 } sisr_ca_tail;
 size_t sisr_ca_tail_bytes(void);
 /* select: 0 (= 4) issue-lean kernel, tile height chosen by grid size, general kernel as fallback; 5 / 6 the same with

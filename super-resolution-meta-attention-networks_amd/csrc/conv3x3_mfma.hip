@@ -71,6 +71,11 @@ struct ConvParams {
     float inv_hw;
     int R;
   } bwd_tail;  // active when shift != nullptr
+  // Gate HEADS (template HEAD of conv3x3_c64_v4_kernel): the CONSUMER of a gate computes it -- every workgroup, for its own
+  // sample, from the partial sums the previous launch wrote -- instead of a launch of its own on the serial chain.  The field
+  // blocks above carry the operands (fwd_tail: HEAD 1, bwd_tail: HEAD 2; counters and parameter-gradient fields unused).
+  const float* head_part;  // [B][head_parts][64]
+  int head_parts;
 };
 
 // General kernel: every prologue / epilogue combination, XOR-swizzled LDS (16-B chunk k of halo pixel p lives
@@ -290,7 +295,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
 //      BOTH chunks' halos resident (2 x 34.8 KB): wave (row, half) runs one K loop over its own half's chunk -- no
 //      branch ("the other two waves skip the chunk" was a wave-uniform branch around the unrolled K loop: 118 spilled VGPRs)
 // The skipped products are exact zeros, so results are those of the dense kernel on the zero-padded weights.
-template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false, bool LEAKY = false, int KSEL = 0>
+// HEAD (small launches, where a 6 us gate kernel between two convs is a tenth of a conv): 1 = with GATE, the gate g of the
+// skip being rebuilt is computed here from the previous conv's GAP partial sums (ca_gate_fwd_sample, every workgroup for
+// its own sample; all write the same s / hid / ca / g); 2 = with AFFINE + MASK, the GAP-backward shift is computed here from
+// the previous conv's DOT partial sums (ca_gate_bwd_sample).  Same device functions as the stand-alone gate kernels.
+template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false, bool LEAKY = false, int KSEL = 0, int HEAD = 0>
 __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x3_c64_v4_kernel(ConvParams p) {
   constexpr int THv = 2 * MT, HHv = THv + 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -328,6 +337,17 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
                     (KSEL == 3 ? ch * (HHv * HALO_W * 64) : 0);
   const unsigned boff = hh * 256 + co * 4;
 
+  if constexpr (HEAD == 1) {
+    ca_gate_fwd_sample<false>(p.head_part, p.head_parts, p.fwd_tail.inv_hw, b, p.fwd_tail.w1, p.fwd_tail.b1, p.fwd_tail.w2,
+                              p.fwd_tail.b2, p.fwd_tail.R, p.fwd_tail.mul, p.fwd_tail.s, p.fwd_tail.hid, p.fwd_tail.ca,
+                              p.fwd_tail.g, lds);
+    __syncthreads();  // g (= p.in_scale of this launch) is in L2 for the whole workgroup; the LDS scratch is free again
+  } else if constexpr (HEAD == 2) {
+    ca_gate_bwd_sample<false>(p.head_part, p.head_parts, p.bwd_tail.inv_hw, b, p.bwd_tail.w1, p.bwd_tail.w2, p.bwd_tail.R,
+                              p.bwd_tail.hid, p.bwd_tail.ca, p.bwd_tail.mul, p.bwd_tail.shift, p.bwd_tail.dmul,
+                              p.bwd_tail.dz2, p.bwd_tail.dz1, lds);
+    __syncthreads();  // shift (= p.in_shift of this launch)
+  }
   int c_begin = 0;
   if constexpr (KSEL == 3) {
     // chunk 0's halo goes to LDS here, chunk 1's in the (single) pass of the loop below into the second half: then one
@@ -599,7 +619,7 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
       }
     }
   }
-  if (p.fwd_tail.g || p.bwd_tail.shift) {  // uniform
+  if (HEAD == 0 && (p.fwd_tail.g || p.bwd_tail.shift)) {  // uniform
     const long parts = (long)p.tiles_w * ((H + 3) / 4) * 2;
     const unsigned per_sample = gridDim.x / (unsigned)p.B;  // workgroups of one sample (cout_chunks == 1 here)
     unsigned* cnt = p.fwd_tail.g ? p.fwd_tail.counter : p.bwd_tail.counter;
@@ -1771,6 +1791,8 @@ struct sisr_ca_tail_host {
   float *shift, *dmul, *dw1, *db1, *dw2, *db2;
   float* workspace;
   unsigned* counter;
+  const float* head_part;  // head != 0: partial sums of the PREVIOUS launch, [B][head_parts][64]
+  int head_parts, head;
 };
 extern "C" size_t sisr_ca_tail_bytes() { return sizeof(sisr_ca_tail_host); }
 
@@ -1784,6 +1806,18 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
                                 int cout, const void* ca_tail, int select, void* stream) {
   if (!x || !wpacked || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
   const sisr_ca_tail_host* tail = static_cast<const sisr_ca_tail_host*>(ca_tail);
+  const sisr_ca_tail_host* head = nullptr;
+  if (tail && tail->head) {  // gate head: computed by this launch's workgroups from the previous launch's partial sums
+    head = tail;
+    tail = nullptr;
+    if (cin != 64 || cout != 64 || !head->head_part || head->head_parts <= 0 || head->hidden < 1 || head->hidden > 16 || select != 0)
+      return SISR_ERR_UNSUPPORTED;
+    if (head->backward ? (!mask || !in_scale || in_shift != head->shift || !head->w1 || !head->w2 || !head->hid || !head->ca ||
+                          !head->shift || !head->workspace || (head->mul && !head->dmul) || gate_add || dot)
+                       : (!gate_add || !gate_out || in_scale != head->g_out || !head->w1 || !head->b1 || !head->w2 || !head->b2 ||
+                          !head->s_out || !head->hid_out || !head->ca_out || !head->g_out))
+      return SISR_ERR_ARG;
+  }
   if (tail) {  // only on the issue-lean 64 -> 64 kernels, from the partial sums this launch writes
     if (cin != 64 || cout != 64 || !gap_partial || !tail->counter || tail->hidden < 1 || tail->hidden > 16 || select == 2)
       return SISR_ERR_UNSUPPORTED;
@@ -1861,6 +1895,20 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
     p.bwd_tail.dw1 = tail->dw1; p.bwd_tail.db1 = tail->db1; p.bwd_tail.dw2 = tail->dw2; p.bwd_tail.db2 = tail->db2;
     p.bwd_tail.counter = tail->counter; p.bwd_tail.inv_hw = tail->inv_hw; p.bwd_tail.R = tail->hidden;
   }
+  if (head) {
+    p.head_part = head->head_part;
+    p.head_parts = head->head_parts;
+    if (!head->backward) {
+      p.fwd_tail.w1 = head->w1; p.fwd_tail.b1 = head->b1; p.fwd_tail.w2 = head->w2; p.fwd_tail.b2 = head->b2;
+      p.fwd_tail.mul = head->mul; p.fwd_tail.s = head->s_out; p.fwd_tail.hid = head->hid_out; p.fwd_tail.ca = head->ca_out;
+      p.fwd_tail.g = head->g_out; p.fwd_tail.inv_hw = head->inv_hw; p.fwd_tail.R = head->hidden;
+    } else {
+      p.bwd_tail.w1 = head->w1; p.bwd_tail.w2 = head->w2; p.bwd_tail.hid = head->hid; p.bwd_tail.ca = head->ca;
+      p.bwd_tail.mul = head->mul; p.bwd_tail.shift = head->shift; p.bwd_tail.dmul = head->dmul;
+      p.bwd_tail.dz2 = head->workspace; p.bwd_tail.dz1 = head->workspace + (size_t)B * 64;
+      p.bwd_tail.inv_hw = head->inv_hw; p.bwd_tail.R = head->hidden;
+    }
+  }
   p.tiles_w = (W + TW - 1) / TW;
   p.tiles_h = (H + TH - 1) / TH;
   const long nblk = (long)p.tiles_w * p.tiles_h * B;
@@ -1885,7 +1933,12 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
       lb = 4 * HALO_W * 64 * sizeof(float);
     }
 #define V4X(RS, MTV, GT, DT) hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, RS, MTV, GT, DT>), g, dim3(256), lb, st, p)
-    if (gate) {
+    if (head && (!gate || head->backward)) return SISR_ERR_ARG;
+#define V4H(RS, MTV) hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, RS, MTV, true, false, false, 0, 1>), g, dim3(256), lb, st, p)
+    if (gate && head) {
+      if (small) { if (rs) V4H(true, 1); else V4H(false, 1); }
+      else       { if (rs) V4H(true, 2); else V4H(false, 2); }
+    } else if (gate) {
       if (small) { if (rs) V4X(true, 1, true, false); else V4X(false, 1, true, false); }
       else       { if (rs) V4X(true, 2, true, false); else V4X(false, 2, true, false); }
     } else {
@@ -1893,6 +1946,7 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
       else       { if (rs) V4X(true, 2, false, true); else V4X(false, 2, false, true); }
     }
 #undef V4X
+#undef V4H
     return sisr_check_launch();
   }
   if (variant == 4 || variant == 5 || variant == 6) {
@@ -1936,6 +1990,8 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
           hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, true, false, 1, false, false, true>), grid2, dim3(256), lb2, st, p);
         else if (leaky)
           hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, 1, false, false, true>), grid2, dim3(256), lb2, st, p);
+        else if (aff && head)
+          hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 1, false, false, false, 0, 2>), grid2, dim3(256), lb2, st, p);
         else if (aff)
           hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 1>), grid2, dim3(256), lb2, st, p);
         else if (msk)
@@ -1951,6 +2007,8 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
         hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, true, false, 2, false, false, true>), grid, dim3(256), lb, st, p);
       else if (leaky)
         hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, 2, false, false, true>), grid, dim3(256), lb, st, p);
+      else if (aff && head)
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 2, false, false, false, 0, 2>), grid, dim3(256), lb, st, p);
       else if (aff)
         hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 2>), grid, dim3(256), lb, st, p);
       else if (msk)
@@ -1961,12 +2019,12 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
         hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, 2>), grid, dim3(256), lb, st, p);
       return sisr_check_launch();
     }
-    if (tail) return SISR_ERR_UNSUPPORTED;  // the general kernel has no tail
+    if (tail || head) return SISR_ERR_UNSUPPORTED;  // the general kernel has neither tails nor heads
     const size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
     hipLaunchKernelGGL(conv3x3_c64_kernel<0>, grid, dim3(256), lb, st, p);
     return sisr_check_launch();
   }
-  if (tail) return SISR_ERR_UNSUPPORTED;
+  if (tail || head) return SISR_ERR_UNSUPPORTED;
   const size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
 #ifdef SISR_DIAG
   if (variant == 13)

@@ -167,7 +167,8 @@ class CaTail(ctypes.Structure):
     workgroup of the conv launch that writes its partial sums."""
     _fields_ = [("backward", c_int), ("hidden", c_int), ("inv_hw", c_float)] + \
                [(n, c_void_p) for n in ("w1", "b1", "w2", "b2", "mul", "s", "hid", "ca", "s_out", "hid_out", "ca_out", "g_out",
-                                        "shift", "dmul", "dw1", "db1", "dw2", "db2", "workspace", "counter")]
+                                        "shift", "dmul", "dw1", "db1", "dw2", "db2", "workspace", "counter", "head_part")] + \
+               [("head_parts", c_int), ("head", c_int)]
 
 
 _tail_counters = {}

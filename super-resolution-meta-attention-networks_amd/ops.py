@@ -384,6 +384,14 @@ def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_sc
 # Weight gradients of one geometry are launched eight at a time while a launch is small (<= BATCH_WGRAD_MAX_PIXELS pixels per
 # map: up to 8 tiles of 128 x 128 per GPU -- BASELINE config 4 has 4): see csrc/wgrad3x3_mfma.hip wgrad3x3_c64_batch_kernel.
 BATCH_WGRAD = os.environ.get("SISR_BATCH_WGRAD", "1") != "0"
+# ... and in the same regime the channel-attention gate (and its backward) is computed by the conv that consumes it (gate
+# HEADS, csrc/conv3x3_mfma.hip template HEAD) instead of a 6 us launch of its own between two convs of the serial chain.
+GATE_HEADS = os.environ.get("SISR_GATE_HEADS", "1") != "0"
+GATE_HEADS_MAX_PIXELS = int(os.environ.get("SISR_GATE_HEADS_MAX_PIXELS", 4 * 128 * 128))  # measured: +2.3 % at 4 tiles, -1 % at 8
+# jobs per launch: the library's maximum, 8 (full per-job argument records by value in the launch arguments).  A variant with
+# slim records and up to 48 jobs per launch (a whole group's 41 in one) was tried: the argument struct copied per job went to
+# scratch memory and the step got 11 % slower; eight also keeps what the jobs read (2 x 8 maps of 16.8 MB) recent.
+BATCH_WGRAD_JOBS = int(os.environ.get("SISR_BATCH_WGRAD_JOBS", 8))
 BATCH_WGRAD_MAX_PIXELS = int(os.environ.get("SISR_BATCH_WGRAD_MAX_PIXELS", 8 * 128 * 128))
 
 
@@ -393,7 +401,7 @@ class WgradQueue:
 
     def __init__(self, B, H, W, device):
         self.geo, self.device, self.jobs = (B, H, W), device, []
-        self.max = hip.lib().sisr_wgrad3x3_c64_batch_max()
+        self.max = min(BATCH_WGRAD_JOBS, hip.lib().sisr_wgrad3x3_c64_batch_max())
 
     @staticmethod
     def wanted(B, H, W):
@@ -947,6 +955,7 @@ class _GatedGroup(Function):
         need = any(ctx.needs_input_grad)
         parts = gap_parts(H, W)
         tails = _use_ca_tail(B, H, W)
+        heads = GATE_HEADS and not tails and WgradQueue.wanted(B, H, W) and B * H * W <= GATE_HEADS_MAX_PIXELS
         PER = _GatedGroup.PER
         cur, pend = x, None
         tensors, packs, meta = [], [], []
@@ -965,7 +974,7 @@ class _GatedGroup(Function):
             else:
                 u = _empty_cl(B, 64, H, W, dev)
                 conv_c64(pend[0], v, p1, b1, (1, 64), t1, v, B, H, W, 64, 64, relu=True, in_scale=pend[1], gate_add=cur,
-                         gate_out=u)
+                         gate_out=u, ca_tail=pend[2])
                 cur = u
             t2 = _empty_cl(B, 64, H, W, dev)
             gap = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
@@ -976,12 +985,21 @@ class _GatedGroup(Function):
             if tails:  # the gate is computed by conv2's last-arriving workgroup per sample
                 conv_c64(t1, v, p2, b2, (1, 64), t2, v, B, H, W, 64, 64, gap=gap,
                          ca_tail=_tail_fwd(B, H, W, R, caw1c, cab1, caw2c, cab2, mm, sv, hid, ca, g, dev))
+            elif heads:  # the gate is computed by the conv that consumes it (the next block's conv1, or the group's tail conv)
+                conv_c64(t1, v, p2, b2, (1, 64), t2, v, B, H, W, 64, 64, gap=gap)
+                hd = hip.CaTail()
+                hd.backward, hd.hidden, hd.inv_hw, hd.head, hd.head_parts = 0, R, 1.0 / (H * W), 1, parts
+                cb1, cb2 = cab1.contiguous(), cab2.contiguous()
+                hd.w1, hd.b1, hd.w2, hd.b2, hd.mul = hip.ptr(caw1c), hip.ptr(cb1), hip.ptr(caw2c), hip.ptr(cb2), hip.ptr(mm)
+                hd.s_out, hd.hid_out, hd.ca_out, hd.g_out = hip.ptr(sv), hip.ptr(hid), hip.ptr(ca), hip.ptr(g)
+                hd.head_part = hip.ptr(gap)
+                head_keep = (hd, gap, cb1, cb2, mm)
             else:
                 conv_c64(t1, v, p2, b2, (1, 64), t2, v, B, H, W, 64, 64, gap=gap)
                 hip.check(L.sisr_ca_gate_fwd(hip.ptr(gap), parts, B, 1.0 / (H * W), hip.ptr(caw1c), hip.ptr_c(cab1),
                                              hip.ptr(caw2c), hip.ptr_c(cab2), 64, R, hip.ptr(mm), hip.ptr(sv),
                                              hip.ptr(hid), hip.ptr(ca), hip.ptr(g), hip.stream()), "sisr_ca_gate_fwd")
-            pend = (t2, g)
+            pend = (t2, g, head_keep[0] if heads else None, head_keep if heads else None)
             blk = [cur, w1, w2, t1, t2, caw1c, caw2c, sv, hid, ca, g] + ([mm] if mm is not None else [])
             meta.append((len(blk), mm is not None, tuple(caw1.shape), tuple(caw2.shape)))
             tensors += blk
@@ -990,7 +1008,8 @@ class _GatedGroup(Function):
         wt = wt.contiguous()
         pt, pdt = pack(wt)
         un, out = _empty_cl(B, 64, H, W, dev), _empty_cl(B, 64, H, W, dev)
-        conv_c64(pend[0], v, pt, bt, (1, 64), out, v, B, H, W, 64, 64, in_scale=pend[1], gate_add=cur, gate_out=un, res=x)
+        conv_c64(pend[0], v, pt, bt, (1, 64), out, v, B, H, W, 64, 64, in_scale=pend[1], gate_add=cur, gate_out=un, res=x,
+                 ca_tail=pend[2])
         ctx.save_for_backward(*tensors, un, wt)
         ctx.cfg = (n, (B, H, W), meta, parts)
         ctx.packs, ctx.pdt = packs, pdt
@@ -1062,7 +1081,17 @@ class _GatedGroup(Function):
                 pd1, pd2 = ctx.packs[k]
                 R = caw1c.shape[0]
                 shift, dmv, dcaw1, dcab1, dcaw2, dcab2 = (go[key] for key in ("shift", "dmv", "dcaw1", "dcab1", "dcaw2", "dcab2"))
-                if not tails and queue is not None:
+                bhead = None
+                if not tails and queue is not None and GATE_HEADS and B * H * W <= GATE_HEADS_MAX_PIXELS:
+                    # ... and the per-sample part is computed by the conv that consumes `shift` (gate head)
+                    dzw = torch.empty((B, 80), device=dev)
+                    bhead = hip.CaTail()
+                    bhead.backward, bhead.hidden, bhead.inv_hw, bhead.head, bhead.head_parts = 1, R, 1.0 / hw, 1, parts
+                    bhead.w1, bhead.w2, bhead.hid, bhead.ca, bhead.mul = (hip.ptr(caw1c), hip.ptr(caw2c), hip.ptr(hid), hip.ptr(ca),
+                                                                          hip.ptr(mm))
+                    bhead.shift, bhead.dmul, bhead.workspace, bhead.head_part = hip.ptr(shift), hip.ptr(dmv), hip.ptr(dzw), hip.ptr(dgp)
+                    gate_jobs.append((dzw, hid, s, dcaw1, dcab1, dcaw2, dcab2, R))
+                elif not tails and queue is not None:
                     # small launches: the chain kernel only produces what the next conv waits for; the gates' parameter
                     # gradients of the whole group are one launch at the end (their dz2 / dz1 wait in per-gate workspaces)
                     dzw = torch.empty((B, 80), device=dev)
@@ -1079,15 +1108,14 @@ class _GatedGroup(Function):
                               "sisr_ca_gate_bwd")
                 dw2, db2 = _grad_buf(w2), torch.empty(64, device=dev)
                 dw1, db1 = _grad_buf(w1), torch.empty(64, device=dev)
-                if queue is not None:
-                    queue.add(t1, dy, dw2, db2, dy_scale=g, dy_shift=shift)
-                else:
+                if queue is None:
                     run(lambda t1=t1, dy=dy, dw2=dw2, db2=db2, g=g, shift=shift:
                         wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, dy_scale=g, dy_shift=shift),
                         (t1, dy, g, shift, dw2, db2))
                 dt1 = _empty_cl(B, 64, H, W, dev)
-                conv_c64(dy, v, pd2, None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1, in_scale=g, in_shift=shift)
-                if queue is not None:
+                conv_c64(dy, v, pd2, None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1, in_scale=g, in_shift=shift, ca_tail=bhead)
+                if queue is not None:  # after the conv above: with a gate head it is that launch which fills `shift`
+                    queue.add(t1, dy, dw2, db2, dy_scale=g, dy_shift=shift)
                     queue.add(xk, dt1, dw1, db1)
                 else:
                     run(lambda xk=xk, dt1=dt1, dw1=dw1, db1=db1: wgrad_c64(xk, v, dt1, v, dw1, db1, B, H, W, 64, 64),

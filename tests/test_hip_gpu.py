@@ -187,6 +187,40 @@ def test_channel_attention_tails_are_bit_identical_to_the_gate_launches(meta):
         assert torch.equal(res["1"][1][k], res["0"][1][k]), k
 
 
+@pytest.mark.parametrize("meta", [False, True])
+@pytest.mark.parametrize("shape", [(3, 37, 70), (2, 128, 128)])  # both within ops.GATE_HEADS_MAX_PIXELS
+def test_gate_heads_are_bit_identical_to_the_gate_launches(meta, shape):
+    """Small launches: the channel-attention gate and its backward are computed by the conv that CONSUMES them (gate heads,
+    ops.GATE_HEADS; every workgroup for its own sample) and the gates' parameter gradients by one launch per group -- against
+    the stand-alone gate launches: same device functions (ca_gate.h), same summation order -> equal to the bit.  Both tile
+    heights (the second shape has enough tiles for the 4-row kernel)."""
+    torch.manual_seed(8)
+    if meta:
+        net = A.QRCAN(n_resblocks=3, n_resgroups=2, n_feats=64, scale=2, style="standard", num_metadata=10,
+                      include_q_layer=True).to(DEV)
+    else:
+        net = A.RCAN(n_resblocks=3, n_resgroups=2, n_feats=64, scale=2).to(DEV)
+    B, H, W = shape
+    x = rnd(B, 3, H, W, seed=80, scale=0.5).to(DEV)
+    md = rnd(B, 10, 1, 1, seed=81, scale=0.3).to(DEV)
+    cot, res, prev = None, {}, ops.GATE_HEADS
+    assert ops.WgradQueue.wanted(B, H, W) or ops.PRECISION != "fp32"
+    try:
+        for mode in (True, False):
+            ops.GATE_HEADS = mode
+            net.zero_grad(set_to_none=True)
+            out = net(x, md) if meta else net(x)
+            if cot is None:
+                cot = rnd(*out.shape, seed=82).to(DEV)
+            out.backward(cot)
+            res[mode] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    finally:
+        ops.GATE_HEADS = prev
+    assert torch.equal(res[True][0], res[False][0])
+    for k in res[True][1]:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
+
+
 def test_conv_residual_alpha_and_multichunk():
     # 128 -> 192 channels, y = conv*alpha + res  (multi-chunk K loop and multiple output chunks)
     B, H, W = 1, 9, 35
@@ -383,9 +417,9 @@ def test_edsr_reduced_vs_oracle(scale):
     net_vs_oracle(net, "edsr", dict(num_blocks=2, scale=scale, res_scale=0.1), rnd(1, 3, 17, 23, seed=32, scale=0.5))
 
 
-@pytest.mark.parametrize("shape,njobs", [((4, 128, 128), 8), ((2, 37, 45), 5), ((1, 16, 32), 1), ((3, 9, 70), 3)])
+@pytest.mark.parametrize("shape,njobs", [((4, 128, 128), 8), ((2, 37, 45), 5), ((1, 16, 32), 1), ((3, 9, 70), 3), ((2, 64, 64), 41)])
 def test_batched_weight_gradients_equal_single_launches(shape, njobs):
-    """ops.WgradQueue (eight 64 -> 64 weight gradients of one geometry per launch, csrc/wgrad3x3_mfma.hip
+    """ops.WgradQueue (eight 64 -> 64 weight gradients of one geometry per launch; 41 jobs = six launches, csrc/wgrad3x3_mfma.hip
     wgrad3x3_c64_batch_kernel): every job equals its own single launch -- bit for bit when the K-split is the same (one job),
     to summation-order rounding otherwise; jobs with and without the dY * scale + shift rebuild and with / without a bias."""
     B, H, W = shape
