@@ -100,6 +100,11 @@ def _grad_buf(w):
     return torch.empty_like(w)
 
 
+def _grad_buf_or(p, n, device):
+    """_grad_buf for an optional small parameter (bias): a plain [n] buffer when there is none."""
+    return _grad_buf(p) if p is not None else torch.empty(n, device=device)
+
+
 def _side_ok(*weights):
     """Weight gradients may be produced on the side stream (which re-joins the main stream only at the end of the
     backward pass) iff autograd will merely ADOPT them: with an existing .grad AccumulateGrad would run
@@ -958,7 +963,7 @@ class _GatedGroup(Function):
         heads = GATE_HEADS and not tails and WgradQueue.wanted(B, H, W) and B * H * W <= GATE_HEADS_MAX_PIXELS
         PER = _GatedGroup.PER
         cur, pend = x, None
-        tensors, packs, meta = [], [], []
+        tensors, packs, meta, small = [], [], [], []
 
         def pack(w):
             return pack_pair(w) if need else (pack_weight(w, "fwd"), None)
@@ -1000,6 +1005,7 @@ class _GatedGroup(Function):
                                              hip.ptr(caw2c), hip.ptr_c(cab2), 64, R, hip.ptr(mm), hip.ptr(sv),
                                              hip.ptr(hid), hip.ptr(ca), hip.ptr(g), hip.stream()), "sisr_ca_gate_fwd")
             pend = (t2, g, head_keep[0] if heads else None, head_keep if heads else None)
+            small.append((b1, b2, caw1, cab1, caw2, cab2))
             blk = [cur, w1, w2, t1, t2, caw1c, caw2c, sv, hid, ca, g] + ([mm] if mm is not None else [])
             meta.append((len(blk), mm is not None, tuple(caw1.shape), tuple(caw2.shape)))
             tensors += blk
@@ -1013,6 +1019,7 @@ class _GatedGroup(Function):
         ctx.save_for_backward(*tensors, un, wt)
         ctx.cfg = (n, (B, H, W), meta, parts)
         ctx.packs, ctx.pdt = packs, pdt
+        ctx.small, ctx.bt = small, bt  # the small parameters: their gradients go straight into the optimiser's arena too
         return out
 
     @staticmethod
@@ -1045,7 +1052,7 @@ class _GatedGroup(Function):
             queue = WgradQueue(B, H, W, dev) if WgradQueue.wanted(B, H, W) else None
             gate_jobs = []
             # tail conv: weight gradient from (u_n, dout); dU_n = convT(dout), with sum(dU_n * t2_n) on the side
-            dwt, dbt = _grad_buf(wt), torch.empty(64, device=dev)
+            dwt, dbt = _grad_buf(wt), _grad_buf_or(ctx.bt, 64, dev)
             if queue is not None:
                 queue.add(un, dout, dwt, dbt)
             else:
@@ -1056,9 +1063,9 @@ class _GatedGroup(Function):
                 """Outputs of block k's gate backward (allocated before the conv launch whose tail fills them)."""
                 tens, has_m, s_caw1, s_caw2 = blocks[k]
                 R = tens[5].shape[0]
+                _, _, caw1, cab1, caw2, cab2 = ctx.small[k]
                 return dict(shift=_vec(B, 64, dev), dmv=_vec(B, 64, dev) if has_m else None,
-                            dcaw1=torch.empty(s_caw1, device=dev), dcab1=torch.empty(R, device=dev),
-                            dcaw2=torch.empty(s_caw2, device=dev), dcab2=torch.empty(64, device=dev))
+                            dcaw1=_grad_buf(caw1), dcab1=_grad_buf(cab1), dcaw2=_grad_buf(caw2), dcab2=_grad_buf(cab2))
 
             def tail_for(k, o):
                 if not tails:
@@ -1106,8 +1113,8 @@ class _GatedGroup(Function):
                                                  hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
                                                  hip.ptr(_gate_ws(B, dev)), hip.gate_counter(dev), hip.stream()),
                               "sisr_ca_gate_bwd")
-                dw2, db2 = _grad_buf(w2), torch.empty(64, device=dev)
-                dw1, db1 = _grad_buf(w1), torch.empty(64, device=dev)
+                dw2, db2 = _grad_buf(w2), _grad_buf_or(ctx.small[k][1], 64, dev)
+                dw1, db1 = _grad_buf(w1), _grad_buf_or(ctx.small[k][0], 64, dev)
                 if queue is None:
                     run(lambda t1=t1, dy=dy, dw2=dw2, db2=db2, g=g, shift=shift:
                         wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, dy_scale=g, dy_shift=shift),

@@ -50,9 +50,8 @@ class FlatAdam(optim.Adam):
                 p.data = view
         self.grad_views = {p: self._view(self.flat_g, p) for p in ps}
         from . import ops
-        for p, view in self.grad_views.items():  # conv weight gradients are produced straight into the arena
-            if p.dim() == 4:
-                ops.GRAD_SINK[p.data_ptr()] = view
+        for p, view in self.grad_views.items():  # gradients the kernels can produce straight into the arena
+            ops.GRAD_SINK[p.data_ptr()] = view
         self._t = 0          # steps taken
         self._missed = {}    # parameter -> number of those steps it had no gradient in (torch counts per parameter)
         self._plan = None    # (frozenset of skipped parameters, [(offset, length, step count)])

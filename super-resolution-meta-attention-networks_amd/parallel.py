@@ -118,7 +118,7 @@ class GradReducer:
         if self.cuda:
             from . import ops
             for p, view in self.views.items():
-                if p.dim() == 4 and p.is_contiguous():
+                if p.is_contiguous():
                     ops.GRAD_SINK[p.data_ptr()] = view
         self.pending = [len(b) for b in self.buckets]
         self.works = [None] * len(self.buckets)
