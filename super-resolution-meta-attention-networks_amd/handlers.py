@@ -210,7 +210,8 @@ class BaseModel(nn.Module):
                 with torch.cuda.stream(side):  # one eager pass off the default stream: allocator + lazy-init warm-up
                     self.optimizer.zero_grad(set_to_none=True)
                     ops.pack_all(self.net, A.conv_weights)
-                    self.criterion(self.run_model(sx, **kw), sy).backward()
+                    with ops.deferred_wgrads():
+                        self.criterion(self.run_model(sx, **kw), sy).backward()
                 torch.cuda.current_stream().wait_stream(side)
                 self.optimizer.zero_grad(set_to_none=True)
                 graph = torch.cuda.CUDAGraph()
@@ -218,7 +219,8 @@ class BaseModel(nn.Module):
                     ops.pack_all(self.net, A.conv_weights)  # first node of the graph: the replay repacks
                     out = self.run_model(sx, **kw)
                     loss = self.criterion(out, sy)
-                    loss.backward()
+                    with ops.deferred_wgrads():  # reducer hooks are off here: nothing reads a gradient before the join
+                        loss.backward()
                 grads = [(p, p.grad) for p in self.net.parameters()]
                 entry = (graph, sx, sy, se, loss, out, grads)
                 self._graphs[key] = entry
@@ -251,7 +253,8 @@ class BaseModel(nn.Module):
 
     def standard_update(self, loss):
         self.optimizer.zero_grad()
-        loss.backward()
+        with ops.deferred_wgrads(enabled=self.reducer is None):  # with a reducer its hooks read gradients mid-backward
+            loss.backward()
         self._finish_update()
 
     def _finish_update(self):

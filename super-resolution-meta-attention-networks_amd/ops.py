@@ -105,11 +105,16 @@ def _grad_buf_or(p, n, device):
     return _grad_buf(p) if p is not None else torch.empty(n, device=device)
 
 
-def _side_ok(*weights):
-    """Weight gradients may be produced on the side stream (which re-joins the main stream only at the end of the
+def _side_ok(*weights, pixels=None):
+    """pixels (B * H * W of the launches): inside a deferred_wgrads() block small weight gradients are queued for batched
+    launches on the main stream instead (a queue flushed from the side stream would read operands the allocator only tracks
+    on the main stream).
+    Weight gradients may be produced on the side stream (which re-joins the main stream only at the end of the
     backward pass) iff autograd will merely ADOPT them: with an existing .grad AccumulateGrad would run
     `p.grad += dw` on the main stream before the side-stream kernel has written dw."""
     if not (WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False and all(w.grad is None for w in weights)):
+        return False
+    if _DEFERRED is not None and pixels is not None and PRECISION == "fp32" and pixels <= BATCH_WGRAD_MAX_PIXELS:
         return False
     # under hipGraph capture the fork / join would become graph edges (SISR_GRAPH_FORK=1); default: one stream
     return GRAPH_FORK or not torch.cuda.is_current_stream_capturing()
@@ -365,9 +370,49 @@ def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=
     hip.check(rc, name)
 
 
+_DEFERRED = None  # {(B, H, W, device index): WgradQueue} while a deferred_wgrads() block is open
+_DEFERRED_STREAM = None  # the stream the block was opened on: launches issued from another stream are not queued
+
+
+class deferred_wgrads:
+    """While open (around ONE backward pass), plain 64 -> 64 weight gradients of small launches are queued and go out eight at
+    a time (WgradQueue), the rest when the block closes.  Only sound when nothing reads a parameter gradient before the block
+    closes and every gradient is merely ADOPTED by autograd (grads None on entry): the handlers open it when no reducer hook
+    can fire (single process, or hipGraph capture / replay where the buckets are reduced at the join).  The queued launches
+    write into the tensors autograd has adopted as .grad (weight AND bias of the conv: both are assumed trainable together)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled and BATCH_WGRAD
+
+    def __enter__(self):
+        global _DEFERRED, _DEFERRED_STREAM
+        if self.enabled:
+            _DEFERRED, _DEFERRED_STREAM = {}, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED
+        queues, _DEFERRED = _DEFERRED, None
+        if queues and exc[0] is None:
+            for q in queues.values():
+                q.flush()
+        return False
+
+
 def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_scale=None, dy_shift=None, shuffle=1,
-              active_units=0):
-    """active_units (fp32 kernel): bit mask of the 32 x 32-channel blocks of the gradient to compute (0 = all)."""
+              active_units=0, owner=None):
+    """active_units (fp32 kernel): bit mask of the 32 x 32-channel blocks of the gradient to compute (0 = all).
+    owner: the weight Parameter -- with it, inside a deferred_wgrads() block, an eligible launch is queued instead."""
+    if (_DEFERRED is not None and hip.stream() == _DEFERRED_STREAM and owner is not None and owner.requires_grad and
+            owner.grad is None and cin == 64 and cout == 64 and shuffle == 1 and
+            alpha == 1.0 and not active_units and WgradQueue.wanted(B, H, W) and xview is hip.view_plain(H, W, 64) and
+            dyview is hip.view_plain(H, W, 64)):
+        key = (B, H, W, x.device.index)
+        q = _DEFERRED.get(key)
+        if q is None:
+            q = _DEFERRED[key] = WgradQueue(B, H, W, x.device)
+        q.add(x, dy, dw, db, dy_scale=dy_scale, dy_shift=dy_shift, hold_outputs=False)
+        return
     L = hip.lib()
     fp32 = False
     if PRECISION == "bf16x3" and X3_WGRAD:
@@ -412,8 +457,15 @@ class WgradQueue:
     def wanted(B, H, W):
         return BATCH_WGRAD and PRECISION == "fp32" and B * H * W <= BATCH_WGRAD_MAX_PIXELS
 
-    def add(self, x, dy, dw, db, dy_scale=None, dy_shift=None):
-        self.jobs.append((x, dy, dy_scale, dy_shift, dw, db))
+    def add(self, x, dy, dw, db, dy_scale=None, dy_shift=None, hold_outputs=True):
+        """hold_outputs=False: keep only the ADDRESSES of dw / db.  A queue that outlives the autograd node must not hold
+        references to the gradients the node returns: AccumulateGrad adopts a gradient only if it holds the sole reference and
+        clones it otherwise -- the clone would be taken before the launch has written it.  The parameter's .grad keeps the
+        buffers alive until the flush."""
+        if hold_outputs:
+            self.jobs.append((x, dy, dy_scale, dy_shift, dw, db))
+        else:
+            self.jobs.append((x, dy, dy_scale, dy_shift, hip.ptr(dw), hip.ptr(db)))
         if len(self.jobs) == self.max:
             self.flush()
 
@@ -425,7 +477,7 @@ class WgradQueue:
         arr = (hip.WgradJob * n)()
         for k, (x, dy, sc, sh, dw, db) in enumerate(self.jobs):
             arr[k].x, arr[k].dy, arr[k].dy_scale, arr[k].dy_shift = hip.ptr(x), hip.ptr(dy), hip.ptr(sc), hip.ptr(sh)
-            arr[k].dw, arr[k].dbias = hip.ptr(dw), hip.ptr(db)
+            arr[k].dw, arr[k].dbias = (dw, db) if isinstance(dw, int) else (hip.ptr(dw), hip.ptr(db))
         nbytes = L.sisr_wgrad3x3_c64_batch_workspace_bytes(n, B, H, W)
         ws = hip.workspace(self.device, nbytes)
         v = hip.view_plain(H, W, 64)
@@ -543,7 +595,7 @@ class _Conv3x3(Function):
                     dw = _grad_buf(w)
                     db = torch.empty(cout, device=dev, dtype=torch.float32) if ctx.has_bias else None
                     wgrad_c64(x, hip.view_plain(H, W, cin), dy, dyview, dw, db, B, H, W, cin, cout, alpha=ctx.alpha,
-                              shuffle=r)
+                              shuffle=r, owner=w)
                 if ctx.has_res and need_r:
                     dres = dy
             elif ctx.kind == "cin3":
@@ -900,10 +952,10 @@ class _ResBlock(Function):
             dw2, db2 = _grad_buf(w2), torch.empty(C, device=dev)
             dw1, db1 = _grad_buf(w1), torch.empty(C, device=dev)
             # plain first-order backward only; not under hipGraph capture (record_stream + private pools)
-            side = _side_ok(w1, w2)
+            side = _side_ok(w1, w2, pixels=B * H * W)
 
             def wgrad2():
-                wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, C, C, alpha=rs, dy_scale=scale, dy_shift=shift)
+                wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, C, C, alpha=rs, dy_scale=scale, dy_shift=shift, owner=w2)
 
             if side:
                 ev = torch.cuda.Event()
@@ -916,7 +968,7 @@ class _ResBlock(Function):
                 wgrad2()
 
             def wgrad1():
-                wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, C, C)
+                wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, C, C, owner=w1)
 
             # conv1 backward (+ skip connection gradient)
             if side:
@@ -1205,13 +1257,13 @@ class _ConvReluConv(Function):
             dt1 = _empty_cl(B, 64, H, W, dev)
             conv_c64(dt2, v, pack_weight(w2, "dgrad"), None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1)
             dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
-            wgrad_c64(t1, v, dt2, v, dw2, db2, B, H, W, 64, 64)
+            wgrad_c64(t1, v, dt2, v, dw2, db2, B, H, W, 64, 64, owner=w2)
             dx = None
             if ctx.needs_input_grad[0]:
                 dx = _empty_cl(B, 64, H, W, dev)
                 conv_c64(dt1, v, pack_weight(w1, "dgrad"), None, (1, 64), dx, v, B, H, W, 64, 64)
             dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
-            wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64)
+            wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64, owner=w1)
             return dx, dw1, db1, dw2, db2
         finally:
             IN_BACKWARD = False
@@ -1639,11 +1691,11 @@ class _SftmdHead(Function):
             d3 = _cl(d3)
             v64 = hip.view_plain(H, W, 64)
             dw3, db3 = _grad_buf(w3), torch.empty(64, device=dev)
-            wgrad_c64(y2, v64, d3, v64, dw3, db3, B, H, W, 64, 64)
+            wgrad_c64(y2, v64, d3, v64, dw3, db3, B, H, W, 64, 64, owner=w3)
             d2 = _empty_cl(B, 64, H, W, dev)
             conv_c64(d3, v64, pd3, None, (1, 64), d2, v64, B, H, W, 64, 64, mask=y2, relu=LEAKY_MASK)
             dw2, db2 = _grad_buf(w2), torch.empty(64, device=dev)
-            wgrad_c64(y1, v64, d2, v64, dw2, db2, B, H, W, 64, 64)
+            wgrad_c64(y1, v64, d2, v64, dw2, db2, B, H, W, 64, 64, owner=w2)
             d1 = _empty_cl(B, 64, H, W, dev)
             conv_c64(d2, v64, pd2, None, (1, 64), d1, v64, B, H, W, 64, 64, mask=y1, relu=LEAKY_MASK)
             dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
@@ -1745,7 +1797,7 @@ class _SftmdTail(Function):
                 g = gin
             v64 = hip.view_plain(H, W, 64)
             dwm, dbm = _grad_buf(wm), torch.empty(64, device=dev)
-            wgrad_c64(maps[0], v64, g, v64, dwm, dbm, B, H, W, 64, 64)
+            wgrad_c64(maps[0], v64, g, v64, dwm, dbm, B, H, W, 64, 64, owner=wm)
             grads[0], grads[1] = dwm, dbm
             dfea = None
             if ctx.needs_input_grad[0]:
