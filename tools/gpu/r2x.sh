@@ -1,5 +1,5 @@
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2x4; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2x5; mkdir -p $O
 cd $R
 timeout -k 10 1000 python -m pytest tests -m gpu -q --capture=sys > $O/pytest.log 2>&1 || { tail -60 $O/pytest.log; exit 1; }
 tail -2 $O/pytest.log
