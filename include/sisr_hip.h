@@ -313,6 +313,14 @@ int sisr_crop_augment(const float* const* src, const int* params, float* dst, in
 int sisr_diag_mfma_peak(int blocks, int iters, float* out, unsigned long long* clk, void* stream);
 /* resident workgroups per CU the runtime computes for the plain bf16x3 (which = 0) / fp32 (1) conv kernel */
 int sisr_diag_conv_occupancy(int which);
+/* every later conv3x3_c64_v4_kernel launch writes, per wave, 8 uint32 {start (shader clock), start (100 MHz clock), staging,
+ * K loop, epilogue (shader cycles), HW_ID, XCC_ID, lifetime (100 MHz ticks)} into buf (device, workgroups*4*8 words); nullptr switches it off
+ * (tools/conv_timeline.py) */
+void sisr_diag_conv_stamp(void* buf);
+/* the cost of `count` (0 with kind 1, else 8 / 16 / 32) filler instructions of one kind per eight v_mfma_f32_32x32x2_f32
+ * (kinds: csrc/diag.hip); clk = {shader cycles, 100 MHz ticks} of block 0's loop (tools/mfma_fill.py) */
+int sisr_diag_mfma_fill(int blocks, int iters, int kind, int count, float* out, const float* src, unsigned long long* clk,
+                        void* stream);
 #endif
 
 /* ---- fp32 through the bf16 matrix cores ("bf16x3", opt-in; the reference has no such mode) -----------------------

@@ -76,6 +76,9 @@ struct ConvParams {
   // blocks above carry the operands (fwd_tail: HEAD 1, bwd_tail: HEAD 2; counters and parameter-gradient fields unused).
   const float* head_part;  // [B][head_parts][64]
   int head_parts;
+#ifdef SISR_DIAG
+  unsigned* stamp;  // diagnostic library only: per wave {start lo, start hi, staging, K loop, epilogue, HW_ID, XCC_ID, 0}
+#endif
 };
 
 // General kernel: every prologue / epilogue combination, XOR-swizzled LDS (16-B chunk k of halo pixel p lives
@@ -322,6 +325,13 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
   const int co = ch * 32 + n;
   const int Cout = p.cout_chunks * 64;
 
+#ifdef SISR_DIAG
+  unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
+  if (p.stamp) {
+    st0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   const float bv = p.bias ? p.bias[co * p.bias_n + q * p.bias_q] : 0.f;
   f32x16 acc0, acc1;  // acc1 is dead code for MT == 1
 #pragma unroll
@@ -458,6 +468,9 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
       }
     }
     __syncthreads();
+#ifdef SISR_DIAG
+    if (p.stamp) st1 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- K loop, fully unrolled: 72 steps x 8 MFMAs; every address is lane constant + immediate
     const float* wq = p.w + ((long)q * p.cin_chunks + c) * (9 * 64 * 64);  // scalar
@@ -542,6 +555,9 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
   }
 
   // ---- epilogue
+#ifdef SISR_DIAG
+  if (p.stamp) st2 = __builtin_amdgcn_s_memtime();
+#endif
   float os = p.alpha;
   if (p.out_scale) os *= p.out_scale[(long)b * Cout + q * 64 + co];
   const float lo = p.relu ? 0.f : -3.402823466e38f;
@@ -619,6 +635,24 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
       }
     }
   }
+#ifdef SISR_DIAG
+  if (p.stamp) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      unsigned* dbg = p.stamp + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+      const unsigned long long rt3 = __builtin_amdgcn_s_memrealtime();
+      dbg[0] = (unsigned)(st0 & 0xffffffffu);
+      dbg[1] = (unsigned)(rt0 & 0xffffffffu);  // 100 MHz, chip-wide: aligns the workgroups of different XCDs
+      dbg[2] = (unsigned)(st1 - st0);
+      dbg[3] = (unsigned)(st2 - st1);
+      dbg[4] = (unsigned)(st3 - st2);
+      dbg[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11));   // HW_REG_HW_ID
+      dbg[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11));  // HW_REG_XCC_ID
+      dbg[7] = (unsigned)(rt3 - rt0);
+    }
+  }
+#endif
   if (HEAD == 0 && (p.fwd_tail.g || p.bwd_tail.shift)) {  // uniform
     const long parts = (long)p.tiles_w * ((H + 3) / 4) * 2;
     const unsigned per_sample = gridDim.x / (unsigned)p.B;  // workgroups of one sample (cout_chunks == 1 here)
@@ -1798,6 +1832,11 @@ extern "C" size_t sisr_ca_tail_bytes() { return sizeof(sisr_ca_tail_host); }
 
 extern "C" int sisr_conv3x3_c64_gap_parts(int H, int W) { return ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * 2; }
 
+#ifdef SISR_DIAG
+static unsigned* g_diag_conv_stamp = nullptr;  // diagnostic library only (the product library keeps no state)
+extern "C" void sisr_diag_conv_stamp(void* buf) { g_diag_conv_stamp = static_cast<unsigned*>(buf); }
+#endif
+
 extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked, const float* bias,
                                 int bias_n, int bias_q, float* y, const int64_t* yview, const float* res,
                                 const float* mask, const float* in_scale, const float* in_shift,
@@ -1851,6 +1890,9 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
     return SISR_ERR_ALIGN;
   ConvParams p;
   memset(&p, 0, sizeof(p));
+#ifdef SISR_DIAG
+  p.stamp = g_diag_conv_stamp;
+#endif
   p.x = x;
   p.xv = view_from(xview);
   p.y = y;

@@ -59,6 +59,8 @@ _SIGS = {
 OPTIONAL_SIGS = {  # only in libsisr_hip_diag.so (csrc/build.sh diag; select it with SISR_HIP_LIB)
     "sisr_diag_mfma_peak": (c_int, [c_int, c_int, P, P, P]),
     "sisr_diag_conv_occupancy": (c_int, [c_int]),
+    "sisr_diag_conv_stamp": (None, [P]),
+    "sisr_diag_mfma_fill": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
 }
 _SIGS.update({
     "sisr_lam_workspace_bytes": (c_size_t, [c_int, c_int, c_long]),

@@ -379,24 +379,46 @@ class deferred_wgrads:
     a time (WgradQueue), the rest when the block closes.  Only sound when nothing reads a parameter gradient before the block
     closes and every gradient is merely ADOPTED by autograd (grads None on entry): the handlers open it when no reducer hook
     can fire (single process, or hipGraph capture / replay where the buckets are reduced at the join).  The queued launches
-    write into the tensors autograd has adopted as .grad (weight AND bias of the conv: both are assumed trainable together)."""
+    write into the tensors autograd has adopted as .grad (weight AND bias of the conv: both are assumed trainable together).
+
+    Two guards keep a queued gradient from ever being read unwritten:
+      * the block flushes on EVERY exit, exceptional ones included: a queue entry keeps the storages of its output buffers
+        alive (not the tensors -- see WgradQueue.add), so the late launches are memory-safe even if the backward pass died
+        before autograd adopted them, and every .grad that was adopted holds its gradient when the block has closed;
+      * a weight is queued at most once per block: a second weight gradient of the same parameter (a conv weight used twice
+        in one backward) first flushes every queue -- autograd sums the two results as soon as the second arrives, on this
+        stream -- and is launched directly."""
 
     def __init__(self, enabled=True):
         self.enabled = enabled and BATCH_WGRAD
 
     def __enter__(self):
-        global _DEFERRED, _DEFERRED_STREAM
+        global _DEFERRED, _DEFERRED_STREAM, _DEFERRED_OWNERS
         if self.enabled:
             _DEFERRED, _DEFERRED_STREAM = {}, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
+            _DEFERRED_OWNERS = set()
         return self
 
     def __exit__(self, *exc):
-        global _DEFERRED
-        queues, _DEFERRED = _DEFERRED, None
-        if queues and exc[0] is None:
+        global _DEFERRED, _DEFERRED_OWNERS
+        queues, _DEFERRED, _DEFERRED_OWNERS = _DEFERRED, None, None
+        if queues:
             for q in queues.values():
-                q.flush()
+                try:
+                    q.flush()
+                except Exception:
+                    if exc[0] is None:
+                        raise  # on an exceptional exit the first error is the one to report
         return False
+
+
+_DEFERRED_OWNERS = None  # ids of the weights with a queued gradient in the open deferred_wgrads() block
+
+
+def _flush_deferred():
+    if _DEFERRED:
+        for q in _DEFERRED.values():
+            q.flush()
 
 
 def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_scale=None, dy_shift=None, shuffle=1,
@@ -407,12 +429,16 @@ def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_sc
             owner.grad is None and cin == 64 and cout == 64 and shuffle == 1 and
             alpha == 1.0 and not active_units and WgradQueue.wanted(B, H, W) and xview is hip.view_plain(H, W, 64) and
             dyview is hip.view_plain(H, W, 64)):
-        key = (B, H, W, x.device.index)
-        q = _DEFERRED.get(key)
-        if q is None:
-            q = _DEFERRED[key] = WgradQueue(B, H, W, x.device)
-        q.add(x, dy, dw, db, dy_scale=dy_scale, dy_shift=dy_shift, hold_outputs=False)
-        return
+        if id(owner) in _DEFERRED_OWNERS:
+            _flush_deferred()  # second gradient of one weight in this pass: the first must be written before autograd adds them
+        else:
+            _DEFERRED_OWNERS.add(id(owner))
+            key = (B, H, W, x.device.index)
+            q = _DEFERRED.get(key)
+            if q is None:
+                q = _DEFERRED[key] = WgradQueue(B, H, W, x.device)
+            q.add(x, dy, dw, db, dy_scale=dy_scale, dy_shift=dy_shift, hold_outputs=False)
+            return
     L = hip.lib()
     fp32 = False
     if PRECISION == "bf16x3" and X3_WGRAD:
@@ -458,14 +484,16 @@ class WgradQueue:
         return BATCH_WGRAD and PRECISION == "fp32" and B * H * W <= BATCH_WGRAD_MAX_PIXELS
 
     def add(self, x, dy, dw, db, dy_scale=None, dy_shift=None, hold_outputs=True):
-        """hold_outputs=False: keep only the ADDRESSES of dw / db.  A queue that outlives the autograd node must not hold
-        references to the gradients the node returns: AccumulateGrad adopts a gradient only if it holds the sole reference and
-        clones it otherwise -- the clone would be taken before the launch has written it.  The parameter's .grad keeps the
-        buffers alive until the flush."""
+        """hold_outputs=False: keep only the ADDRESSES of dw / db, and their STORAGES.  A queue that outlives the autograd node
+        must not hold references to the gradient tensors the node returns: AccumulateGrad adopts a gradient only if it holds
+        the sole reference to the tensor and clones it otherwise -- the clone would be taken before the launch has written it.
+        A storage reference does not count there, and it keeps the memory from being recycled before the flush even when
+        the backward pass dies before the gradient is adopted."""
         if hold_outputs:
-            self.jobs.append((x, dy, dy_scale, dy_shift, dw, db))
+            self.jobs.append((x, dy, dy_scale, dy_shift, dw, db, None))
         else:
-            self.jobs.append((x, dy, dy_scale, dy_shift, hip.ptr(dw), hip.ptr(db)))
+            keep = (dw.untyped_storage(), db.untyped_storage() if db is not None else None)
+            self.jobs.append((x, dy, dy_scale, dy_shift, hip.ptr(dw), hip.ptr(db), keep))
         if len(self.jobs) == self.max:
             self.flush()
 
@@ -475,7 +503,7 @@ class WgradQueue:
         B, H, W = self.geo
         L, n = hip.lib(), len(self.jobs)
         arr = (hip.WgradJob * n)()
-        for k, (x, dy, sc, sh, dw, db) in enumerate(self.jobs):
+        for k, (x, dy, sc, sh, dw, db, _) in enumerate(self.jobs):
             arr[k].x, arr[k].dy, arr[k].dy_scale, arr[k].dy_shift = hip.ptr(x), hip.ptr(dy), hip.ptr(sc), hip.ptr(sh)
             arr[k].dw, arr[k].dbias = (dw, db) if isinstance(dw, int) else (hip.ptr(dw), hip.ptr(db))
         nbytes = L.sisr_wgrad3x3_c64_batch_workspace_bytes(n, B, H, W)

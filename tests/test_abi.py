@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -41,8 +43,58 @@ def test_product_library_has_no_process_wide_switches():
     import torch  # noqa: F401
     lib = ctypes.CDLL(path)
     for name in ("sisr_conv3x3_c64_set_variant", "sisr_conv3x3_c64_bf16_set_persistent", "sisr_diag_mfma_peak",
-                 "sisr_diag_conv_occupancy"):
+                 "sisr_diag_conv_occupancy", "sisr_diag_conv_stamp"):
         assert not hasattr(lib, name), name
+
+
+def _integration_sample():
+    """The Level-2 binding sample of INTEGRATION.md, verbatim."""
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        doc = f.read()
+    blocks = re.findall(r"```python\n(.*?)```", doc, flags=re.S)
+    hit = [b for b in blocks if "lib.sisr_conv3x3_c64(" in b]
+    assert len(hit) == 1
+    return hit[0]
+
+
+def _call_arg_count(src, fn):
+    """Number of top-level arguments of the first call of `fn` in Python source `src`."""
+    import ast
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == fn:
+            return len(node.args)
+    raise AssertionError(fn)
+
+
+def test_integration_sample_passes_as_many_arguments_as_the_header_declares():
+    """INTEGRATION.md once fell one argument behind include/sisr_hip.h (ca_tail): a maintainer following it would have
+    passed the stream as `select`.  The documented calls must match the declared prototypes argument for argument."""
+    with open(os.path.join(ROOT, "include", "sisr_hip.h")) as f:
+        hdr = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    src = _integration_sample()
+    import sisr_amd
+    for fn in ("sisr_conv3x3_c64", "sisr_pack_conv3x3"):
+        proto = re.search(r"\b%s\s*\((.*?)\)\s*;" % fn, hdr, flags=re.S).group(1)
+        n_decl = len([a for a in proto.split(",") if a.strip()])
+        assert _call_arg_count(src, fn) == n_decl == len(sisr_amd.hip._SIGS[fn][1]), fn
+
+
+@pytest.mark.gpu
+def test_integration_level2_sample_runs_verbatim():
+    """Executes the documented binding as written (ref it replaces: advanced/common.py:5-8 default_conv + ReLU) and checks
+    its result against F.conv2d."""
+    import torch
+    import torch.nn.functional as F
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)  # the sample opens the library by its path relative to the repository root
+    try:
+        exec(compile(_integration_sample(), "INTEGRATION.md:level-2", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv2d(ns["x"].cpu().double(), ns["w"].cpu().double(), ns["bias"].cpu().double(), padding=1))
+    assert (ns["y"].cpu().double() - ref).abs().max().item() < 2e-5
 
 
 def test_pure_host_queries():

@@ -944,3 +944,45 @@ def test_hip_graph_replay_matches_eager():
         losses[mode] = (ls, float(sum(p.double().sum() for p in h.net.parameters())))
     assert np.allclose(losses[True][0], losses[False][0], rtol=0, atol=1e-6), losses
     assert abs(losses[True][1] - losses[False][1]) < 1e-5
+
+
+# ----------------------------------------------------------------------------- deferred weight-gradient queue: guards
+def _two_conv_grads(shared, deferred, fail=False):
+    g = torch.Generator(device="cpu").manual_seed(70)
+    x = torch.randn(2, 64, 24, 40, generator=g).to(DEV)
+    w1 = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    w2 = w1 if shared else (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    b1 = torch.randn(64, generator=g).to(DEV).requires_grad_(True)
+    b2 = torch.randn(64, generator=g).to(DEV).requires_grad_(True)
+    dy = torch.randn(2, 64, 24, 40, generator=g).to(DEV)
+    y = ops.conv3x3(ops.conv3x3(x, w1, b1), w2, b2)
+    try:
+        with ops.deferred_wgrads(enabled=deferred):
+            y.backward(dy)
+            if fail:
+                raise KeyError("the step dies after backward, inside the block")
+    except KeyError:
+        assert fail
+    torch.cuda.synchronize()
+    return [t.grad.detach().cpu().clone() for t in ((w1, b1, b2) if shared else (w1, w2, b1, b2))]
+
+
+def test_deferred_wgrad_block_flushes_on_exceptional_exit():
+    """A deferred_wgrads() block that exits on an exception still launches what it queued: the gradients autograd adopted
+    hold their values (not uninitialised memory) when the block has closed."""
+    assert ops.WgradQueue.wanted(2, 24, 40)
+    plain = _two_conv_grads(False, False)
+    died = _two_conv_grads(False, True, fail=True)
+    for a, b in zip(plain, died):
+        assert torch.equal(a, b)
+
+
+def test_deferred_wgrad_queue_takes_a_weight_once_per_pass():
+    """One 64 -> 64 weight used by two convs of the same backward pass: the second weight gradient is not queued (autograd
+    adds the two as soon as the second arrives) and the first is flushed before it; result = the undeferred one."""
+    plain = _two_conv_grads(True, False)
+    queued = _two_conv_grads(True, True)
+    for a, b in zip(plain, queued):
+        assert torch.equal(a, b)
+    ref_w = plain[0].double()
+    assert torch.isfinite(ref_w).all() and ref_w.abs().max() > 0

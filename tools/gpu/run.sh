@@ -1,0 +1,73 @@
+#!/usr/bin/env bash
+# One parameterised lease script for the GPU box:  gpurun -- 'bash tools/gpu/run.sh RECIPE [ARGS] [-- RECIPE [ARGS]]...'
+# Outputs go to gpurun_out/<recipe>/ (merged back by gpurun); summaries worth keeping are copied to profiles/ by hand.
+set -eo pipefail
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+cd "$R"
+DIAG=$R/super-resolution-meta-attention-networks_amd/libsisr_hip_diag.so
+
+prof() {  # prof OUTDIR NAME python-args...   (rocprofv3 kernel-trace summary -> OUTDIR/kernel_stats_NAME.csv)
+  local O=$1 name=$2; shift 2
+  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$O/prof_$name" -o p -- python "$@" > "$O/prof_$name.log" 2>&1 )
+  python tools/rocpd_stats.py "$O/prof_$name/p_results.db" > "$O/kernel_stats_$name.csv"
+  rm -rf "$O/prof_$name"
+}
+
+recipe() {
+  local RECIPE=$1; shift
+  local O=$R/gpurun_out/$RECIPE; mkdir -p "$O"
+  case "$RECIPE" in
+    tests)      # the driver's GPU tier
+      timeout -k 10 1100 python -m pytest tests -m gpu -q -x --capture=sys "$@" > "$O/pytest.log" 2>&1 || { tail -60 "$O/pytest.log"; return 1; }
+      tail -3 "$O/pytest.log"
+      python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.log" 2>&1 || { tail -20 "$O/smoke.log"; return 1; }
+      tail -1 "$O/smoke.log" ;;
+    pytest)     # selected tests: pytest ARGS
+      timeout -k 10 1100 python -m pytest -q -x --capture=sys "$@" > "$O/pytest.log" 2>&1 || { tail -80 "$O/pytest.log"; return 1; }
+      tail -5 "$O/pytest.log" ;;
+    timeline)   # in-kernel stamps of the fp32 conv (diagnostic library): timeline [BATCHES] [FORMS]
+      for b in ${1:-4 32}; do for f in ${2:-plain mask gate}; do
+        SISR_HIP_LIB=$DIAG timeout -k 10 120 python tools/conv_timeline.py $b $f > "$O/timeline_b${b}_$f.json" 2> "$O/timeline_b${b}_$f.err" || tail -5 "$O/timeline_b${b}_$f.err"
+        head -1 "$O/timeline_b${b}_$f.json" | cut -c1-1400
+      done; done ;;
+    kbench)     # kbench [BATCHES] [extra kbench args]
+      local bs=${1:-4 32}; shift || true
+      for b in $bs; do timeout -k 10 200 python tools/kbench.py --batch $b --iters 30 --only conv,conv_dgrad2,conv_res,conv_relu_gap,wgrad,wgrad_affine "$@" > "$O/kbench_b$b.jsonl"; cat "$O/kbench_b$b.jsonl"; done ;;
+    peak)       # sustained fp32 MFMA rate and in-kernel clock, trivial and random operands
+      SISR_HIP_LIB=$DIAG timeout -k 10 200 python tools/mfma_peak.py > "$O/mfma_peak.jsonl" 2>&1; cat "$O/mfma_peak.jsonl" ;;
+    fill)       # cost of filler instructions beside the fp32 MFMA stream
+      SISR_HIP_LIB=$DIAG timeout -k 10 300 python tools/mfma_fill.py > "$O/mfma_fill.jsonl" 2>&1; cat "$O/mfma_fill.jsonl" ;;
+    copies)
+      timeout -k 10 300 python tools/copy_probe.py 4 qrcan > "$O/copies_qrcan_b4.txt" 2>&1 || true
+      tail -70 "$O/copies_qrcan_b4.txt" ;;
+    bench)      # bench TAG bench.py-args...  -> gpurun_out/bench/bench_TAG.json
+      local tag=$1; shift
+      timeout -k 10 900 python bench.py "$@" > "$O/bench_$tag.json" 2> "$O/bench_$tag.err" || { tail -20 "$O/bench_$tag.err"; return 1; }
+      python - "$O/bench_$tag.json" <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])
+print(sys.argv[1].split('/')[-1], 'value', round(d['value'], 2), 'ms', round(d['ms_per_step'], 2), 'frac', (d.get('roofline') or {}).get('frac'))
+for f in (d.get('roofline') or {}).get('families') or []:
+    print('   ', f['family'][:50], f['launches_per_step'], round(f['avg_launch_us'], 1), round(f['frac'], 3))
+for k in ('config4_point', 'han_bf16', 'meta_rcan', 'bf16x3'):
+    if k in d:
+        print('   ', k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in d[k].items() if not isinstance(b, (dict, list, str))})
+PY
+      ;;
+    profile)    # profile TAG bench.py-args...  -> rocprofv3 kernel summary of that bench command
+      local tag=$1; shift
+      prof "$O" "$tag" "$R/bench.py" "$@"
+      head -14 "$O/kernel_stats_$tag.csv" | cut -c1-170 ;;
+    sh)         # sh 'command'   (ad-hoc)
+      bash -c "$1" > "$O/sh.log" 2>&1 || { tail -40 "$O/sh.log"; return 1; }
+      tail -40 "$O/sh.log" ;;
+    *) echo "unknown recipe $RECIPE"; return 2 ;;
+  esac
+}
+
+# several recipes in one lease: separated by `--`
+args=()
+for a in "$@"; do
+  if [ "$a" = "--" ]; then recipe "${args[@]}"; args=(); else args+=("$a"); fi
+done
+[ ${#args[@]} -gt 0 ] && recipe "${args[@]}"
