@@ -306,6 +306,9 @@ template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT 
 __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x3_c64_v4_kernel(ConvParams p) {
   constexpr int THv = 2 * MT, HHv = THv + 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // (Wave priorities were measured and left out: with staging and epilogue at s_setprio 3 the staging phase shrinks from
+  // 42 k to 7 k cycles -- the unbroken MFMA stream of an older wave otherwise starves it -- but launches take the same time
+  // or 1-2 % longer: the pipe is busy either way.)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.y;
   int bid;
@@ -390,11 +393,25 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
   for (int c = c_begin; c < p.cin_chunks; ++c) {
     if (KSEL != 3 && c) __syncthreads();
     float* ldsc = lds + (KSEL == 3 ? c * (HHv * HALO_W * 64) : 0);  // KSEL 3: both chunks' halos are resident
-    {  // ---- halo staging: thread = (chunk c4, column pcol + {0,16,32}), rows 0..5
+    // The first six weight fragments of the K loop are requested BEFORE the halo is staged: they do not depend on it, and a
+    // K loop that asks for them after the staging barrier opens with an L2 round trip (0.4-0.6 us per tile in which the
+    // matrix pipe of this workgroup's SIMDs idles unless another workgroup happens to be mid-loop; per-CU timelines from
+    // in-kernel stamps, tools/conv_timeline.py).
+    f32x4 bq[8];
+    const sisr_rsrc_t rw = sisr_rsrc(p.w + ((long)q * p.cin_chunks + c) * (9 * 64 * 64));
+    // (Not in the builds with an arithmetic staging prologue: there the 24 registers spill and the launch gets 2-3 % slower.)
+    constexpr bool EARLY_B = KSEL == 0 && !AFFINE && !GATE;
+    if constexpr (EARLY_B) {
+#pragma unroll
+      for (int s = 0; s < 6; ++s) bq[s] = sisr_buf_load4(rw, boff * 4u, (unsigned)(s * 2048));
+    }
+    {  // ---- halo staging: thread = (chunk c4, column pcol + {0,16,32}), rows 0..5.  Every access is {scalar resource of
+       // the sample's chunk, lane byte offset of (column, 16-B piece), scalar row offset}: no per-access address arithmetic on
+       // the vector unit, which the MFMA stream of the co-resident waves would pay for (sisr_common.h, buffer addressing)
       int tl = tid;
       asm volatile("" : "+v"(tl));  // keep the per-chunk address math out of the K loop's live ranges
       const int c4 = tl & 15, pcol = tl >> 4;
-      const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(c);
+      const sisr_rsrc_t rx = sisr_rsrc(p.x + (long)b * p.xv.sB + p.xv.chunk(c));  // scalar
       f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
       if (AFFINE) {
         s4 = *reinterpret_cast<const f32x4*>(p.in_scale + ((long)b * p.cin_chunks + c) * 64 + c4 * 4);
@@ -407,46 +424,60 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
         const int col = pcol + 16 * k;
         const int gw = w0 - 1 + col;
         cok[k] = gw >= 0 && gw < W && col < HALO_W;
-        goff[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c4 * 4);
+        goff[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c4 * 4) * 4u;  // bytes
         loff[k] = col * 64 + ((c4 ^ (col & 15)) << 2);
       }
+      // a tile whose halo lies inside the image needs no zero padding: its staging stores skip the masking (4 VALU per piece)
+      const bool interior = h0 >= 1 && h0 + THv + 1 <= H && w0 >= 1 && w0 + TW + 1 <= W;  // scalar
       if (!GATE) {
         f32x4 v[HHv][3];
 #pragma unroll
         for (int r = 0; r < HHv; ++r) {
-          const int gh = h0 - 1 + r;
-          const float* xrow = xb + (long)min(max(gh, 0), H - 1) * p.xv.sH;  // scalar
+          const unsigned ro = (unsigned)(min(max(h0 - 1 + r, 0), H - 1) * (int)p.xv.sH) * 4u;  // scalar, bytes
 #pragma unroll
           for (int k = 0; k < 3; ++k)
-            if (k < 2 || pcol < 2) v[r][k] = *reinterpret_cast<const f32x4*>(xrow + goff[k]);
+            if (k < 2 || pcol < 2) v[r][k] = sisr_buf_load4(rx, goff[k], ro);
         }
+        if (interior) {
 #pragma unroll
-        for (int r = 0; r < HHv; ++r) {
-          const int gh = h0 - 1 + r;
-          const bool rok = gh >= 0 && gh < H;  // scalar
+          for (int r = 0; r < HHv; ++r)
 #pragma unroll
-          for (int k = 0; k < 3; ++k)
-            if (k < 2 || pcol < 2) {
-              f32x4 t = v[r][k];
-              if (AFFINE) t = t * s4 + t4;
-              *reinterpret_cast<f32x4*>(ldsc + r * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
-            }
+            for (int k = 0; k < 3; ++k)
+              if (k < 2 || pcol < 2) {
+                f32x4 t = v[r][k];
+                if (AFFINE) t = t * s4 + t4;
+                *reinterpret_cast<f32x4*>(ldsc + r * (HALO_W * 64) + loff[k]) = t;
+              }
+        } else {
+#pragma unroll
+          for (int r = 0; r < HHv; ++r) {
+            const int gh = h0 - 1 + r;
+            const bool rok = gh >= 0 && gh < H;  // scalar
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              if (k < 2 || pcol < 2) {
+                f32x4 t = v[r][k];
+                if (AFFINE) t = t * s4 + t4;
+                *reinterpret_cast<f32x4*>(ldsc + r * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
+              }
+          }
         }
       } else {  // y = t * gate + skip on the fly; rows in batches of HHv / 2 (two operand tensors in flight)
         const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.in_scale + (long)b * 64 + c4 * 4);
-        const long boffs = (long)b * p.xv.sB;
+        const sisr_rsrc_t ru = sisr_rsrc(p.gate_add + (long)b * p.xv.sB);
+        const sisr_rsrc_t ro_ = sisr_rsrc(p.gate_out + (long)b * p.xv.sB);
         constexpr int RB = HHv / 2;
 #pragma unroll
         for (int r0 = 0; r0 < HHv; r0 += RB) {
           f32x4 v[RB][3], u[RB][3];
 #pragma unroll
           for (int r = 0; r < RB; ++r) {
-            const long ro = boffs + (long)min(max(h0 - 1 + r0 + r, 0), H - 1) * p.xv.sH;  // scalar
+            const unsigned ro = (unsigned)(min(max(h0 - 1 + r0 + r, 0), H - 1) * (int)p.xv.sH) * 4u;  // scalar, bytes
 #pragma unroll
             for (int k = 0; k < 3; ++k)
               if (k < 2 || pcol < 2) {
-                v[r][k] = *reinterpret_cast<const f32x4*>(p.x + ro + goff[k]);
-                u[r][k] = *reinterpret_cast<const f32x4*>(p.gate_add + ro + goff[k]);
+                v[r][k] = sisr_buf_load4(rx, goff[k], ro);
+                u[r][k] = sisr_buf_load4(ru, goff[k], ro);
               }
           }
 #pragma unroll
@@ -454,14 +485,15 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
             const int hr = r0 + r, gh = h0 - 1 + hr;
             const bool rok = gh >= 0 && gh < H;               // scalar
             const bool rown = hr >= 1 && hr <= THv && gh < H;  // scalar: a row this tile owns
-            const long ro = boffs + (long)min(max(gh, 0), H - 1) * p.xv.sH;
+            const unsigned ro = (unsigned)(min(max(gh, 0), H - 1) * (int)p.xv.sH) * 4u;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
               if (k < 2 || pcol < 2) {
                 const f32x4 t = sisr_mul_add4(v[r][k], g4, u[r][k]);
-                *reinterpret_cast<f32x4*>(lds + hr * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
+                if (interior) *reinterpret_cast<f32x4*>(lds + hr * (HALO_W * 64) + loff[k]) = t;
+                else *reinterpret_cast<f32x4*>(lds + hr * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
                 const int col = pcol + 16 * k;
-                if (rown && cok[k] && col >= 1 && col <= TW) *reinterpret_cast<f32x4*>(p.gate_out + ro + goff[k]) = t;
+                if (rown && cok[k] && col >= 1 && col <= TW) sisr_buf_store4(t, ro_, goff[k], ro);
               }
           }
         }
@@ -478,7 +510,8 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
       // NJ octets per tap starting at octet J0 (KSEL 1: J0 = 4q, folded into aoff and the weight base); same pipeline
       auto kloop = [&](auto nj_tag, const float* wb) {
         constexpr int NJ = decltype(nj_tag)::value, NS = 9 * NJ;
-        auto ldb = [&](int s) { return *reinterpret_cast<const f32x4*>(wb + ((s / NJ) * 8 + (s % NJ)) * 512 + boff); };
+        const sisr_rsrc_t rwb = sisr_rsrc(wb);
+        auto ldb = [&](int s) { return sisr_buf_load4(rwb, boff * 4u, (unsigned)(((s / NJ) * 8 + (s % NJ)) * 2048)); };
         auto lda = [&](int m, int s) {
           return *reinterpret_cast<const f32x4*>(lds + (((s / NJ) / 3 + m) * (HALO_W * 64)) + aoff[(s / NJ) % 3][s % NJ]);
         };
@@ -519,13 +552,14 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
         else kloop(std::integral_constant<int, 2>{}, wq);
       }
     } else {
-#define V4_LOAD_B(s) (*reinterpret_cast<const f32x4*>(wq + (s) * 512 + boff))
+#define V4_LOAD_B(s) sisr_buf_load4(rw, boff * 4u, (unsigned)((s) * 2048))
 #define V4_LOAD_A(m, s) \
   (*reinterpret_cast<const f32x4*>(lds + ((((s) >> 3) / 3 + (m)) * (HALO_W * 64)) + aoff[((s) >> 3) % 3][(s) & 7]))
-    f32x4 bq[8];
     f32x4 aq[4][2];
+    if constexpr (!EARLY_B) {
 #pragma unroll
-    for (int s = 0; s < 6; ++s) bq[s] = V4_LOAD_B(s);
+      for (int s = 0; s < 6; ++s) bq[s] = V4_LOAD_B(s);
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       aq[s][0] = V4_LOAD_A(0, s);
@@ -558,12 +592,21 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
 #ifdef SISR_DIAG
   if (p.stamp) st2 = __builtin_amdgcn_s_memtime();
 #endif
+  // Every VALU instruction here is paid in matrix-pipe time by the co-resident waves (~4.5 cycles each), so the optional
+  // steps are skipped by scalar branches rather than computed with neutral constants, and all addresses are {scalar resource
+  // of the tile, lane byte offset, scalar byte offset}.
   float os = p.alpha;
   if (p.out_scale) os *= p.out_scale[(long)b * Cout + q * 64 + co];
-  const float lo = p.relu ? 0.f : -3.402823466e38f;
-  const unsigned loff_y = (unsigned)(co + 4 * hh * (int)p.yv.sW);  // lane part of every output address
-  const long tile_base = (long)b * p.yv.sB + p.yv.chunk(q) + (long)w0 * p.yv.sW;  // scalar
-  const bool full = (h0 + THv <= H) && (w0 + TW <= W);                             // scalar
+  const bool scaled = p.out_scale != nullptr || p.alpha != 1.0f;                    // scalar
+  const bool want_sum = p.gap != nullptr;                                           // scalar
+  const unsigned loff_y = (unsigned)(co + 4 * hh * (int)p.yv.sW) * 4u;              // lane part of every output address, bytes
+  const long tile_base = (long)b * p.yv.sB + p.yv.chunk(q) + (long)w0 * p.yv.sW;    // scalar
+  const bool full = (h0 + THv <= H) && (w0 + TW <= W);                              // scalar
+  const unsigned swb = (unsigned)p.yv.sW * 4u;                                      // bytes per pixel column
+  const sisr_rsrc_t ry = sisr_rsrc(p.y + tile_base);
+  const sisr_rsrc_t rmk = sisr_rsrc(MASK ? p.mask + tile_base : p.y);
+  const sisr_rsrc_t rrs = sisr_rsrc(RES ? p.res + tile_base : p.y);
+  const sisr_rsrc_t rdt = sisr_rsrc(DOT ? p.dot + tile_base : p.y);
   float grow[2] = {0.f, 0.f};  // per output row: the GAP partial is (row 0) + (row 1) of a 2-row strip
   // Epilogue operands (ReLU mask / residual / DOT map) of BOTH output rows are requested before the first store: y, mask,
   // res and dot are distinct buffers, but the compiler cannot know that, and with loads and stores interleaved it emitted
@@ -573,16 +616,16 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
   float mk[MT][16], rs[MT][16], dt[MT][16];
   auto fetch = [&](int m, bool first_set, bool second_set) {
     const int row = h0 + MT * ph + m;
-    const long row_base = tile_base + (long)min(row, H - 1) * p.yv.sH;  // scalar
+    const unsigned row_off = (unsigned)(min(row, H - 1) * (int)p.yv.sH) * 4u;  // scalar, bytes
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cr = (r & 3) + 8 * (r >> 2);
-      // partial tiles: unconditional loads from a clamped (in-image) address instead of a branch + wait per element
-      const long off = full ? row_base + (long)cr * p.yv.sW
-                            : row_base + (long)(min(w0 + cr + 4 * hh, W - 1) - (w0 + 4 * hh)) * p.yv.sW;
-      if (MASK && first_set) mk[m][r] = (p.mask + off)[loff_y];
-      if (RES && first_set) rs[m][r] = (p.res + off)[loff_y];
-      if (DOT && (TWO_SETS ? second_set : first_set)) dt[m][r] = (p.dot + off)[loff_y];
+      // partial tiles: unconditional loads from a clamped (in-image) column instead of a branch + wait per element
+      const unsigned vo = full ? loff_y : (unsigned)(co + (min(w0 + cr + 4 * hh, W - 1) - w0) * (int)p.yv.sW) * 4u;
+      const unsigned so = full ? row_off + (unsigned)cr * swb : row_off;
+      if (MASK && first_set) mk[m][r] = sisr_buf_load1(rmk, vo, so);
+      if (RES && first_set) rs[m][r] = sisr_buf_load1(rrs, vo, so);
+      if (DOT && (TWO_SETS ? second_set : first_set)) dt[m][r] = sisr_buf_load1(rdt, vo, so);
     }
   };
 #pragma unroll
@@ -591,30 +634,43 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
   for (int m = 0; m < MT; ++m) {
     float gsum = 0.f;
     const int row = h0 + MT * ph + m;
-    const f32x16 acc = m ? acc1 : acc0;
-    const long row_base = tile_base + (long)row * p.yv.sH;  // scalar
+    f32x16 acc = m ? acc1 : acc0;
+    const unsigned row_off = (unsigned)(row * (int)p.yv.sH) * 4u;  // scalar, bytes (used for in-image rows only)
     if (TWO_SETS) fetch(m, false, true);
+    if (LEAKY && !MASK) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = acc[r] > 0.f ? acc[r] : 0.2f * acc[r];
+    } else if (p.relu) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+    }
+    if (scaled) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] *= os;
+    }
+    if (MASK) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = mk[m][r] > 0.f ? acc[r] : (LEAKY ? 0.2f * acc[r] : 0.f);
+    }
+    if (RES) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += rs[m][r];
+    }
     if (full) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long off = row_base + (long)((r & 3) + 8 * (r >> 2)) * p.yv.sW;  // scalar
-        float v = (LEAKY && !MASK ? (acc[r] > 0.f ? acc[r] : 0.2f * acc[r]) : fmaxf(acc[r], lo)) * os;
-        if (MASK) v = mk[m][r] > 0.f ? v : (LEAKY ? 0.2f * v : 0.f);
-        if (RES) v += rs[m][r];
-        (p.y + off)[loff_y] = v;
-        gsum = DOT ? __builtin_fmaf(v, dt[m][r], gsum) : gsum + v;  // explicit fma: same bits in every build
+      for (int r = 0; r < 16; ++r)
+        sisr_buf_store1(acc[r], ry, loff_y, row_off + (unsigned)((r & 3) + 8 * (r >> 2)) * swb);
+      if (want_sum) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gsum = DOT ? __builtin_fmaf(acc[r], dt[m][r], gsum) : gsum + acc[r];  // explicit fma: same bits in every build
       }
     } else if (row < H) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cr = (r & 3) + 8 * (r >> 2);
         if (w0 + cr + 4 * hh < W) {
-          const long off = row_base + (long)cr * p.yv.sW;
-          float v = (LEAKY && !MASK ? (acc[r] > 0.f ? acc[r] : 0.2f * acc[r]) : fmaxf(acc[r], lo)) * os;
-          if (MASK) v = mk[m][r] > 0.f ? v : (LEAKY ? 0.2f * v : 0.f);
-          if (RES) v += rs[m][r];
-          (p.y + off)[loff_y] = v;
-          gsum = DOT ? __builtin_fmaf(v, dt[m][r], gsum) : gsum + v;  // explicit fma: same bits in every build
+          sisr_buf_store1(acc[r], ry, loff_y, row_off + (unsigned)cr * swb);
+          gsum = DOT ? __builtin_fmaf(acc[r], dt[m][r], gsum) : gsum + acc[r];  // explicit fma: same bits in every build
         }
       }
     }
@@ -1814,7 +1870,19 @@ extern "C" int sisr_pack_conv3x3_many(const void* jobs_device, int n_jobs, int t
 // Kernel selection (process-wide, read-only during launches): 4 = issue-lean kernel (2-row tiles on small grids,
 // 4-row tiles otherwise) with the general kernel as fallback (default); 5 / 6 = the same with the 4-row / 2-row
 // tile forced; 2 = general kernel only; 13 / 16 = diagnostic builds of the general kernel (see above).
-#define SMALL_GRID_BLOCKS 200  // 4-row-tile workgroups below which the 2-row kernel is used (measured: 1.6x at 128, a tie or worse from 256 up)
+// 4-row-tile workgroups below which the 2-row kernel is used.  Round 2 (weights fetched with 64-bit lane addresses: the
+// 2-row tile's twice-as-many weight loads per MFMA cost matrix-pipe time): 1.6x faster at 128 workgroups, a tie or worse from
+// 256 up, so 200.  With buffer-addressed weight loads (free beside the MFMAs) the 2-row tile wins at every size measured
+// (64 -> 64, 128 x 128 maps: 8 samples 85 vs 101 us, 16: 158 vs 170, 32: 296 vs 307): four resident workgroups per CU
+// instead of three and a finer last round.  SISR_CONV_TILE_ROWS=4 (read per call, no state kept) restores the old rule.
+#define SMALL_GRID_BLOCKS (sisr_small_grid_blocks())
+static inline long sisr_small_grid_blocks() {
+  const char* e = getenv("SISR_CONV_TILE_ROWS");
+  if (e && e[0] == '4') return 200;
+  if (e && e[0] == '2') return 0x7fffffffL;
+  if (const char* n = getenv("SISR_CONV_SMALL_BLOCKS")) return atol(n);
+  return 0x7fffffffL;
+}
 // Host-side description of a channel-attention tail (include/sisr_hip.h: sisr_ca_tail).
 struct sisr_ca_tail_host {
   int backward, hidden;

@@ -31,8 +31,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* __rest
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(RAND ? ra[e] : a, RAND ? rb[e] : b, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(RAND ? rb[e] : b, RAND ? ra[3 - e] : a, acc1, 0, 0, 0);
     }
-    a += 1e-7f;
-    if (RAND) { ra[i & 3] = -ra[i & 3]; rb[(i + 1) & 3] = -rb[(i + 1) & 3]; }
+    if (!RAND) a += 1e-7f;  // RAND: the eight operand registers stay as they are -- no vector instruction but the MFMAs
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();

@@ -42,6 +42,29 @@ __device__ __forceinline__ f32x4 sisr_mul_add4(f32x4 a, f32x4 b, f32x4 c) {
   return p + c;
 }
 
+// Buffer addressing.  Beside the fp32 MFMA stream a vector-memory instruction with a 64-bit per-lane address
+// (`global_load_dwordx4 v, v[a:a+1], off`) costs its SIMD 30-40 cycles, and every VALU instruction that builds such an
+// address ~4.5 more; the same access as SGPR resource + 32-bit lane offset + SGPR offset (`buffer_load_dwordx4 v, voff,
+// s[rsrc], soff offen`) is free at the K loop's density, like SALU work (measured: tools/mfma_fill.py).  So the hot
+// kernels address every operand as {wave-uniform base -> resource, lane-constant byte offset, scalar byte offset}.
+// Raw resource (stride 0), bounds check off (num_records = 2^32 - 1): the offsets are in range by construction.
+typedef __amdgpu_buffer_rsrc_t sisr_rsrc_t;
+__device__ __forceinline__ sisr_rsrc_t sisr_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xffffffffu, 0x00020000);
+}
+__device__ __forceinline__ f32x4 sisr_buf_load4(sisr_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
+}
+__device__ __forceinline__ float sisr_buf_load1(sisr_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff_bytes, (int)soff_bytes, 0));
+}
+__device__ __forceinline__ void sisr_buf_store4(f32x4 v, sisr_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff_bytes, (int)soff_bytes, 0);
+}
+__device__ __forceinline__ void sisr_buf_store1(float v, sisr_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff_bytes, (int)soff_bytes, 0);
+}
+
 #define SISR_OK 0
 #define SISR_ERR_ARG (-1)
 #define SISR_ERR_ALIGN (-2)

@@ -33,7 +33,8 @@ b = torch.randn(64, device=dev)
 sc, sh = torch.rand(B, 64, device=dev), torch.rand(B, 64, device=dev)
 pk = ops.pack_weight(w, "fwd")
 v = hip.view_plain(H, W, 64)
-nwg = B * (H // 4) * (W // 32)
+rows = 4 if os.environ.get("SISR_CONV_TILE_ROWS", "") == "4" else 2  # the library's tile-height rule for this grid
+nwg = B * (H // rows) * (W // 32)
 stamp = torch.zeros(nwg * 4 * 8, dtype=torch.int32, device=dev)
 L = hip.lib()
 
@@ -133,8 +134,8 @@ out["kloop_cover_of_span"] = {"mean": float(np.mean(cover)), "min": float(np.min
 out["workgroups_in_kloop_when_any"] = float(np.mean(conc))
 out["resident_workgroups_mean_over_span"] = float(np.mean(resident))
 out["workgroups_per_cu"] = {"mean": float(np.mean(nres)), "min": int(np.min(nres)), "max": int(np.max(nres))}
-out["mfma_cycles_per_wave"] = 576 * 64
-out["mfma_us_per_cu_at_this_clock"] = float(np.mean(nres)) * 576 * 64 / (ghz * 1e3)
+out["mfma_cycles_per_wave"] = 144 * rows * 64
+out["mfma_us_per_cu_at_this_clock"] = float(np.mean(nres)) * 144 * rows * 64 / (ghz * 1e3)
 rel = np.sort(w_s)
 out["start_quantiles_us"] = [round(float(rel[int(q * (len(rel) - 1))]), 2) for q in (0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 1.0)]
 rel = np.sort(w_e)

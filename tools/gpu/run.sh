@@ -33,6 +33,27 @@ recipe() {
     kbench)     # kbench [BATCHES] [extra kbench args]
       local bs=${1:-4 32}; shift || true
       for b in $bs; do timeout -k 10 200 python tools/kbench.py --batch $b --iters 30 --only conv,conv_dgrad2,conv_res,conv_relu_gap,wgrad,wgrad_affine "$@" > "$O/kbench_b$b.jsonl"; cat "$O/kbench_b$b.jsonl"; done ;;
+    ab)         # ab [BATCHES] [ONLY]: kbench with the library of the previous commit (_ab/libsisr_hip_old.so) and the current one, interleaved
+      local bs=${1:-4 32} only=${2:-conv_relu_gap,conv_dgrad2,conv_res,wgrad}
+      local OLD=$R/super-resolution-meta-attention-networks_amd/_ab/libsisr_hip_old.so
+      for b in $bs; do for rep in 1 2; do for lib in old new; do
+        if [ $lib = old ]; then export SISR_HIP_LIB=$OLD; else unset SISR_HIP_LIB; fi
+        timeout -k 10 200 python tools/kbench.py --batch $b --iters 40 --warm 60 --only $only 2>/dev/null | sed "s/^{/{\"lib\": \"$lib\", /" >> "$O/ab_b$b.jsonl"
+      done; done; done
+      unset SISR_HIP_LIB
+      python - "$O" $bs <<'PY'
+import json, sys, collections
+O = sys.argv[1]
+for b in sys.argv[2:]:
+    acc = collections.defaultdict(list)
+    for l in open(f"{O}/ab_b{b}.jsonl"):
+        if l.startswith('{'):
+            d = json.loads(l); acc[(d['kernel'], d['lib'])].append(d['us'])
+    for k in sorted({k for k, _ in acc}):
+        o, n = min(acc[(k, 'old')]), min(acc[(k, 'new')])
+        print(f"B={b} {k:16s} old {o:8.1f} us  new {n:8.1f} us  ({100 * (o / n - 1):+.1f} %)")
+PY
+      ;;
     peak)       # sustained fp32 MFMA rate and in-kernel clock, trivial and random operands
       SISR_HIP_LIB=$DIAG timeout -k 10 200 python tools/mfma_peak.py > "$O/mfma_peak.jsonl" 2>&1; cat "$O/mfma_peak.jsonl" ;;
     fill)       # cost of filler instructions beside the fp32 MFMA stream

@@ -18,8 +18,11 @@ import sisr_amd  # noqa: E402
 ops, hip = sisr_amd.ops, sisr_amd.hip
 
 
-def timeit(fn, iters, warm=3):
-    for _ in range(warm):
+WARM = [3]
+
+
+def timeit(fn, iters, warm=None):
+    for _ in range(WARM[0] if warm is None else warm):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,12 +39,14 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--hw", type=int, default=128)
+    ap.add_argument("--warm", type=int, default=3, help="untimed launches before each timed loop (clocks settle over tens of ms)")
     ap.add_argument("--only", default="")
     ap.add_argument("--variants", default="4,2", help="conv kernel selections to time: 4 auto, 5 / 6 forced 4-row / 2-row tile, 2 general")
     ap.add_argument("--rounds", type=int, default=0, help="interleaved A/B rounds over --variants (conv only)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"])
     a = ap.parse_args()
     ops.set_precision(a.precision)
+    WARM[0] = a.warm
     if a.precision != "fp32":
         a.variants = "4"  # one bf16 conv kernel; report GB/s of the two fp32 maps beside TFLOP/s
     only = set(a.only.split(",")) if a.only else None
