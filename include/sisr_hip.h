@@ -186,6 +186,12 @@ size_t sisr_meta_gate_many_bwd_workspace_bytes(int B, int hidden, int channels, 
 int sisr_meta_gate_many_bwd(const float* dm, const float* m, const float* hid, const float* md, int B, int M, int hidden,
                             int channels, int layers, const float* const* v1_table, const float* const* v2_table,
                             int relu, float* dv1, float* dc1, float* dv2, float* dc2, float* workspace, void* stream);
+/* the same, with each layer's four gradients written to the addresses in four device tables of `layers` pointers (e.g.
+ * slices of an optimiser's flat gradient arena) instead of into [layers][...] arrays */
+int sisr_meta_gate_many_bwd_scatter(const float* dm, const float* m, const float* hid, const float* md, int B, int M,
+                                    int hidden, int channels, int layers, const float* const* v1_table,
+                                    const float* const* v2_table, int relu, float* const* dv1_table, float* const* dc1_table,
+                                    float* const* dv2_table, float* const* dc2_table, float* workspace, void* stream);
 
 /* ---- generic gate MLP: the metadata-mixing QCALayer styles ---------------------------------------------
  * ref: attention_manipulators/architectures.py:105-127 (QCALayer.forward after avg_pool: 'modulate', 'max_concat',

@@ -232,6 +232,24 @@ __global__ __launch_bounds__(256) void meta_gate_many_bwd_param_kernel(const flo
                            dc1 + l * Hd, dv2 + l * C * Hd, dc2 + l * C);
 }
 
+// the same, every layer's four gradients written where the caller's tables point (the optimiser's gradient arena: the 800
+// small gradients of a QRCAN then need no gather before the update)
+struct MetaGradTables {
+  float* const* dv1;
+  float* const* dc1;
+  float* const* dv2;
+  float* const* dc2;
+};
+__global__ __launch_bounds__(256) void meta_gate_many_bwd_param_scatter_kernel(const float* __restrict__ dz2,
+                                                                               const float* __restrict__ dz1,
+                                                                               const float* __restrict__ hid,
+                                                                               const float* __restrict__ md, int B, int M,
+                                                                               int Hd, int C, MetaGradTables g) {
+  const long l = blockIdx.y;
+  meta_gate_bwd_param_body(dz2 + l * B * C, dz1 + l * B * Hd, hid + l * B * Hd, md, B, M, Hd, C, g.dv1[l], g.dc1[l], g.dv2[l],
+                           g.dc2[l]);
+}
+
 // ---------------------------------------------------------------- generic gate MLP (the metadata-mixing QCALayer styles)
 // ref: attention_manipulators/architectures.py:105-127.  After the global average pool every style is a 2..4 layer MLP
 // on a <= 74-element vector per sample, with the metadata vector concatenated to some layers' inputs:
@@ -720,6 +738,30 @@ extern "C" int sisr_meta_gate_many_bwd(const float* dm, const float* m, const fl
   const long total = (long)channels * hidden + (long)hidden * M + channels + hidden;
   hipLaunchKernelGGL(meta_gate_many_bwd_param_kernel, dim3((unsigned)((total + 255) / 256), layers), dim3(256), 0,
                      (hipStream_t)stream, dz2, dz1, hid, md, B, M, hidden, channels, dv1, dc1, dv2, dc2);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_meta_gate_many_bwd_scatter(const float* dm, const float* m, const float* hid, const float* md, int B,
+                                               int M, int hidden, int channels, int layers, const float* const* v1_table,
+                                               const float* const* v2_table, int relu, float* const* dv1_table,
+                                               float* const* dc1_table, float* const* dv2_table, float* const* dc2_table,
+                                               float* workspace, void* stream) {
+  if (!dm || !m || !hid || !md || !v1_table || !v2_table || !dv1_table || !dc1_table || !dv2_table || !dc2_table ||
+      !workspace || B <= 0 || layers <= 0)
+    return SISR_ERR_ARG;
+  const size_t lds = ((size_t)hidden + channels + (size_t)channels * hidden + (size_t)hidden * M) * sizeof(float);
+  if (lds > 60000 || layers > 65535) return SISR_ERR_UNSUPPORTED;
+  float* dz2 = workspace;
+  float* dz1 = workspace + (size_t)layers * B * channels;
+  const MetaTables t = {v1_table, nullptr, v2_table, nullptr};
+  hipLaunchKernelGGL(meta_gate_many_bwd_sample_kernel, dim3(B, layers), dim3(256), lds, (hipStream_t)stream, dm, m, hid, B,
+                     M, hidden, channels, t, relu, dz2, dz1);
+  int rc = sisr_check_launch();
+  if (rc) return rc;
+  const long total = (long)channels * hidden + (long)hidden * M + channels + hidden;
+  const MetaGradTables g = {dv1_table, dc1_table, dv2_table, dc2_table};
+  hipLaunchKernelGGL(meta_gate_many_bwd_param_scatter_kernel, dim3((unsigned)((total + 255) / 256), layers), dim3(256), 0,
+                     (hipStream_t)stream, dz2, dz1, hid, md, B, M, hidden, channels, g);
   return sisr_check_launch();
 }
 

@@ -25,6 +25,13 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifdef SISR_WT_STORES
+#define SISR_Y_STORE1 sisr_buf_store1_wt
+#define SISR_Y_STORE4 sisr_buf_store4_wt
+#else
+#define SISR_Y_STORE1 sisr_buf_store1
+#define SISR_Y_STORE4 sisr_buf_store4
+#endif
 #define TH 4
 #define TW 32
 #define HALO_H (TH + 2)
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
                 if (interior) *reinterpret_cast<f32x4*>(lds + hr * (HALO_W * 64) + loff[k]) = t;
                 else *reinterpret_cast<f32x4*>(lds + hr * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
                 const int col = pcol + 16 * k;
-                if (rown && cok[k] && col >= 1 && col <= TW) sisr_buf_store4(t, ro_, goff[k], ro);
+                if (rown && cok[k] && col >= 1 && col <= TW) SISR_Y_STORE4(t, ro_, goff[k], ro);
               }
           }
         }
@@ -659,7 +666,7 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
     if (full) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        sisr_buf_store1(acc[r], ry, loff_y, row_off + (unsigned)((r & 3) + 8 * (r >> 2)) * swb);
+        SISR_Y_STORE1(acc[r], ry, loff_y, row_off + (unsigned)((r & 3) + 8 * (r >> 2)) * swb);
       if (want_sum) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) gsum = DOT ? __builtin_fmaf(acc[r], dt[m][r], gsum) : gsum + acc[r];  // explicit fma: same bits in every build
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
       for (int r = 0; r < 16; ++r) {
         const int cr = (r & 3) + 8 * (r >> 2);
         if (w0 + cr + 4 * hh < W) {
-          sisr_buf_store1(acc[r], ry, loff_y, row_off + (unsigned)cr * swb);
+          SISR_Y_STORE1(acc[r], ry, loff_y, row_off + (unsigned)cr * swb);
           gsum = DOT ? __builtin_fmaf(acc[r], dt[m][r], gsum) : gsum + acc[r];  // explicit fma: same bits in every build
         }
       }

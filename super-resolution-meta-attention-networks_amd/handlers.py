@@ -215,12 +215,17 @@ class BaseModel(nn.Module):
                 torch.cuda.current_stream().wait_stream(side)
                 self.optimizer.zero_grad(set_to_none=True)
                 graph = torch.cuda.CUDAGraph()
+                dump = os.environ.get("SISR_GRAPH_DUMP")  # diagnostic: write the captured graph as a DOT file
+                if dump:
+                    graph.enable_debug_mode()
                 with torch.cuda.graph(graph):
                     ops.pack_all(self.net, A.conv_weights)  # first node of the graph: the replay repacks
                     out = self.run_model(sx, **kw)
                     loss = self.criterion(out, sy)
                     with ops.deferred_wgrads():  # reducer hooks are off here: nothing reads a gradient before the join
                         loss.backward()
+                if dump:
+                    graph.debug_dump(dump)
                 grads = [(p, p.grad) for p in self.net.parameters()]
                 entry = (graph, sx, sy, se, loss, out, grads)
                 self._graphs[key] = entry

@@ -84,6 +84,7 @@ _SIGS.update({  # step-level launches (round 2): all conv weights / all meta gat
     "sisr_meta_gate_many_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P]),
     "sisr_meta_gate_many_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "sisr_meta_gate_many_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P]),
+    "sisr_meta_gate_many_bwd_scatter": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P]),
 })
 _SIGS.update({  # generic gate MLP: the metadata-mixing QCALayer styles (csrc/attention.hip)
     "sisr_gate_mlp_desc_bytes": (c_size_t, []),

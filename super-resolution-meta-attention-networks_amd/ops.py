@@ -597,6 +597,7 @@ class _Conv3x3(Function):
                 f"3-channel RGB ends (the reference's in-scope configs all use n_feats = 64 or 256)")
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.bias = bias  # the leaf itself: its gradient goes straight into the optimiser's arena when it has a slot there
         return y
 
     @staticmethod
@@ -621,7 +622,7 @@ class _Conv3x3(Function):
                              alpha=ctx.alpha)
                 if need_w or need_b:
                     dw = _grad_buf(w)
-                    db = torch.empty(cout, device=dev, dtype=torch.float32) if ctx.has_bias else None
+                    db = _grad_buf(ctx.bias) if ctx.has_bias else None
                     wgrad_c64(x, hip.view_plain(H, W, cin), dy, dyview, dw, db, B, H, W, cin, cout, alpha=ctx.alpha,
                               shuffle=r, owner=w)
                 if ctx.has_res and need_r:
@@ -634,8 +635,8 @@ class _Conv3x3(Function):
                                               hip.ptr(dx), B, H, W, cout, hip.stream())
                     hip.check(rc, "sisr_conv3x3_cout3(dgrad)")
                 if need_w or need_b:
-                    dw = torch.empty_like(w)
-                    db = torch.empty(cout, device=dev, dtype=torch.float32) if ctx.has_bias else None
+                    dw = _grad_buf(w)
+                    db = _grad_buf(ctx.bias) if ctx.has_bias else None
                     nbytes = L.sisr_corr3x3_c3_workspace_bytes(B, H, W, cout)
                     ws = hip.workspace(dev, nbytes)
                     rc = L.sisr_corr3x3_c3(hip.ptr(x), hip.ptr(dy), hip.view_plain(H, W, cout), 1.0, hip.ptr(dw), 27, 9, 0,
@@ -649,8 +650,8 @@ class _Conv3x3(Function):
                                              hip.view_plain(H, W, cin), B, H, W, cin, hip.stream())
                     hip.check(rc, "sisr_conv3x3_cin3(dgrad)")
                 if need_w or need_b:
-                    dw = torch.empty_like(w)
-                    db = torch.empty(3, device=dev, dtype=torch.float32) if ctx.has_bias else None
+                    dw = _grad_buf(w)
+                    db = _grad_buf(ctx.bias) if ctx.has_bias else None
                     nbytes = L.sisr_corr3x3_c3_workspace_bytes(B, H, W, cin)
                     ws = hip.workspace(dev, nbytes)
                     rc = L.sisr_corr3x3_c3(hip.ptr(dy), hip.ptr(x), hip.view_plain(H, W, cin), 1.0, hip.ptr(dw), cin * 9, 9,
@@ -750,6 +751,7 @@ class _MetaGateMany(Function):
                   "sisr_meta_gate_many_fwd")
         ctx.save_for_backward(md2, hid, m, tab)
         ctx.cfg = (relu, L, B, M, Hd, C, [tuple(t.shape) for t in params[:4]])
+        ctx.params = params  # the leaves themselves: their gradient sinks are looked up in backward
         return m
 
     @staticmethod
@@ -758,13 +760,24 @@ class _MetaGateMany(Function):
         relu, L, B, M, Hd, C, shapes = ctx.cfg
         dev = md2.device
         dmc = dm.contiguous()
+        ws = torch.empty(L * B * (Hd + C), device=dev)
+        es = tab.element_size() * L
+        base = tab.data_ptr()
+        sinks = [GRAD_SINK.get(t.data_ptr()) for t in ctx.params]
+        if all(sk is not None and sk.shape == t.shape and t.grad is None for sk, t in zip(sinks, ctx.params)):
+            # every gradient goes straight into the optimiser's arena (no gather before the update, no per-layer copy)
+            gt = _meta_grad_table(sinks, dev)
+            ges = gt.element_size() * L
+            gb = gt.data_ptr()
+            hip.check(hip.lib().sisr_meta_gate_many_bwd_scatter(hip.ptr(dmc), hip.ptr(m), hip.ptr(hid), hip.ptr(md2), B, M, Hd, C,
+                                                                L, base, base + 2 * es, int(relu), gb, gb + ges, gb + 2 * ges,
+                                                                gb + 3 * ges, hip.ptr(ws), hip.stream()),
+                      "sisr_meta_gate_many_bwd_scatter")
+            return (None, None, *[sk.view(sk.shape) for sk in sinks])  # fresh aliases: autograd adopts what it alone holds
         dv1 = torch.empty((L,) + shapes[0], device=dev)
         dc1 = torch.empty((L,) + shapes[1], device=dev)
         dv2 = torch.empty((L,) + shapes[2], device=dev)
         dc2 = torch.empty((L,) + shapes[3], device=dev)
-        ws = torch.empty(L * B * (Hd + C), device=dev)
-        es = tab.element_size() * L
-        base = tab.data_ptr()
         hip.check(hip.lib().sisr_meta_gate_many_bwd(hip.ptr(dmc), hip.ptr(m), hip.ptr(hid), hip.ptr(md2), B, M, Hd, C, L,
                                                     base, base + 2 * es, int(relu), hip.ptr(dv1), hip.ptr(dc1),
                                                     hip.ptr(dv2), hip.ptr(dc2), hip.ptr(ws), hip.stream()),
@@ -773,6 +786,22 @@ class _MetaGateMany(Function):
         for l in range(L):  # row views: each is the only reference to its tensor object, so autograd adopts it
             grads += [dv1[l], dc1[l], dv2[l], dc2[l]]
         return (None, None, *grads)
+
+
+_meta_grad_tables = {}
+
+
+def _meta_grad_table(sinks, device):
+    """Device table [4][L] of the layers' gradient-sink addresses (dv1, dc1, dv2, dc2), rebuilt when a sink moved."""
+    ptrs = tuple(t.data_ptr() for t in sinks)
+    key = (device.index, len(ptrs))
+    hit = _meta_grad_tables.get(key)
+    if hit is None or hit[0] != ptrs:
+        L = len(ptrs) // 4
+        tab = torch.tensor([[ptrs[4 * l + k] for l in range(L)] for k in range(4)], dtype=torch.int64).to(device)
+        hit = (ptrs, tab)
+        _meta_grad_tables[key] = hit
+    return hit[1]
 
 
 def meta_gate_many(md, layers, relu):

@@ -18,22 +18,32 @@ torch.manual_seed(8)
 h = sisr_amd.available_models[name](device=0, model_save_dir="/tmp", eval_mode=False, scale=4, lr=1e-4, **kw)
 x, y = torch.rand(B, 3, 128, 128).cuda(), torch.rand(B, 3, 512, 512).cuda()
 extra = {"extra_channels": (torch.rand(B, 10, 1, 1) * 0.4).cuda()} if name.startswith("q") else {}
+if len(sys.argv) > 3:  # one-rank RCCL world, as bench.py --force-dp
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    h.set_multi_gpu()
 for _ in range(2):
     h.train_step(x, y, **extra)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     h.train_step(x, y, **extra)
     torch.cuda.synchronize()
 by = collections.Counter()
 kern = collections.Counter()
 for ev in prof.events():
-    if ev.device_type == torch.autograd.DeviceType.CUDA or "Memcpy" in ev.name or "copyBuffer" in ev.name:
-        kern[ev.name[:60]] += 1
-    if ev.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::_to_copy", "aten::fill_", "aten::zero_"):
-        st = [s for s in (ev.stack or []) if "repo" in s or "sisr" in s]
-        by[(ev.name, st[0] if st else (ev.stack[0] if ev.stack else "?"))] += 1
-for (n, s), c in by.most_common(40):
-    print(c, n, s)
+    if ev.device_type == torch.autograd.DeviceType.CUDA:
+        kern[ev.name[:70]] += 1
+    if ev.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::_to_copy", "aten::fill_", "aten::zero_", "aten::add_",
+                   "aten::add", "aten::mul", "aten::stack", "aten::cat"):
+        chain, q = [], ev.cpu_parent
+        while q is not None and len(chain) < 4:
+            chain.append(q.name[:60])
+            q = q.cpu_parent
+        by[(ev.name, tuple(str(s) for s in ev.input_shapes)[:2], " <- ".join(chain))] += 1
+for (n, shp, s), c in by.most_common(40):
+    print(c, n, shp, s)
 print("---- device activities")
-for n, c in kern.most_common(25):
+for n, c in kern.most_common(30):
     print(c, n)

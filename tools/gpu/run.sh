@@ -59,7 +59,7 @@ PY
     fill)       # cost of filler instructions beside the fp32 MFMA stream
       SISR_HIP_LIB=$DIAG timeout -k 10 300 python tools/mfma_fill.py > "$O/mfma_fill.jsonl" 2>&1; cat "$O/mfma_fill.jsonl" ;;
     copies)
-      timeout -k 10 300 python tools/copy_probe.py 4 qrcan > "$O/copies_qrcan_b4.txt" 2>&1 || true
+      timeout -k 10 300 python tools/copy_probe.py 4 qrcan dp > "$O/copies_qrcan_b4.txt" 2>&1 || true
       tail -70 "$O/copies_qrcan_b4.txt" ;;
     bench)      # bench TAG bench.py-args...  -> gpurun_out/bench/bench_TAG.json
       local tag=$1; shift
