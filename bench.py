@@ -27,6 +27,11 @@ Extra objects on the JSON line:
                 mean launch duration.  "kernel" names the family with the largest share of the step.
   cpu_baseline  rank 0, N=1 only: the CPU oracle (a restatement of the reference proven equal to it by the
                 golden vectors) doing the same step at batch 1 on the host cores -- a bounded sample.
+  config4_point N=1 default run only: BASELINE config 4's per-GPU operating point measured on this one GPU -- QRCAN, 4 tiles,
+                through a one-rank RCCL world (GradReducer buckets, all-reduce, join) with forward+backward replayed from a
+                hipGraph -- with its own whole-step fraction and per-family launch times.
+  han_bf16      N=1 default run only: BASELINE config 5 (HAN x4, bf16 matrix-core operands, 16 tiles), roofline bound "hbm"
+                against the bytes of the storage format in use (fp32 maps).
 """
 import argparse
 import json
@@ -44,7 +49,10 @@ CONV_BODY_FLOP_PER_PIXEL = 2 * 64 * 64 * 9
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix == fp32 vector peak
 HBM_PEAK_GBS = 8000.0          # same guide: HBM3E ~8 TB/s
 # algorithmic HBM bytes per LR patch, fwd + bwd, fp32 maps, layer at a time with the legal fusions
-HBM_GB_PER_PATCH = {"rcan": 16.5, "qrcan": 16.5, "edsr": 1.4, "qedsr": 1.4}
+HBM_GB_PER_PATCH = {"rcan": 16.5, "qrcan": 16.5, "edsr": 1.4, "qedsr": 1.4, "han": 17.0, "qhan": 17.0}
+# algorithmic HBM bytes of ONE 64 -> 64 launch per 128 x 128 sample (fp32 maps of 4 MiB): what each kernel family must move
+FAMILY_MAPS = {"conv fwd, plain": 2, "conv fwd, GATE": 4, "dgrad, ReLU mask": 3, "dgrad + residual, DOT": 4,
+               "dgrad, plain / residual": 3, "wgrad": 2}
 WORKLOADS = {
     # name: (registry name, handler kwargs, fwd+bwd algorithmic TFLOP per LR patch)
     "rcan": ("rcan", {}, 1.565),
@@ -300,6 +308,59 @@ def main():
             "algorithmic_tflops_per_gpu": s["value"] / world * s["tflop_per_patch"],
             "frac_of_fp32_mfma_peak": s["value"] / world * s["tflop_per_patch"] / FP32_MFMA_PEAK_TFLOPS})
 
+    c4 = han16 = None
+    if not explicit and not args.no_secondary and args.precision == "fp32" and world == 1:
+        # BASELINE config 4's per-GPU operating point (global batch 32 over 8 GPUs = 4 tiles each), on this one GPU: the
+        # reducer, its buckets and the all-reduce run through a one-rank RCCL world, forward + backward replay from a hipGraph
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+        s4 = measure(sisr, "qrcan", 4, max(2, min(args.steps, 10)), min(args.warmup, 3), True, rank, world, local, dev,
+                     families=not args.no_kernel_timing, dp=True)
+        tf4 = s4["value"] * s4["tflop_per_patch"]
+        c4 = {"workload": "QRCAN (RCAN + meta-attention) x4 full depth, 4 tiles of 128x128 per GPU (BASELINE config 4: global "
+                          "batch 32 on 8 GPUs), one-rank RCCL world, forward+backward replayed from a hipGraph",
+              "value": s4["value"], "unit": "patches/s", "ms_per_step": s4["ms_per_step"], "per_gpu_batch": 4,
+              "hip_graph": True, "parallelism": "dp1 (one-rank RCCL world: buckets, all_reduce, join)",
+              "grad_exchange": "SISR_GRAPH_OVERLAP=" + os.environ.get("SISR_GRAPH_OVERLAP", "auto") + " (auto: buckets all-reduced at "
+                               "the join in a one-rank world, behind signal nodes of the replay in a world of more ranks)",
+              "roofline": {"bound": "mfma", "achieved": tf4, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": tf4 / FP32_MFMA_PEAK_TFLOPS,
+                           "families": s4["timer"].summary(FP32_MFMA_PEAK_TFLOPS) if "timer" in s4 else []}}
+        # the same point with the exchange overlapped with the replayed backward (what a world of more ranks runs by default)
+        prev = os.environ.get("SISR_GRAPH_OVERLAP")
+        os.environ["SISR_GRAPH_OVERLAP"] = "1"
+        try:
+            s4o = measure(sisr, "qrcan", 4, max(2, min(args.steps, 5)), 2, True, rank, world, local, dev, dp=True)
+        finally:
+            if prev is None:
+                os.environ.pop("SISR_GRAPH_OVERLAP")
+            else:
+                os.environ["SISR_GRAPH_OVERLAP"] = prev
+        c4["overlapped_grad_exchange"] = {
+            "what": "SISR_GRAPH_OVERLAP=1: every bucket's all-reduce is released by a signal node of the replay and runs on the "
+                    "reducer stream beside the rest of the captured backward (in a one-rank world there is nothing to hide: this "
+                    "is the cost of the mechanism)", "value": s4o["value"], "unit": "patches/s", "ms_per_step": s4o["ms_per_step"]}
+        # BASELINE config 5: HAN x4, bf16 matrix-core operands (opt-in mode), 16 tiles
+        sisr.ops.set_precision("bf16")
+        try:
+            sh = measure(sisr, "han", 16, max(2, min(args.steps, 5)), min(args.warmup, 2), False, rank, world, local, dev)
+        finally:
+            sisr.ops.set_precision("fp32")
+        gbs = sh["value"] * HBM_GB_PER_PATCH["han"]
+        han16 = {"workload": "HAN x4 full depth, 16 tiles of 128x128, train step (BASELINE config 5)",
+                 "dtype": "bf16 MFMA operands (rounded while staged into LDS), f32 accumulate, f32 feature maps / gradients / "
+                          "optimiser state in HBM", "value": sh["value"], "unit": "patches/s", "ms_per_step": sh["ms_per_step"],
+                 "final_loss": sh["loss"],
+                 "roofline": {"bound": "hbm", "what": "whole step: algorithmic bytes per patch of the storage format in use "
+                              "(fp32 maps, 17.0 GB per patch fwd+bwd) x patches/s", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                              "secondary": {"bound": "mfma", "achieved": sh["value"] * sh["tflop_per_patch"], "peak": 2500.0,
+                                            "unit": "TFLOP/s", "frac": sh["value"] * sh["tflop_per_patch"] / 2500.0}},
+                 "parity": "unpinned against the reference (it has no reduced-precision mode); pinned against the oracle's "
+                           "bf16 restatement and, statistically, against fp32 (tests/test_bf16_gpu.py)"}
+
     x3 = None
     if not explicit and not args.no_secondary and args.precision == "fp32" and world == 1:
         # second line asked for by the round-1 review: the same step with the convs as bf16x3 splits
@@ -335,16 +396,18 @@ def main():
         step_tf = value / world * tflop_per_patch
         if args.precision == "fp32":
             fams = main_res["timer"].summary(FP32_MFMA_PEAK_TFLOPS) if "timer" in main_res else []
-            traffic, tsrc = None, None
+            traffic, tsrc, tfam = None, None, None
             tj = os.path.join(ROOT, "profiles", "traffic_conv3x3_c64.json")
             if os.path.exists(tj) and main_res["width"] == 64:
                 with open(tj) as f:
                     tdoc = json.load(f)
                 traffic, tsrc = tdoc.get(str(B)), tdoc.get("source")
+                if B == 32:  # measured HBM bytes per launch of every family beside what it must move (PMC passes)
+                    tfam = tdoc.get("families_b32")
             line["roofline"] = {
                 "bound": "mfma", "what": "whole training step: algorithmic TFLOP/s per GPU (patches/s x TFLOP per patch)",
                 "achieved": step_tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_tf / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": traffic, "traffic_source": tsrc,
+                "traffic": traffic, "traffic_source": tsrc, "traffic_families": tfam,
                 "kernel": fams[0]["family"] if fams else None, "families": fams,
             }
             if workload in HBM_GB_PER_PATCH:
@@ -368,6 +431,10 @@ def main():
                                               "frac": step_tf / 2500.0}}
         if secondary is not None:
             line[secondary[0]] = secondary[1]
+        if c4 is not None:
+            line["config4_point"] = c4
+        if han16 is not None:
+            line["han_bf16"] = han16
         if x3 is not None:
             line["bf16x3"] = x3
         if world == 1 and not args.no_cpu_baseline and args.precision == "fp32":

@@ -308,6 +308,19 @@ int sisr_l1_loss(const float* a, const float* b, long n, float* loss, float* gra
 int sisr_adam_flat(float* p, const float* g, float* m, float* v, long n, float beta2, float one_minus_beta1,
                    float one_minus_beta2, float eps, float step_size, float bc2_sqrt, float grad_scale, void* stream);
 
+/* ---- progress words for hipGraph replays (data-parallel reducer; ref: SISR/models/__init__.py:344-347 DataParallel) ----
+ * sisr_host_flags_alloc: n zeroed 32-bit words of pinned, host-coherent, device-visible memory (nullptr on failure; the
+ * one allocation the library makes on the caller's behalf, returned to sisr_host_flags_free).  sisr_signal_host enqueues
+ * a one-thread kernel that adds 1 to *flag once every earlier kernel of the stream has completed; under stream capture it
+ * becomes a graph node, so a replay reports how far it has got without host round trips inside the graph. */
+void* sisr_host_flags_alloc(int n);
+void sisr_host_flags_free(void* flags);
+int sisr_signal_host(void* flag, void* stream);
+/* device-side wait: work enqueued on `stream` after this call starts once *flag >= value (hipStreamWaitValue32) */
+int sisr_stream_wait_flag(void* flag, unsigned value, void* stream);
+/* the same as a one-lane polling kernel on `stream` (bounded: after about a minute it stores 1 to *timed_out, nullable) */
+int sisr_stream_spin_flag(void* flag, unsigned value, void* timed_out, void* stream);
+
 /* ---- training tiles cut on the device (the step in front of the path) ---------------
  * ref: sr_tools/image_manipulation.py:233-257 random_flip_rotate + random_matched_crop, in the order
  * data_handler.py:500-513 applies them.  src: B device pointers to planar [C][H_b][W_b] fp32 images; params: B records

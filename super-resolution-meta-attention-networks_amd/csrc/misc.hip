@@ -7,6 +7,7 @@
 //          p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
 // Both are single-pass HBM-bound streams; the loss reduction is two-stage and ordered.
 #include "sisr_common.h"
+#include <string.h>
 
 #define L1_BLOCKS 512
 
@@ -104,6 +105,68 @@ extern "C" int sisr_adam_flat(float* p, const float* g, float* m, float* v, long
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta2,
                      one_minus_beta1, one_minus_beta2, eps, step_size, bc2_sqrt, grad_scale);
+  return sisr_check_launch();
+}
+
+// ---------------------------------------------------------------- progress words a captured step publishes to the host
+// A training step replayed from a hipGraph fires no autograd hooks, so a data-parallel reducer cannot learn from the host
+// side when a gradient bucket is complete.  sisr_signal_host is a one-thread kernel placed in the captured stream right
+// after a bucket's last gradient kernel: it adds 1 to a word in host-coherent pinned memory (system-scope release), which
+// the host polls before it issues that bucket's all-reduce on its own stream while the rest of the replay keeps running
+// (parallel.GradReducer; ref: the reference's DataParallel gathers gradients only after the whole backward,
+// SISR/models/__init__.py:344-347, 481-489).  Kernels ahead of the signal in the capture have completed, and their writes
+// are device-visible, when the word changes.
+__global__ void signal_host_kernel(unsigned* flag) {
+  __threadfence_system();
+  __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One lane that sleeps and re-reads the progress word until it has reached `value` (wrap-around safe), bounded: after
+// ~2^26 polls (about a minute) it gives up and raises *timed_out, so the grid always drains.  Launched on the reducer's
+// stream in front of a bucket's all-reduce: the stream then waits for the replay's signal node without the host (which
+// would block) and without a command-processor wait packet (hipStreamWaitValue32 slowed the replay's own launches).
+__global__ void wait_flag_kernel(const unsigned* flag, unsigned value, unsigned* timed_out) {
+  for (unsigned i = 0; i < (1u << 26); ++i) {
+    const unsigned v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int)(v - value) >= 0) return;
+    __builtin_amdgcn_s_sleep(127);
+  }
+  if (timed_out) __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" void* sisr_host_flags_alloc(int n) {
+  if (n <= 0) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, (size_t)n * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
+  memset(p, 0, (size_t)n * sizeof(unsigned));
+  return p;
+}
+
+extern "C" void sisr_host_flags_free(void* flags) {
+  if (flags) (void)hipHostFree(flags);
+}
+
+// Device-side wait: `stream` proceeds once *flag - value >= 0 (32-bit, wrap-around safe while the two stay within 2^31).
+// With it the host enqueues a bucket's all-reduce right after graph.replay() without blocking: the reducer stream itself
+// waits for the replay's signal node.
+extern "C" int sisr_stream_wait_flag(void* flag, unsigned value, void* stream) {
+  if (!flag) return SISR_ERR_ARG;
+  const hipError_t e = hipStreamWaitValue32((hipStream_t)stream, flag, value, hipStreamWaitValueGte, 0xffffffffu);
+  return e == hipSuccess ? SISR_OK : SISR_ERR_LAUNCH - (int)e * 16;
+}
+
+// the same wait as a one-lane polling kernel (bounded; *timed_out, a word of the same allocation or nullptr, is set to 1 if
+// the value never arrives)
+extern "C" int sisr_stream_spin_flag(void* flag, unsigned value, void* timed_out, void* stream) {
+  if (!flag) return SISR_ERR_ARG;
+  hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, static_cast<const unsigned*>(flag), value,
+                     static_cast<unsigned*>(timed_out));
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_signal_host(void* flag, void* stream) {
+  if (!flag) return SISR_ERR_ARG;
+  hipLaunchKernelGGL(signal_host_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, static_cast<unsigned*>(flag));
   return sisr_check_launch();
 }
 

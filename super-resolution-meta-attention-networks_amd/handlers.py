@@ -67,7 +67,9 @@ class BaseModel(nn.Module):
         betas = (optimizer_params['beta_1'], optimizer_params['beta_2']) if optimizer_params is not None else (0.9, 0.999)
         if params and all(p.is_cuda for p in params) and os.environ.get("SISR_FLAT_ADAM", "1") != "0":
             from .optim import FlatAdam  # one-launch Adam over a flat arena, torch.optim.Adam's schema (optim.py)
-            self.optimizer = FlatAdam(params, lr=lr, betas=betas)
+            # the meta-attention layers' gradients come out of ONE launch at the very end of backward (architectures.meta_gates)
+            late = [p for m in self.net.modules() if type(m).__name__ == 'ParaCALayer' for p in m.parameters()]
+            self.optimizer = FlatAdam(params, lr=lr, betas=betas, late=late)
         else:  # CPU handlers exist for construction / checkpoint plumbing only and are never stepped
             self.optimizer = optim.Adam(params, lr=lr, betas=betas)
 
@@ -105,12 +107,14 @@ class BaseModel(nn.Module):
             raise NotImplementedError('perceptual (VGG) loss is outside the HIP hot path; every sample config '
                                       'of the reference uses perceptual=None')
 
-    def set_multi_gpu(self, device_ids=None):
-        """One process per GPU: gradients are averaged over the torch.distributed (RCCL) world."""
+    def set_multi_gpu(self, device_ids=None, bucket_mb=None):
+        """One process per GPU: gradients are averaged over the torch.distributed (RCCL) world.  bucket_mb: size of the
+        all-reduce buckets (default 8, or SISR_DP_BUCKET_MB)."""
         from .parallel import GradReducer
-        self.reducer = GradReducer(self.net, arena=getattr(self.optimizer, 'grad_views', None),
+        self.reducer = GradReducer(self.net, bucket_mb=bucket_mb, arena=getattr(self.optimizer, 'grad_views', None),
                                    arena_flat=getattr(self.optimizer, 'flat_g', None),
-                                   arena_offsets=getattr(self.optimizer, 'offsets', None))
+                                   arena_offsets=getattr(self.optimizer, 'offsets', None),
+                                   arena_order=getattr(self.optimizer, 'arena_order', None))
 
     # -- checkpoints (ref :349-464)
     def save_model(self, model_save_name, model_idx, extract_state_only=False):
@@ -190,12 +194,16 @@ class BaseModel(nn.Module):
         A replay writes gradients into the tensors that were the parameters' .grad at capture time, so every
         entry keeps those tensors and re-binds p.grad to them after each replay: the data-parallel join (which
         hands out bucket views as .grad) and a capture for another batch shape both re-point p.grad in between.
-        With a GradReducer the captured weight-gradient kernels write straight into its buckets (ops.GRAD_SINK),
-        its hooks stay off while capturing / replaying and all buckets are all-reduced at the join."""
+        With a GradReducer the captured weight-gradient kernels write straight into its buckets (ops.GRAD_SINK).  A
+        replay fires no hooks; instead the capture places a signal node behind every bucket's last gradient kernel and the
+        host issues each all-reduce as soon as the replay reports the bucket complete (GradReducer.launch_signalled), so the
+        exchange overlaps the rest of the replayed backward as it does in eager mode.  SISR_GRAPH_OVERLAP=0 (or a CPU
+        reducer): all buckets are all-reduced at the join."""
         extra = kwargs.get('extra_channels')
         key = (tuple(x.shape), tuple(y.shape), None if extra is None else tuple(extra.shape))
         entry = self._graphs.get(key)
         red = self.reducer
+        signal = red is not None and red.can_signal()
         if red is not None:
             red.hooks_enabled = False
         try:
@@ -218,18 +226,27 @@ class BaseModel(nn.Module):
                 dump = os.environ.get("SISR_GRAPH_DUMP")  # diagnostic: write the captured graph as a DOT file
                 if dump:
                     graph.enable_debug_mode()
+                order = []
                 with torch.cuda.graph(graph):
                     ops.pack_all(self.net, A.conv_weights)  # first node of the graph: the replay repacks
                     out = self.run_model(sx, **kw)
                     loss = self.criterion(out, sy)
-                    with ops.deferred_wgrads():  # reducer hooks are off here: nothing reads a gradient before the join
-                        loss.backward()
+                    if signal:
+                        red.begin_capture()
+                    try:
+                        # with signal nodes a gradient must be launched before its parameter's hook runs: nothing is deferred
+                        # past the autograd node that produces it (the group nodes flush their own batches before they return)
+                        with ops.deferred_wgrads(enabled=not signal):
+                            loss.backward()
+                    finally:
+                        if signal:
+                            order = red.end_capture()
                 if dump:
                     graph.debug_dump(dump)
                 grads = [(p, p.grad) for p in self.net.parameters()]
-                entry = (graph, sx, sy, se, loss, out, grads)
+                entry = (graph, sx, sy, se, loss, out, grads, order)
                 self._graphs[key] = entry
-            graph, sx, sy, se, loss, out, grads = entry
+            graph, sx, sy, se, loss, out, grads, order = entry
             sx.copy_(x)
             sy.copy_(y)
             if se is not None:
@@ -237,6 +254,8 @@ class BaseModel(nn.Module):
             graph.replay()
             for p, g in grads:  # this replay's gradients live in this entry's capture-time tensors
                 p.grad = g
+            if signal and order:
+                red.launch_signalled(order)
         finally:
             ops.invalidate_packs()
             if red is not None:

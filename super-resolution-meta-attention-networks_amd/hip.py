@@ -55,6 +55,11 @@ _SIGS = {
     "sisr_l1_loss": (c_int, [P, P, c_long, P, P, P, P]),
     "sisr_crop_augment": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "sisr_adam_flat": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P]),
+    "sisr_host_flags_alloc": (P, [c_int]),
+    "sisr_host_flags_free": (None, [P]),
+    "sisr_signal_host": (c_int, [P, P]),
+    "sisr_stream_wait_flag": (c_int, [P, ctypes.c_uint, P]),
+    "sisr_stream_spin_flag": (c_int, [P, ctypes.c_uint, P, P]),
 }
 OPTIONAL_SIGS = {  # only in libsisr_hip_diag.so (csrc/build.sh diag; select it with SISR_HIP_LIB)
     "sisr_diag_mfma_peak": (c_int, [c_int, c_int, P, P, P]),

@@ -25,7 +25,12 @@ ALIGN = 4  # floats: every parameter starts on a 16-byte boundary
 
 
 class FlatAdam(optim.Adam):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, late=()):
+        """late: parameters whose gradients only arrive at the very end of a backward pass (the meta-attention layers, whose
+        gates are all computed -- and differentiated -- by one launch before the first block).  They are laid out BEHIND
+        the others in the arenas, so that a data-parallel reducer's buckets (contiguous runs of the gradient arena) of conv
+        weights complete, and can be all-reduced, while backward is still running.  The arena order is internal:
+        param_groups, state and state_dict() keep the registration order."""
         params = list(params)
         super().__init__(params, lr=lr, betas=betas, eps=eps)
         if len(self.param_groups) != 1:
@@ -35,7 +40,9 @@ class FlatAdam(optim.Adam):
             raise RuntimeError("FlatAdam needs fp32 parameters on a HIP device")
         dev = ps[0].device
         self.offsets, off = {}, 0
-        for p in ps:
+        late_ids = {id(p) for p in late}
+        self.arena_order = [p for p in ps if id(p) not in late_ids] + [p for p in ps if id(p) in late_ids]
+        for p in self.arena_order:
             self.offsets[p] = off
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
@@ -75,7 +82,7 @@ class FlatAdam(optim.Adam):
         if self._plan is not None and self._plan[0] == key:
             return self._plan[1]
         segs = []
-        for p in self.param_groups[0]['params']:
+        for p in self.arena_order:
             if id(p) in skip:
                 continue
             o, n = self.offsets[p], (p.numel() + ALIGN - 1) // ALIGN * ALIGN

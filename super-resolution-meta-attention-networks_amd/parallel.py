@@ -71,8 +71,8 @@ def shard_batch(batch, rank, world):
 
 
 class GradReducer:
-    def __init__(self, net, bucket_mb=8.0, process_group=None, overlap=True, arena=None, arena_flat=None,
-                 arena_offsets=None):
+    def __init__(self, net, bucket_mb=None, process_group=None, overlap=True, arena=None, arena_flat=None,
+                 arena_offsets=None, arena_order=None):
         """arena / arena_flat / arena_offsets: optim.FlatAdam's gradient views, flat gradient buffer and parameter
         offsets.  With them a bucket IS a slice of that buffer (buckets are runs of consecutive parameters), so the
         gradients are all-reduced where the optimiser reads them and nothing is copied back."""
@@ -80,13 +80,22 @@ class GradReducer:
             raise RuntimeError("gpu='multi' runs one process per GPU: launch with "
                                "`python -m torch.distributed.run --nproc-per-node N ...` "
                                "(see parallel.init_distributed)")
+        if bucket_mb is None:  # ~8 MB ~ one residual group of a 64-wide net; SISR_DP_BUCKET_MB overrides (tests, tuning)
+            bucket_mb = float(os.environ.get("SISR_DP_BUCKET_MB", 8.0))
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.cuda = self.params[0].is_cuda
         cap = int(bucket_mb * (1 << 20) / 4)
         self.buckets, cur, size = [], [], 0
-        for p in reversed(self.params):
+        # buckets walk the optimiser's arena backwards (= reverse registration order, except that parameters whose gradients
+        # arrive last -- optim.FlatAdam's `late` -- sit at its end and so share the first bucket(s) instead of holding
+        # every bucket open until the end of backward)
+        walk = self.params
+        if arena_order is not None and arena is not None and all(p in arena for p in self.params):
+            keep = {id(p) for p in self.params}
+            walk = [p for p in arena_order if id(p) in keep]
+        for p in reversed(walk):
             cur.append(p)
             size += p.numel()
             if size >= cap:
@@ -128,6 +137,17 @@ class GradReducer:
         # hooks_enabled is switched off by BaseModel._graphed_step while it captures / replays a hipGraph: a captured
         # backward must not launch collectives, and a replay fires no hooks, so every bucket is reduced at the join
         self.hooks_enabled = True
+        # hipGraph replays: a replay fires no hooks, so while a step is CAPTURED the hooks put a one-thread signal kernel
+        # behind each bucket's last gradient kernel instead (progress words in host-coherent memory, csrc/misc.hip);
+        # after graph.replay() the host polls the words and issues every bucket's all-reduce as soon as its word moves,
+        # on the reducer stream, while the rest of the replay is still running (launch_signalled).
+        self.capturing = False
+        self.signal_order = []
+        self.flags = None
+        self.flag_seen = [0] * len(self.buckets)
+        if self.cuda:
+            from . import hip
+            self.flags = hip.lib().sisr_host_flags_alloc(len(self.buckets) + 1)  # + one "a wait timed out" word
         self.handles = []
         if overlap:
             for p in self.params:
@@ -144,9 +164,86 @@ class GradReducer:
         bi = self.bucket_of[p]
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
+            if self.capturing:  # becomes a node of the graph being captured, right behind this bucket's last gradient
+                # on the CAPTURE stream, by handle: a hook runs in the autograd engine's worker thread, whose current stream
+                # is not the capturing one (a launch on it would become a parallel branch of the graph, joined at the end).
+                # The engine runs one node at a time, so every kernel of the nodes before this hook has been issued already.
+                from . import hip
+                hip.check(hip.lib().sisr_signal_host(self.flags + 4 * bi, self.capture_stream), "sisr_signal_host")
+                self.signal_order.append(bi)
+                self.pending[bi] = len(self.buckets[bi])
+            else:
+                self._launch(bi)
+
+    # -- hipGraph replays (BaseModel._graphed_step)
+    @staticmethod
+    def graph_overlap_mode():
+        """SISR_GRAPH_OVERLAP: auto (default: 'spin' in a world of more than one rank, '0' in a one-rank world, where there is
+        nothing to hide and the extra nodes cost ~2 %) | 0 (all buckets at the join) | 1 = spin | poll | wait."""
+        mode = os.environ.get("SISR_GRAPH_OVERLAP", "auto")
+        return "spin" if mode == "1" else mode
+
+    def can_signal(self):
+        mode = self.graph_overlap_mode()
+        if mode == "auto":
+            mode = "spin" if self.world > 1 else "0"
+        return self.flags is not None and self.overlap and mode != "0"
+
+    def begin_capture(self):
+        """Call on the capturing stream, right before the backward pass that is being captured."""
+        self.capture_stream = torch.cuda.current_stream().cuda_stream
+        self.capturing, self.signal_order, self.hooks_enabled = True, [], True
+        self.pending = [len(b) for b in self.buckets]
+
+    def end_capture(self):
+        """-> the buckets that got a signal node, in the order the captured backward completes them."""
+        order, self.capturing, self.signal_order, self.hooks_enabled = self.signal_order, False, [], False
+        self.pending = [len(b) for b in self.buckets]
+        return order
+
+    def launch_signalled(self, order, timeout_s=60.0):
+        """Called right after graph.replay(): every bucket of `order` is all-reduced as soon as the replay reports it complete.
+
+        spin (the default where overlap is on): a one-lane polling kernel on the reducer stream holds each bucket's all-reduce
+        back until the replay's signal node has fired; the host enqueues everything at once and keeps running ahead of the
+        device, as in eager mode.  Measured on one MI355X (QRCAN, 4 tiles, one-rank RCCL world, ms per step): join 59.1,
+        spin 60.4, wait (hipStreamWaitValue32 on the reducer stream: the pending command-processor wait slows the replay's own
+        launches) 67.1, poll (host polls the words and blocks meanwhile; the last SISR_GRAPH_OVERLAP_TAIL = 2 buckets are
+        left to the stream-ordered join so that the host's remaining work still fits under the device's) 64.2."""
+        from . import hip
+        mode = self.graph_overlap_mode()
+        if mode == "auto":
+            mode = "spin"
+        tail = max(0, int(os.environ.get("SISR_GRAPH_OVERLAP_TAIL", 2))) if mode == "poll" else 0
+        polled = order[:max(0, len(order) - tail)]
+        for bi in order:
+            self.flag_seen[bi] = (self.flag_seen[bi] + 1) & 0x7fffffff
+            if self.flag_seen[bi] == 0:
+                raise RuntimeError("GradReducer: progress word wrapped after 2^31 replays; re-create the reducer")
+        for bi in polled:
+            if mode == "wait":
+                hip.check(hip.lib().sisr_stream_wait_flag(self.flags + 4 * bi, self.flag_seen[bi], self.stream.cuda_stream),
+                          "sisr_stream_wait_flag")
+            elif mode != "poll":  # spin
+                hip.check(hip.lib().sisr_stream_spin_flag(self.flags + 4 * bi, self.flag_seen[bi],
+                                                          self.flags + 4 * len(self.buckets), self.stream.cuda_stream),
+                          "sisr_stream_spin_flag")
+            else:
+                import ctypes
+                import time
+                word, t0, spins = ctypes.c_uint32.from_address(self.flags + 4 * bi), None, 0
+                while word.value < self.flag_seen[bi]:
+                    spins += 1
+                    if spins % 2000 == 0:
+                        if t0 is None:
+                            t0 = time.perf_counter()
+                        elif time.perf_counter() - t0 > timeout_s:
+                            raise RuntimeError(f"GradReducer: the replayed step never signalled gradient bucket {bi}")
+            self._launch(bi, gradients_complete=True)
+        for bi in order[len(polled):]:
             self._launch(bi)
 
-    def _launch(self, bi):
+    def _launch(self, bi, gradients_complete=False):
         bucket, flat = self.buckets[bi], self.flat[bi]
         # Gradients the kernels of THIS step wrote straight into the bucket (ops.GRAD_SINK) need no copy.  The test is
         # "p.grad aliases the bucket", which is only sound because p.grad always names this step's gradient when we
@@ -156,11 +253,12 @@ class GradReducer:
         dst = [self.views[p] for p in todo]
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in todo]
         if self.cuda:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            from . import ops
-            wside = ops.side_stream(flat.device, create=False)  # weight gradients are produced on this stream
-            if wside is not None:
-                self.stream.wait_stream(wside)
+            if not gradients_complete:  # (a signalled bucket: its kernels have finished; waiting for the stream = the whole replay)
+                self.stream.wait_stream(torch.cuda.current_stream())
+                from . import ops
+                wside = ops.side_stream(flat.device, create=False)  # weight gradients are produced on this stream
+                if wside is not None:
+                    self.stream.wait_stream(wside)
             with torch.cuda.stream(self.stream):
                 if todo:
                     torch._foreach_copy_(dst, grads)
@@ -176,6 +274,11 @@ class GradReducer:
         for bi in range(len(self.buckets)):
             if not self.launched[bi]:
                 self._launch(bi)
+        if self.flags is not None:
+            import ctypes
+            if ctypes.c_uint32.from_address(self.flags + 4 * len(self.buckets)).value:
+                raise RuntimeError("GradReducer: a replayed step never signalled one of its gradient buckets (the reducer "
+                                   "stream's wait gave up after about a minute)")
         inv = 1.0 / self.world
         for bi, bucket in enumerate(self.buckets):
             self.works[bi].wait()
@@ -194,6 +297,11 @@ class GradReducer:
         for h in self.handles:
             h.remove()
         self.handles = []
+        if self.flags is not None:
+            from . import hip
+            torch.cuda.synchronize()
+            hip.lib().sisr_host_flags_free(self.flags)
+            self.flags = None
         if self.cuda:
             from . import ops
             for p in self.views:

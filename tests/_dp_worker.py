@@ -7,7 +7,8 @@
 Every rank sits on cuda:0 (transport SISR_DIST_BACKEND, gloo on a 1-GPU box).  A seeded GLOBAL batch per step is cut
 into contiguous rank slices (parallel.shard_batch); `BaseModel.train_step` runs with lr = 0, so parameters stay
 put and step k's gradient depends on step k's batch only -- a stale gradient (replayed graph writing elsewhere, bucket
-not refreshed) shows up at k >= 1.  Rank 0 stores {step: {name: grad}} + losses.  MODE: eager | graph | eager_noside
+not refreshed) shows up at k >= 1.  Rank 0 stores {step: {name: grad}} + losses (+ the reducer's bucket count and, for graph
+mode, how many buckets each captured graph signals; SISR_DP_BUCKET_MB in the environment sets the bucket size).  MODE: eager | graph | eager_noside
 (eager with SISR_WGRAD_SIDE_STREAM=0); ALT = 1 alternates two batch shapes from step to step.
 """
 import os
@@ -65,6 +66,9 @@ for step in range(steps):
     record["loss"].append(float(loss))
     record["grads"].append({n: p.grad.detach().cpu().clone() for n, p in h.net.named_parameters() if p.grad is not None})
 torch.cuda.synchronize()
+if h.reducer is not None:
+    record["buckets"] = len(h.reducer.buckets)
+    record["signalled"] = [len(e[7]) for e in h._graphs.values()]  # buckets with a signal node, per captured graph
 if rank == 0:
     torch.save(record, out_path)
 if world > 1:

@@ -693,7 +693,7 @@ def test_native_library_is_loaded():
         assert "libsisr_hip.so" in f.read()
 
 
-def _run_dp_worker(tmp_path, model, mode, steps, ranks, alt=0, port=29731):
+def _run_dp_worker(tmp_path, model, mode, steps, ranks, alt=0, port=29731, bucket_mb=None):
     import os
     import subprocess
     import sys
@@ -703,6 +703,9 @@ def _run_dp_worker(tmp_path, model, mode, steps, ranks, alt=0, port=29731):
     env = dict(os.environ, SISR_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
+    if bucket_mb is not None:
+        env["SISR_DP_BUCKET_MB"] = str(bucket_mb)
+    env.setdefault("SISR_GRAPH_OVERLAP", "auto")
     args = [worker, out, model, mode, str(steps), str(alt)]
     if ranks == 1:
         cmd = [sys.executable] + args
@@ -739,6 +742,20 @@ def test_two_ranks_on_one_gpu_equal_one_process_gradients(tmp_path, model, mode,
     one = _run_dp_worker(tmp_path, model, "eager", 4, 1, alt)
     two = _run_dp_worker(tmp_path, model, mode, 4, 2, alt, port)
     _assert_same_grads(one, two, 2e-6, (model, mode, alt))
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_two_ranks_many_buckets_equal_one_process_gradients(tmp_path, mode):
+    """The same equivalence with 0.25 MB buckets (>= 4 of them on the reduced QRCAN): in eager mode the hooks fire mid-backward
+    and bucket k is all-reduced on the reducer stream while the side-stream weight-gradient kernels are still writing
+    bucket k + 1 of the same arena; in graph mode the replay's signal nodes release the buckets one by one
+    (GradReducer.launch_signalled) while the rest of the captured backward runs.  Same 2e-6 bound, four different batches."""
+    one = _run_dp_worker(tmp_path, "qrcan", "eager", 4, 1, 0)
+    two = _run_dp_worker(tmp_path, "qrcan", mode, 4, 2, 0, 29777 + (mode == "graph"), bucket_mb=0.25)
+    assert two["buckets"] >= 4, two["buckets"]
+    if mode == "graph":
+        assert two["signalled"] and min(two["signalled"]) >= 4, two["signalled"]  # the overlapped path, not the join
+    _assert_same_grads(one, two, 2e-6, ("qrcan", mode, "many buckets"))
 
 
 def test_hip_graph_two_batch_shapes_alternating(tmp_path):
