@@ -32,6 +32,12 @@
 #define SISR_Y_STORE1 sisr_buf_store1
 #define SISR_Y_STORE4 sisr_buf_store4
 #endif
+#ifndef SISR_GATE_WGS
+#define SISR_GATE_WGS 4   // resident workgroups per CU of the 2-row GATE build (3: single-batch staging, see the kernel)
+#endif
+#ifndef SISR_GATE_PRIO
+#define SISR_GATE_PRIO 0  // 1: the GATE prologue (two maps, arithmetic, a store) runs at wave priority 3
+#endif
 #define TH 4
 #define TW 32
 #define HALO_H (TH + 2)
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
 // its own sample; all write the same s / hid / ca / g); 2 = with AFFINE + MASK, the GAP-backward shift is computed here from
 // the previous conv's DOT partial sums (ca_gate_bwd_sample).  Same device functions as the stand-alone gate kernels.
 template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false, bool LEAKY = false, int KSEL = 0, int HEAD = 0>
-__global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x3_c64_v4_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_WGS : 4) : 3)) void conv3x3_c64_v4_kernel(ConvParams p) {
   constexpr int THv = 2 * MT, HHv = THv + 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // (Wave priorities were measured and left out: with staging and epilogue at s_setprio 3 the staging phase shrinks from
@@ -473,7 +479,10 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
         const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.in_scale + (long)b * 64 + c4 * 4);
         const sisr_rsrc_t ru = sisr_rsrc(p.gate_add + (long)b * p.xv.sB);
         const sisr_rsrc_t ro_ = sisr_rsrc(p.gate_out + (long)b * p.xv.sB);
-        constexpr int RB = HHv / 2;
+        // 2-row tiles with three resident workgroups (168 registers): both operand maps of all four halo rows are requested
+        // at once, one memory round trip per tile instead of two
+        constexpr int RB = (MT == 1 && SISR_GATE_WGS == 3) ? HHv : HHv / 2;
+        if (SISR_GATE_PRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int r0 = 0; r0 < HHv; r0 += RB) {
           f32x4 v[RB][3], u[RB][3];
@@ -504,6 +513,7 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? 4 : 3)) void conv3x
               }
           }
         }
+        if (SISR_GATE_PRIO) __builtin_amdgcn_s_setprio(0);
       }
     }
     __syncthreads();

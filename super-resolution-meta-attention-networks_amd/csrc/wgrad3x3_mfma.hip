@@ -95,6 +95,12 @@ static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
       f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
       if (p.dy_scale) s4 = *reinterpret_cast<const f32x4*>(p.dy_scale + (long)b * Cout + cq * 64 + coh * 32 + c4 * 4);
       if (p.dy_shift) t4 = *reinterpret_cast<const f32x4*>(p.dy_shift + (long)b * Cout + cq * 64 + coh * 32 + c4 * 4);
+      // what a tile does not need is skipped by scalar branches, not computed with neutral constants (every vector
+      // instruction here costs the co-resident workgroup's MFMA stream ~4.5 cycles): the zero-padding mask on tiles whose
+      // halo lies inside the image, the affine rebuild when dY is taken as it is, the column sums where no bias gradient
+      // is wanted from this quadrant
+      const bool interior = h0 >= 1 && h0 + WT_H + 1 <= H && w0 >= 1 && w0 + WT_W + 1 <= W;  // scalar
+      const bool affine = p.dy_scale != nullptr || p.dy_shift != nullptr;                     // scalar
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         f32x4 v[5], u[4], e;
@@ -108,20 +114,30 @@ static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
         if (half == 0)
           e = *reinterpret_cast<const f32x4*>(xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH +
                                               min(max(gwe, 0), W - 1) * (int)p.xv.sW + ec4 * 4);
+        if (affine) {
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-          const int gh = h0 - 1 + 5 * half + r;
-          *reinterpret_cast<f32x4*>(ldx + (5 * half + r) * (WH_W * WSTR) + lx) = sisr_keep_if(v[r], gh >= 0 && gh < H && okc);
+          for (int r = 0; r < 4; ++r) u[r] = u[r] * s4 + t4;
+        }
+        if (!interior) {
+#pragma unroll
+          for (int r = 0; r < 5; ++r) {
+            const int gh = h0 - 1 + 5 * half + r;
+            v[r] = sisr_keep_if(v[r], gh >= 0 && gh < H && okc);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u[r] = sisr_keep_if(u[r], okc && (h0 + 4 * half + r < H));
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const f32x4 t = sisr_keep_if(u[r] * s4 + t4, okc && (h0 + 4 * half + r < H));
-          *reinterpret_cast<f32x4*>(ldy + (4 * half + r) * (WT_W * WSTR) + ly) = t;
-          bsum += t;
+        for (int r = 0; r < 5; ++r) *reinterpret_cast<f32x4*>(ldx + (5 * half + r) * (WH_W * WSTR) + lx) = v[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(ldy + (4 * half + r) * (WT_W * WSTR) + ly) = u[r];
+        if (do_bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bsum += u[r];
         }
         if (half == 0) {
           const int ghe = h0 - 1 + er;
-          e = sisr_keep_if(e, ghe >= 0 && ghe < H && gwe >= 0 && gwe < W);
+          if (!interior) e = sisr_keep_if(e, ghe >= 0 && ghe < H && gwe >= 0 && gwe < W);
           if (tl < 160) *reinterpret_cast<f32x4*>(ldx + er * (WH_W * WSTR) + (eside ? WH_W - 1 : 0) * WSTR + ec4 * 4) = e;
         }
       }

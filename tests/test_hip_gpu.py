@@ -16,6 +16,19 @@ from conftest import golden_json, load_golden
 from oracle import sisr_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["fp32", "bf16x3"])
+def arith(request):
+    """Arithmetic of the 64-channel convs for the golden-fixture tests: the exact-fp32 MFMA kernels (the headline) and fp32
+    through the bf16 matrix cores (operands split exactly into three bf16 numbers, six products, fp32 accumulate: DESIGN.md
+    section 7b).  Both must meet the SAME reference fixtures with the SAME tolerances."""
+    sisr_amd.ops.set_precision(request.param)
+    yield request.param
+    sisr_amd.ops.set_precision("fp32")
+
+
+ARITH = pytest.mark.usefixtures("arith")
 A = sisr_amd.architectures
 ops = sisr_amd.ops
 DEV = "cuda:0"
@@ -308,6 +321,7 @@ def run_block(name, module, n_inputs, call=None, rtol=2e-4, atol=3e-5):
         close(g, a["pg/" + k], 1e-3, 1e-4, f"{name} pg/{k}")
 
 
+@ARITH
 def test_g1_conv64():
     for name in ("g1_conv64", "g1_conv64_odd"):
         m = A.default_conv(64, 64, 3)
@@ -323,11 +337,13 @@ def test_g1_calayer():
     run_block("g1_calayer", A.CALayer(64, 16), 1)
 
 
+@ARITH
 @pytest.mark.parametrize("name", ["g1_rcab", "g1_rcab_odd"])
 def test_g1_rcab(name):
     run_block(name, A.RCAB(A.default_conv, 64, 3, 16), 1)
 
 
+@ARITH
 def test_g1_resblock():
     run_block("g1_resblock", A.ResBlock(A.default_conv, 64, 3, res_scale=0.1), 1)
 
@@ -343,6 +359,7 @@ def test_g1_qca(style):
     run_block(f"g1_qca_{style}", A.QCALayer(64, style, reduction=16, num_metadata=10), 2)
 
 
+@ARITH
 @pytest.mark.parametrize("q", [0, 1])
 @pytest.mark.parametrize("pa", [0, 1])
 def test_g1_qrcab(q, pa):
@@ -354,6 +371,7 @@ def test_g1_palayer():
     run_block("g1_palayer", A.PALayer(64), 1)
 
 
+@ARITH
 @pytest.mark.parametrize("nl", [0, 1])
 def test_g1_paramresblock(nl):
     m = A.ParamResBlock(A.default_conv, 64, 10, 3, res_scale=0.1, q_layer_nonlinearity=bool(nl))
@@ -404,12 +422,14 @@ def net_vs_oracle(net, name, cfg, x, md=None, rtol=5e-4, atol=5e-5):
         close(p.grad, sd[k].grad, 2e-3, 2e-4, f"{name} grad {k}")
 
 
+@ARITH
 def test_rcan_reduced_vs_oracle():
     torch.manual_seed(8)
     net = A.RCAN(n_resblocks=2, n_resgroups=2, n_feats=64, scale=4)
     net_vs_oracle(net, "rcan", dict(n_resgroups=2, n_resblocks=2, scale=4), rnd(2, 3, 20, 36, seed=30, scale=0.5))
 
 
+@ARITH
 @pytest.mark.parametrize("scale", [2, 3, 4])
 def test_edsr_reduced_vs_oracle(scale):
     torch.manual_seed(8)
@@ -524,6 +544,7 @@ F64_CASES = {
 }
 
 
+@ARITH
 @pytest.mark.parametrize("kind", sorted(F64_CASES))
 def test_reduced_net_gradients_against_float64_oracle(kind):
     """Tighter than the elementwise fp32 comparisons: every parameter gradient of a reduced net within 5e-5 of a FLOAT64
@@ -562,6 +583,7 @@ def test_reduced_net_gradients_against_float64_oracle(kind):
         assert err <= 5e-5 * float(want.norm()) + 1e-5, (k, err, float(want.norm()))
 
 
+@ARITH
 def test_qrcan_reduced_vs_oracle():
     torch.manual_seed(8)
     net = A.QRCAN(n_resblocks=3, n_resgroups=2, n_feats=64, scale=4, style="standard", num_metadata=10,
@@ -577,6 +599,7 @@ def _live_gammas(net):
         net.csa.gamma.fill_(0.37)
 
 
+@ARITH
 def test_han_reduced_vs_oracle():
     torch.manual_seed(8)
     net = sisr_amd.han.HAN(n_resgroups=10, n_resblocks=1, n_feats=64, scale=4)
@@ -584,6 +607,7 @@ def test_han_reduced_vs_oracle():
     net_vs_oracle(net, "han", dict(n_resgroups=10, n_resblocks=1, scale=4), rnd(1, 3, 12, 20, seed=37, scale=0.5))
 
 
+@ARITH
 def test_qhan_reduced_vs_oracle():
     torch.manual_seed(8)
     net = sisr_amd.han.QHAN(n_resgroups=10, n_resblocks=1, n_feats=64, num_metadata=10, scale=4)
@@ -605,6 +629,7 @@ def test_qrcan_pixel_attention_and_modulate_vs_oracle():
     net_vs_oracle(net, "qrcan", cfg, rnd(2, 3, 9, 21, seed=45, scale=0.5), rnd(2, 64, 1, 1, seed=46, scale=0.3).abs())
 
 
+@ARITH
 def test_qedsr_reduced_vs_oracle():
     torch.manual_seed(8)
     net = A.QEDSR(num_features=64, num_blocks=2, scale=4, res_scale=0.1, input_para=10)
@@ -624,6 +649,7 @@ def build_gpu(name, eval_mode=True, **extra):
 
 @pytest.mark.parametrize("name", [n for n in ("edsr", "rcan", "qedsr", "qrcan", "han", "qhan")
                                   if n in sisr_amd.available_models])
+@ARITH
 def test_set5_forward_psnr_parity_with_reference(name):
     """Seed-8 full-depth net on every Set5 LR image: Y-PSNR within 1e-3 dB of the reference's CPU output."""
     ref = golden_json("g3_full_depth")[name]["images"]
@@ -639,6 +665,7 @@ def test_set5_forward_psnr_parity_with_reference(name):
         close(o[:, hh // 2 - 16:hh // 2 + 16, ww // 2 - 16:ww // 2 + 16], crops[im], 1e-3, 1e-4, im)
 
 
+@ARITH
 @pytest.mark.parametrize("name", [n for n in ("edsr", "qedsr", "rcan", "qrcan") if n in sisr_amd.available_models])
 def test_run_train_trajectory_matches_reference(name):
     """5 handler.run_train steps (L1 + backward + Adam + per-batch cosine restarts) vs the reference's."""
@@ -804,6 +831,7 @@ def test_rccl_backend_single_rank_grad_reducer():
     assert res["0"] == res["1"], res
 
 
+@ARITH
 def test_set5_training_psnr_parity_at_equal_steps():
     """north_star: 'PSNR on Set5 within 0.02 dB of the reference at equal steps'.  EDSR-baseline (16 blocks,
     full depth) trained for 40 Adam steps on seeded Set5 crops, once on the HIP kernels and once by the CPU
@@ -842,6 +870,7 @@ def test_set5_training_psnr_parity_at_equal_steps():
     assert max(abs(d) for d in diffs) < 0.02, diffs
 
 
+@ARITH
 @pytest.mark.parametrize("groups,blocks", [(2, 3), (10, 20)])
 def test_set5_training_psnr_parity_meta_rcan(groups, blocks):
     """The same for north_star's target family -- RCAN + meta-attention (QRCAN, style 'standard', q-layers on), at a
