@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void meta_gate_many_bwd_param_scatter_kernel(c
 // meta-attention gate) is applied last.  The forward keeps every layer's output (acts) for the backward, which
 // returns d pool, d metadata, d mul and, summed over the batch in batch order, the parameter gradients.
 #define GM_MAXL 4
-#define GM_MAXW 160
+#define GM_MAXW 544  // widest layer input: 512 pooled channels + 32 metadata values
 struct GateMlp {
   const float* w[GM_MAXL];
   const float* b[GM_MAXL];
@@ -466,28 +466,31 @@ __global__ __launch_bounds__(256) void gate_residual_fwd_kernel(const float* __r
 
 // dg partials: part[b][k][c] = sum over pixel slice k of dy*t (t == nullptr: of dy -- the plain GAP)
 // (C = 64, 256 threads = 16 px x 16 float4)
+// Maps wider than 64 channels (gated blocks at n_feats = 128, 256, ...): blockIdx.z = 64-channel chunk of a pixel of C
+// channels; part is [B][parts][C].  For C = 64 this is the kernel it always was.
 __global__ __launch_bounds__(256) void gate_dg_partial_kernel(const float* __restrict__ dy, const float* __restrict__ t,
-                                                              float* __restrict__ part, long hw, int parts) {
+                                                              float* __restrict__ part, long hw, int parts, int C) {
   __shared__ f32x4 red[256];
-  const int b = blockIdx.y, k = blockIdx.x;
+  const int b = blockIdx.y, k = blockIdx.x, chunk = blockIdx.z;
   const int c4 = threadIdx.x & 15, pr = threadIdx.x >> 4;
+  const int ps = C >> 2;  // float4 per pixel
   const long per = (hw + parts - 1) / parts;
   const long p0 = (long)k * per;
   const long p1 = p0 + per < hw ? p0 + per : hw;
-  const f32x4* d4 = reinterpret_cast<const f32x4*>(dy) + (long)b * hw * 16;
-  const f32x4* t4 = reinterpret_cast<const f32x4*>(t) + (long)b * hw * 16;
+  const f32x4* d4 = reinterpret_cast<const f32x4*>(dy) + (long)b * hw * ps + chunk * 16;
+  const f32x4* t4 = reinterpret_cast<const f32x4*>(t) + (long)b * hw * ps + chunk * 16;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (t) {
-    for (long p = p0 + pr; p < p1; p += 16) acc += d4[p * 16 + c4] * t4[p * 16 + c4];
+    for (long p = p0 + pr; p < p1; p += 16) acc += d4[p * ps + c4] * t4[p * ps + c4];
   } else {
-    for (long p = p0 + pr; p < p1; p += 16) acc += d4[p * 16 + c4];
+    for (long p = p0 + pr; p < p1; p += 16) acc += d4[p * ps + c4];
   }
   red[threadIdx.x] = acc;
   __syncthreads();
   if (threadIdx.x < 16) {
     f32x4 s = red[threadIdx.x];
     for (int r = 1; r < 16; ++r) s += red[r * 16 + threadIdx.x];
-    reinterpret_cast<f32x4*>(part + ((long)b * parts + k) * 64)[threadIdx.x] = s;
+    reinterpret_cast<f32x4*>(part + ((long)b * parts + k) * C + chunk * 64)[threadIdx.x] = s;
   }
 }
 
@@ -844,10 +847,11 @@ extern "C" int sisr_gate_dg_parts(long hw) {
 extern "C" int sisr_gate_dg_partial(const float* dy, const float* t, float* part, int B, long hw, int channels,
                                     void* stream) {
   if (!dy || !part || B <= 0 || hw <= 0) return SISR_ERR_ARG;  /* t may be NULL: plain pixel sums */
-  if (channels != 64) return SISR_ERR_UNSUPPORTED;
+  if (channels <= 0 || (channels & 63) || channels > 64 * 64) return SISR_ERR_UNSUPPORTED;
   if (!sisr_aligned16(dy) || !sisr_aligned16(t) || !sisr_aligned16(part)) return SISR_ERR_ALIGN;
   const int parts = sisr_gate_dg_parts(hw);
-  hipLaunchKernelGGL(gate_dg_partial_kernel, dim3(parts, B), dim3(256), 0, (hipStream_t)stream, dy, t, part, hw, parts);
+  hipLaunchKernelGGL(gate_dg_partial_kernel, dim3(parts, B, channels / 64), dim3(256), 0, (hipStream_t)stream, dy, t, part, hw,
+                     parts, channels);
   return sisr_check_launch();
 }
 

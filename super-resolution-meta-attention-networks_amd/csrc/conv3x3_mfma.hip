@@ -781,6 +781,10 @@ __device__ __forceinline__ u32x4 sisr_pack_bf16x8(f32x4 a, f32x4 b) {
   return __builtin_bit_cast(u32x4, r);
 }
 
+__device__ __forceinline__ bf16x8 sisr_buf_load_bf16x8(sisr_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
+}
+
 #define BH_PIX 128  // bytes per halo pixel
 #define BE_LD 68    // floats per pixel row of the epilogue transpose buffer (64 + 4: rows 272 B apart)
 
@@ -930,7 +934,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_bf16_kernel(ConvParams p) 
 
     // ---- K loop: 36 steps (tap t = s >> 2, 16-channel block kb = s & 3) x 2 MFMAs
     const unsigned char* wq = wbase + ((long)q * p.cin_chunks + c) * (36 * 2048);  // scalar
-#define BF_LOAD_B(s) (*reinterpret_cast<const bf16x8*>(wq + (s) * 2048 + boff))
+    const sisr_rsrc_t rwq = sisr_rsrc(wq);  // weight fragments by {resource, lane offset, scalar offset}: sisr_common.h
+#define BF_LOAD_B(s) sisr_buf_load_bf16x8(rwq, boff, (unsigned)((s) * 2048))
 #define BF_LOAD_A(m, s) \
   (*reinterpret_cast<const bf16x8*>(ldsb + ((((s) >> 2) / 3 + (m)) * (HALO_W * BH_PIX)) + aoff[((s) >> 2) % 3][(s) & 3]))
     bf16x8 bq[4];
@@ -1074,6 +1079,12 @@ __device__ __forceinline__ void sisr_store_split3(unsigned char* dst, f32x4 a, f
 template <bool AFFINE, bool MASK, bool RES, bool GATE = false, bool DOT = false, int BD = 4, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, long wplane) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  // Wave priority: the two resident workgroups take turns in the K loop (the older wave's MFMA stream wins the SIMD's
+  // arbiter), and per-CU timelines from in-kernel stamps showed the waiting workgroup's staging -- ~1 500 vector
+  // instructions of operand splitting -- crawling in the leftover slots and finishing ~2 us AFTER the pipe had freed up
+  // (K phases of 8.8 us with 2 us holes).  Unlike the fp32 MFMA, the bf16 MFMA holds the issue port for 8 of its 32 cycles
+  // only, so staging and epilogue at raised priority fit into the gaps of the other workgroup's MFMA stream.
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.y;
   int bid;
@@ -1094,8 +1105,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, lo
   const int Cout = p.cout_chunks * 64;
 
   const float bv = p.bias ? p.bias[co * p.bias_n + q * p.bias_q] : 0.f;
-  unsigned long long st0 = 0, st1 = 0, st2 = 0;  // STAMP: diagnostic build (tools/x3_phases.py), outputs meaningless
-  if (STAMP) st0 = __builtin_amdgcn_s_memtime();
+  unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;  // STAMP: diagnostic build (tools/conv_timeline.py x3), outputs meaningless
+  if (STAMP) {
+    st0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
   f32x16 acc0, acc1, cor0 = {0}, cor1 = {0};  // hi*hi products / the five correction products
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = bv;
@@ -1204,10 +1218,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, lo
     __syncthreads();
 
     if (STAMP) st1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_setprio(0);
     // ---- K loop: 36 steps (tap t = s >> 2, 16-channel block kb = s & 3); per step and M-tile six MFMAs:
     // hi*hi into the main accumulator, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid into the correction accumulator
     const unsigned char* wq = wbase + ((long)q * p.cin_chunks + c) * (36 * 2048);  // scalar
-#define BF_LOAD_B(s, pl) (*reinterpret_cast<const bf16x8*>(wq + (pl) * wplane + (s) * 2048 + boff))
+    const sisr_rsrc_t rwq = sisr_rsrc(wq);  // weight fragments by {resource, lane offset, scalar offset}: sisr_common.h
+#define BF_LOAD_B(s, pl) sisr_buf_load_bf16x8(rwq, boff, (unsigned)((pl) * (unsigned)wplane + (s) * 2048))
 #define BF_LOAD_A(m, s, pl) \
   (*reinterpret_cast<const bf16x8*>(ldsb + (pl) * X3_PLANE + ((((s) >> 2) / 3 + (m)) * (HALO_W * BH_PIX)) + aoff[((s) >> 2) % 3][(s) & 3]))
     constexpr int RING = BD + 1;
@@ -1258,6 +1274,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, lo
   }
 
   if (STAMP) st2 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_setprio(3);
   acc0 += cor0;
   acc1 += cor1;
   // ---- epilogue.  The kernel is HBM-bound, so output / mask / residual traffic must move as whole 256-B pixel
@@ -1343,11 +1360,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, lo
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long st3 = __builtin_amdgcn_s_memtime();
     if (lane == 0 && p.dot) {  // the stamp buffer rides in p.dot (unused by this instantiation)
-      unsigned* dbg = reinterpret_cast<unsigned*>(const_cast<float*>(p.dot)) + ((long)blockIdx.x * 4 + wave) * 4;
-      dbg[0] = (unsigned)(st1 - st0);
-      dbg[1] = (unsigned)(st2 - st1);
-      dbg[2] = (unsigned)(st3 - st2);
-      dbg[3] = (unsigned)(st0 & 0xffffffffu);
+      // same record as the fp32 kernel's (sisr_diag_conv_stamp): shader-clock phases, 100 MHz start and lifetime, placement
+      const unsigned long long rt3 = __builtin_amdgcn_s_memrealtime();
+      unsigned* dbg = reinterpret_cast<unsigned*>(const_cast<float*>(p.dot)) + ((long)blockIdx.x * 4 + wave) * 8;
+      dbg[0] = (unsigned)(st0 & 0xffffffffu);
+      dbg[1] = (unsigned)(rt0 & 0xffffffffu);
+      dbg[2] = (unsigned)(st1 - st0);
+      dbg[3] = (unsigned)(st2 - st1);
+      dbg[4] = (unsigned)(st3 - st2);
+      dbg[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+      dbg[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+      dbg[7] = (unsigned)(rt3 - rt0);
     }
   }
 }
@@ -1502,12 +1525,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
     decode(tile, b, h0, w0);
 
     // ---- K loop (36 steps x 2 MFMAs), B fragments eight steps ahead
-    const unsigned char* wq = wq0;
-    asm volatile("" : "+s"(wq));  // per-iteration copy: keeps 36 loop-invariant 64-bit B addresses from being hoisted
+    const sisr_rsrc_t rwq = sisr_rsrc(wq0);  // weight fragments by {resource, lane offset, scalar offset}: no address VGPRs
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = bv;
-#define PB_LOAD_B(s) (*reinterpret_cast<const bf16x8*>(wq + (s) * 2048 + boff))
+#define PB_LOAD_B(s) sisr_buf_load_bf16x8(rwq, boff, (unsigned)((s) * 2048))
 #define PB_LOAD_A(m, s) \
   (*reinterpret_cast<const bf16x8*>(cur + ((((s) >> 2) / 3 + (m)) * (HALO_W * BH_PIX)) + aoff[((s) >> 2) % 3][(s) & 3]))
     {

@@ -1280,25 +1280,29 @@ def fused_groups_enabled():
 
 def res_block(x, w1, b1, w2, b2, ca=None, m=None, res_scale=1.0):
     """ca = (w1,b1,w2,b2) of the CA squeeze/excite 1x1 convs or None; m = (B,64) meta gate or None."""
+    if x.shape[1] != 64 and (ca is not None or m is not None):
+        return _wide_gated_block(x, w1, b1, w2, b2, ca, m, float(res_scale))
     caw1, cab1, caw2, cab2 = ca if ca is not None else (None, None, None, None)
     return _ResBlock.apply(x, w1, b1, w2, b2, caw1, cab1, caw2, cab2, m, float(res_scale))
 
 
 class _ConvReluConv(Function):
-    """t2 = conv2(relu(conv1(x))) without gate/skip (used by the metadata-mixing QCALayer styles)."""
+    """t2 = alpha * conv2(relu(conv1(x))) without gate/skip (the metadata-mixing QCALayer styles; gated blocks wider than 64
+    channels); any multiple of 64 channels."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, alpha):
         B, C, H, W = x.shape
-        if C != 64:
-            raise NotImplementedError("fused conv pair is specialised for n_feats = 64")
+        if C % 64 or tuple(w1.shape) != (C, C, 3, 3) or tuple(w2.shape) != (C, C, 3, 3):
+            raise NotImplementedError("fused conv pair needs n_feats to be a multiple of 64")
         x = _cl(x)
         w1, w2 = w1.contiguous(), w2.contiguous()
-        v = hip.view_plain(H, W, 64)
-        t1, t2 = _empty_cl(B, 64, H, W, x.device), _empty_cl(B, 64, H, W, x.device)
-        conv_c64(x, v, pack_weight(w1, "fwd"), b1, (1, 64), t1, v, B, H, W, 64, 64, relu=True)
-        conv_c64(t1, v, pack_weight(w2, "fwd"), b2, (1, 64), t2, v, B, H, W, 64, 64)
+        v = hip.view_plain(H, W, C)
+        t1, t2 = _empty_cl(B, C, H, W, x.device), _empty_cl(B, C, H, W, x.device)
+        conv_c64(x, v, pack_weight(w1, "fwd"), b1, (1, 64), t1, v, B, H, W, C, C, relu=True)
+        conv_c64(t1, v, pack_weight(w2, "fwd"), b2, (1, 64), t2, v, B, H, W, C, C, alpha=alpha)
         ctx.save_for_backward(x, w1, w2, t1)
+        ctx.alpha, ctx.b1, ctx.b2 = alpha, b1, b2
         return t2
 
     @staticmethod
@@ -1310,24 +1314,41 @@ class _ConvReluConv(Function):
             B, C, H, W = x.shape
             dev = x.device
             dt2 = _cl(dt2)
-            v = hip.view_plain(H, W, 64)
-            dt1 = _empty_cl(B, 64, H, W, dev)
-            conv_c64(dt2, v, pack_weight(w2, "dgrad"), None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1)
-            dw2, db2 = torch.empty_like(w2), torch.empty(64, device=dev)
-            wgrad_c64(t1, v, dt2, v, dw2, db2, B, H, W, 64, 64, owner=w2)
+            v = hip.view_plain(H, W, C)
+            dt1 = _empty_cl(B, C, H, W, dev)
+            conv_c64(dt2, v, pack_weight(w2, "dgrad"), None, (1, 64), dt1, v, B, H, W, C, C, mask=t1, alpha=ctx.alpha)
+            dw2, db2 = _grad_buf(w2), _grad_buf_or(ctx.b2, C, dev)
+            wgrad_c64(t1, v, dt2, v, dw2, db2, B, H, W, C, C, alpha=ctx.alpha, owner=w2)
             dx = None
             if ctx.needs_input_grad[0]:
-                dx = _empty_cl(B, 64, H, W, dev)
-                conv_c64(dt1, v, pack_weight(w1, "dgrad"), None, (1, 64), dx, v, B, H, W, 64, 64)
-            dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
-            wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, 64, 64, owner=w1)
-            return dx, dw1, db1, dw2, db2
+                dx = _empty_cl(B, C, H, W, dev)
+                conv_c64(dt1, v, pack_weight(w1, "dgrad"), None, (1, 64), dx, v, B, H, W, C, C)
+            dw1, db1 = _grad_buf(w1), _grad_buf_or(ctx.b1, C, dev)
+            wgrad_c64(x, v, dt1, v, dw1, db1, B, H, W, C, C, owner=w1)
+            return dx, dw1, db1, dw2, db2, None
         finally:
             IN_BACKWARD = False
 
 
-def res_block_convs(x, w1, b1, w2, b2):
-    return _ConvReluConv.apply(x, w1, b1, w2, b2)
+def res_block_convs(x, w1, b1, w2, b2, alpha=1.0):
+    return _ConvReluConv.apply(x, w1, b1, w2, b2, float(alpha))
+
+
+def _wide_gated_block(x, w1, b1, w2, b2, ca, m, res_scale):
+    """RCAB / QRCAB('standard') / ParamResBlock at n_feats = 128, 192, 256, ... (ref: attention_manipulators/handlers.py:24-29
+    forwards n_feats to QRCAN): the same arithmetic from the modular operators -- conv pair on the multi-chunk MFMA kernels,
+    ordered pixel sums, the squeeze / excite MLP on the generic gate kernel (one workgroup per sample), gate * t2 + x --
+    instead of the 64-channel fused node."""
+    B, C = x.shape[0], x.shape[1]
+    t2 = res_block_convs(x, w1, b1, w2, b2, alpha=res_scale)
+    if ca is not None:
+        caw1, cab1, caw2, cab2 = ca
+        pool = global_avg_pool(t2)
+        md0 = x.new_zeros((B, 1, 1, 1))  # the plain squeeze / excite stack concatenates no metadata
+        g = _GateMlp.apply(pool, md0, m, ([(0, 0, 1), (0, 0, 2)], 0), caw1, cab1, caw2, cab2)
+    else:
+        g = m
+    return gate_mul(t2, g.reshape(B, C, 1, 1), x)
 
 
 # ----------------------------------------------------------------------------- plain conv(+ReLU) chains (SRMD)
@@ -1905,12 +1926,12 @@ def sftmd_forward(net, x, metadata):
 
 
 # ----------------------------------------------------------------------------- stand-alone gates
-def _pixel_sums(t, other, B, H, W):
-    """[B][parts][64] ordered partial sums of t*other (other None: of t)."""
+def _pixel_sums(t, other, B, H, W, C=64):
+    """[B][parts][C] ordered partial sums of t*other (other None: of t); C a multiple of 64."""
     L = hip.lib()
     parts = L.sisr_gate_dg_parts(H * W)
-    part = torch.empty((B, parts, 64), device=t.device, dtype=torch.float32)
-    hip.check(L.sisr_gate_dg_partial(hip.ptr(t), hip.ptr(other), hip.ptr(part), B, H * W, 64, hip.stream()),
+    part = torch.empty((B, parts, C), device=t.device, dtype=torch.float32)
+    hip.check(L.sisr_gate_dg_partial(hip.ptr(t), hip.ptr(other), hip.ptr(part), B, H * W, C, hip.stream()),
               "sisr_gate_dg_partial")
     return part, parts
 
@@ -1965,6 +1986,10 @@ class _CALayer(Function):
 
 
 def ca_layer(x, w1, b1, w2, b2):
+    if x.shape[1] != 64:  # wider maps: pooled sums + the generic gate MLP + gate multiply (see _wide_gated_block)
+        B, C = x.shape[0], x.shape[1]
+        g = _GateMlp.apply(global_avg_pool(x), x.new_zeros((B, 1, 1, 1)), None, ([(0, 0, 1), (0, 0, 2)], 0), w1, b1, w2, b2)
+        return gate_mul(x, g.reshape(B, C, 1, 1))
     return _CALayer.apply(x, w1, b1, w2, b2)
 
 
@@ -1985,11 +2010,11 @@ class _GateMul(Function):
     def backward(ctx, dy):
         t, g2 = ctx.saved_tensors
         B, C, H, W = t.shape
-        if C != 64:
-            raise NotImplementedError("gate backward is specialised for 64 channels")
+        if C % 64:
+            raise NotImplementedError("gate backward needs a multiple of 64 channels")
         dy = _cl(dy)
         dt = _affine(dy, g2, None, None, B, H, W, C)
-        dgp, parts = _pixel_sums(dy, t, B, H, W)
+        dgp, parts = _pixel_sums(dy, t, B, H, W, C)
         dg = _vec(B, C, t.device)
         hip.check(hip.lib().sisr_sum_partials(hip.ptr(dgp), parts, B, C, 1.0, hip.ptr(dg), hip.stream()),
                   "sisr_sum_partials")
@@ -2006,10 +2031,10 @@ class _GlobalAvgPool(Function):
     @staticmethod
     def forward(ctx, t):
         B, C, H, W = t.shape
-        if C != 64:
-            raise NotImplementedError("GAP kernel is specialised for 64 channels")
+        if C % 64:
+            raise NotImplementedError("GAP kernel needs a multiple of 64 channels")
         t = _cl(t)
-        part, parts = _pixel_sums(t, None, B, H, W)
+        part, parts = _pixel_sums(t, None, B, H, W, C)
         s = _vec(B, C, t.device)
         hip.check(hip.lib().sisr_sum_partials(hip.ptr(part), parts, B, C, 1.0 / (H * W), hip.ptr(s), hip.stream()),
                   "sisr_sum_partials")

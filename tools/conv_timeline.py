@@ -21,6 +21,9 @@ import sisr_amd  # noqa: E402
 ops, hip = sisr_amd.ops, sisr_amd.hip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 form = sys.argv[2] if len(sys.argv) > 2 else "plain"
+if form == "x3":  # the bf16x3 conv kernel's stamped instantiation (its record rides in the `dot` operand)
+    os.environ["SISR_X3_STAMP"] = "1"
+    ops.set_precision("bf16x3")
 H = W = 128
 dev = torch.device("cuda:0")
 cl = torch.channels_last
@@ -33,9 +36,10 @@ b = torch.randn(64, device=dev)
 sc, sh = torch.rand(B, 64, device=dev), torch.rand(B, 64, device=dev)
 pk = ops.pack_weight(w, "fwd")
 v = hip.view_plain(H, W, 64)
-rows = 4 if os.environ.get("SISR_CONV_TILE_ROWS", "") == "4" else 2  # the library's tile-height rule for this grid
+rows = 4 if (os.environ.get("SISR_CONV_TILE_ROWS", "") == "4" or form == "x3") else 2  # the library's tile-height rule for this grid
 nwg = B * (H // rows) * (W // 32)
 stamp = torch.zeros(nwg * 4 * 8, dtype=torch.int32, device=dev)
+gap = torch.empty(B, ops.gap_parts(H, W), 64, device=dev)
 L = hip.lib()
 
 
@@ -46,6 +50,8 @@ def launch():
         ops.conv_c64(x, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1, in_scale=sc, in_shift=sh)
     elif form == "res":
         ops.conv_c64(x, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, res=t1)
+    elif form == "x3":
+        ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64, gap=gap, dot=stamp.view(torch.float32))
     elif form == "gate":
         ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64, relu=True, in_scale=sc, gate_add=t1, gate_out=u)
     else:
@@ -74,7 +80,8 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 plain_us = e0.elapsed_time(e1) * 50
-L.sisr_diag_conv_stamp(stamp.data_ptr())
+if form != "x3":
+    L.sisr_diag_conv_stamp(stamp.data_ptr())
 for _ in range(20):
     launch()
 torch.cuda.synchronize()
@@ -134,8 +141,9 @@ out["kloop_cover_of_span"] = {"mean": float(np.mean(cover)), "min": float(np.min
 out["workgroups_in_kloop_when_any"] = float(np.mean(conc))
 out["resident_workgroups_mean_over_span"] = float(np.mean(resident))
 out["workgroups_per_cu"] = {"mean": float(np.mean(nres)), "min": int(np.min(nres)), "max": int(np.max(nres))}
-out["mfma_cycles_per_wave"] = 144 * rows * 64
-out["mfma_us_per_cu_at_this_clock"] = float(np.mean(nres)) * 144 * rows * 64 / (ghz * 1e3)
+mfma_cyc = 432 * 32 if form == "x3" else 144 * rows * 64  # bf16x3: 36 steps x 12 MFMAs of 32 cycles per wave-tile
+out["mfma_cycles_per_wave"] = mfma_cyc
+out["mfma_us_per_cu_at_this_clock"] = float(np.mean(nres)) * mfma_cyc / (ghz * 1e3)
 rel = np.sort(w_s)
 out["start_quantiles_us"] = [round(float(rel[int(q * (len(rel) - 1))]), 2) for q in (0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 1.0)]
 rel = np.sort(w_e)
