@@ -389,6 +389,9 @@ int sisr_pixel_shuffle_cl(const float* src, float* dst, int B, int H, int W, int
  * bounds [out][2] (first tap, taps) and coef [out][ksize] int32 are device copies of the host tables. */
 int sisr_blur_quant(const float* x, const float* kernel, unsigned char* y_u8, float* y_f32, int C, int H, int W, int l,
                     void* stream);
+/* y = byte(255 * clamp(noise * sigma + blur, 0, 1)) over n values: b_GaussianNoising on the blurred image followed by
+ * ToPILImage's quantisation (ref: sr_tools/gaussian_utils.py:306-312, 409-411); `noise` is the host-drawn N(0,1) field */
+int sisr_noise_quant(const float* blur, const float* noise, float sigma, unsigned char* y_u8, long n, void* stream);
 int sisr_pil_resample(const unsigned char* in, void* out, const int* bounds, const int* coef, int ksize, int C, int Hin,
                       int Win, int Hout, int Wout, int vertical, int to_float, void* stream);
 

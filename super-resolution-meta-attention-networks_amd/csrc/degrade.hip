@@ -49,6 +49,18 @@ __global__ __launch_bounds__(256) void blur_quant_kernel(const float* __restrict
   }
 }
 
+// Gaussian noise on the blurred image, then ToPILImage's quantisation (ref: gaussian_utils.py:306-312 b_GaussianNoising,
+// :409-411): y = byte(255 * clamp(noise * sigma + blur, 0, 1)).  The noise field itself is drawn on the host from numpy's
+// global stream (the reference's np.random.normal call); product and sum are rounded separately, as torch's mul / add are.
+__global__ __launch_bounds__(256) void noise_quant_kernel(const float* __restrict__ blur, const float* __restrict__ noise,
+                                                          float sigma, unsigned char* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = __fadd_rn(__fmul_rn(noise[i], sigma), blur[i]);
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    y[i] = (unsigned char)(int)(v * 255.0f);
+  }
+}
+
 // One PIL resample pass over a planar uint8 image: out[c][y][x] = clip8((2^21 + sum_k in[...] * coef[x][k]) >> 22).
 // horizontal: in [C][H][Win] -> out [C][H][Wout], taps run along x; vertical: in [C][Hin][W] -> out [C][Hout][W].
 // bounds[o] = (first input index, tap count); coef [out][ksize] int32.
@@ -92,6 +104,13 @@ extern "C" int sisr_blur_quant(const float* x, const float* kernel, unsigned cha
   const dim3 grid((W + BT - 1) / BT, (H + BT - 1) / BT, C);
   if (grid.y > 65535) return SISR_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(blur_quant_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, kernel, y_u8, y_f32, H, W, l);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_noise_quant(const float* blur, const float* noise, float sigma, unsigned char* y_u8, long n,
+                                void* stream) {
+  if (!blur || !noise || !y_u8 || n <= 0) return SISR_ERR_ARG;
+  hipLaunchKernelGGL(noise_quant_kernel, dim3(deg_blocks(n)), dim3(256), 0, (hipStream_t)stream, blur, noise, sigma, y_u8, n);
   return sisr_check_launch();
 }
 

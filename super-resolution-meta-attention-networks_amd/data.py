@@ -93,26 +93,31 @@ class DeviceTileSampler:
     """
 
     def __init__(self, lr_images, hr_images, scale, crop, device, augment=True):
+        """lr_images None: HR images only -- the LR side of every batch is synthesised on the device per access
+        (DeviceTileLoader with `online_degradations`) and handed to sample_pairs."""
         from . import hip
-        if len(lr_images) != len(hr_images) or not lr_images:
+        if not hr_images or (lr_images is not None and len(lr_images) != len(hr_images)):
             raise ValueError("need the same, non-zero number of LR and HR images")
         self.hip, self.scale, self.crop, self.augment = hip, int(scale), int(crop), bool(augment)
         self.device = torch.device(device)
-        self.lr = [t.to(self.device, torch.float32).contiguous() for t in lr_images]
         self.hr = [t.to(self.device, torch.float32).contiguous() for t in hr_images]
+        self.lr = [t.to(self.device, torch.float32).contiguous() for t in lr_images] if lr_images is not None else []
+        self.channels = self.hr[0].shape[0]
         for a, b in zip(self.lr, self.hr):
             if a.dim() != 3 or b.dim() != 3 or b.shape[1] != a.shape[1] * self.scale or b.shape[2] != a.shape[2] * self.scale:
                 raise ValueError(f"HR {tuple(b.shape)} is not {self.scale}x LR {tuple(a.shape)}")
             if min(a.shape[1], a.shape[2]) < self.crop:
                 raise ValueError(f"LR image {tuple(a.shape)} is smaller than the {self.crop}-pixel tile")
-        self.channels = self.lr[0].shape[0]
 
     def __len__(self):
-        return len(self.lr)
+        return len(self.hr)
 
     def draw(self, index, rng=random):
         """(top, left, hflip, vflip, transpose) for one sample, consuming `rng` exactly like the reference."""
-        _, h, w = self.lr[index].shape
+        return self.draw_for(self.lr[index], rng)
+
+    def draw_for(self, lr_image, rng=random):
+        _, h, w = lr_image.shape
         hflip = vflip = rot = False
         if self.augment:
             hflip = rng.random() < 0.5
@@ -125,17 +130,21 @@ class DeviceTileSampler:
 
     def sample(self, indices, rng=random):
         """-> (lr [B][C][crop][crop], hr [B][C][s*crop][s*crop]) fp32 tensors on the device."""
+        return self.sample_pairs([(self.lr[i], self.hr[i]) for i in indices], rng)
+
+    def sample_pairs(self, pairs, rng=random):
+        """The same for explicit (LR, HR) device image pairs (contiguous planar fp32, HR = scale x LR): one gather per side."""
         hip, s = self.hip, self.scale
-        B = len(indices)
+        B = len(pairs)
         rec_lr, rec_hr = [], []
-        for i in indices:
-            top, left, hf, vf, rot = self.draw(i, rng)
-            _, h, w = self.lr[i].shape
+        for lr_im, _ in pairs:
+            top, left, hf, vf, rot = self.draw_for(lr_im, rng)
+            _, h, w = lr_im.shape
             rec_lr.append([h, w, top, left, int(hf), int(vf), int(rot), 0])
             rec_hr.append([h * s, w * s, top * s, left * s, int(hf), int(vf), int(rot), 0])
         out = []
-        for imgs, recs, c in ((self.lr, rec_lr, self.crop), (self.hr, rec_hr, self.crop * s)):
-            ptrs = torch.tensor([imgs[i].data_ptr() for i in indices], dtype=torch.int64).to(self.device)
+        for side, recs, c in ((0, rec_lr, self.crop), (1, rec_hr, self.crop * s)):
+            ptrs = torch.tensor([p[side].data_ptr() for p in pairs], dtype=torch.int64).to(self.device)
             prm = torch.tensor(recs, dtype=torch.int32).to(self.device)
             dst = torch.empty((B, self.channels, c, c), device=self.device, dtype=torch.float32)
             hip.check(hip.lib().sisr_crop_augment(ptrs.data_ptr(), prm.data_ptr(), hip.ptr(dst), B, self.channels, c,
@@ -163,11 +172,28 @@ class DeviceTileLoader:
             raise ValueError("device_tiles needs one common `crop` size, augmentation flag and scale on all training sets")
         lr, hr, self.tags, self.hr_tags, meta = [], [], [], [], []
         self.metadata_keys = datasets[0].metadata_keys
+        online = {bool(getattr(d, 'online_degradations', False)) for d in datasets}
+        if len(online) != 1:
+            raise ValueError("device_tiles: either every training set synthesises its LR images (online_degradations) or none")
+        self.online = online.pop()
+        self.degraders = []  # per image: the degrader of its dataset (each dataset builds its own PCA basis, ref :228-238)
         for d in datasets:
             if d.hr_base is None:
                 raise ValueError("device_tiles needs HR images (training sets)")
             if d.metadata_keys != self.metadata_keys:
                 raise ValueError("training sets disagree on their metadata columns")
+            if self.online:
+                # ref data_handler.py:446-456: the LR image is synthesised from the HR one at every access.  Only the HR
+                # images live on the device; each access blurs / (noises) / down-samples the WHOLE image there, as the
+                # reference does before it crops, with the kernel (and noise) draws on the host in the reference's order
+                for i in range(len(d)):
+                    base_name = d.base_filenames[i]
+                    hr.append(to_tensor(read_image(os.path.join(d.hr_base, base_name))))
+                    self.tags.append(base_name)
+                    self.hr_tags.append(base_name)
+                    meta.append(None)
+                    self.degraders.append(d.degrader)
+                continue
             for i in range(len(d)):
                 base_name, image_name = d.base_filenames[i], d.lr_filenames[i]
                 lr_im = read_image(os.path.join(d.lr_base, image_name))
@@ -181,7 +207,8 @@ class DeviceTileLoader:
                 self.hr_tags.append(base_name)
                 meta.append(d.metadata[i] if d.metadata is not None else None)
         self.metadata = meta
-        self.sampler = DeviceTileSampler(lr, hr, scale=scales.pop(), crop=crops.pop(), device=device, augment=augs.pop())
+        self.sampler = DeviceTileSampler(None if self.online else lr, hr, scale=scales.pop(), crop=crops.pop(), device=device,
+                                         augment=augs.pop())
         self.dataset = self.sampler  # len(loader.dataset), as callers of a DataLoader expect
 
     def __len__(self):
@@ -199,9 +226,24 @@ class DeviceTileLoader:
             idx = order[start:start + self.batch_size]
             if len(idx) < self.batch_size and self.drop_last:
                 return
-            lr, hr = self.sampler.sample(idx)
             B = len(idx)
             zeros = torch.zeros(B, dtype=torch.int64)
+            if self.online:
+                pairs, codes, kernels = [], [], []
+                for i in idx:  # per sample, in batch order: degrader draws (np.random), then flip / crop draws (random)
+                    hr_full = self.sampler.hr[i]
+                    lr_dev, code, kernel, (top, left, rh, rw) = self.degraders[i](hr_full)
+                    hr_c = hr_full if (rh, rw) == tuple(hr_full.shape[1:]) else hr_full[:, top:top + rh, left:left + rw].contiguous()
+                    pairs.append((lr_dev.contiguous(), hr_c))
+                    codes.append(code.numpy())
+                    kernels.append(kernel.numpy().squeeze())
+                lr, hr = self.sampler.sample_pairs(pairs)
+                yield {'lr': lr, 'hr': hr, 'tag': [self.tags[i] for i in idx], 'hr_tag': [self.hr_tags[i] for i in idx],
+                       'mask': zeros.clone(), 'halfway_data': zeros.clone(), 'metadata': torch.from_numpy(np.stack(codes)),
+                       'metadata_keys': [tuple(k for _ in range(B)) for k in self.metadata_keys],
+                       'blur_kernels': torch.from_numpy(np.stack(kernels))}
+                continue
+            lr, hr = self.sampler.sample(idx)
             if self.metadata[idx[0]] is not None:
                 md = torch.from_numpy(np.stack([self.metadata[i] for i in idx]))
             else:

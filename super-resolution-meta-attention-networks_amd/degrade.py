@@ -137,19 +137,39 @@ def _device_table(in_size, out_size, device):
 
 
 # ----------------------------------------------------------------------------- device pipeline
-def blur_quant(hr, kernel, want_float=False):
+def blur_quant(hr, kernel, want_float=False, want_u8=True):
     """(C, H, W) fp32 on the device, (l, l) kernel -> uint8 (C, H, W) = byte(255 * BatchBlur(hr)); want_float: also
-    the unquantised blur."""
+    the unquantised blur (want_u8 False: only that)."""
     if not hr.is_cuda:
         raise RuntimeError("degrade.blur_quant: the image must be on a HIP device (no CPU path)")
     C, H, W = hr.shape
     k = torch.as_tensor(kernel, dtype=torch.float32).to(hr.device).contiguous()
     l = k.shape[-1]
-    y = torch.empty((C, H, W), device=hr.device, dtype=torch.uint8)
+    y = torch.empty((C, H, W), device=hr.device, dtype=torch.uint8) if want_u8 else None
     yf = torch.empty((C, H, W), device=hr.device, dtype=torch.float32) if want_float else None
-    hip.check(hip.lib().sisr_blur_quant(hip.ptr(hr.contiguous()), hip.ptr(k), y.data_ptr(), hip.ptr(yf), C, H, W, l,
-                                        hip.stream()), "sisr_blur_quant")
+    hip.check(hip.lib().sisr_blur_quant(hip.ptr(hr.contiguous()), hip.ptr(k), y.data_ptr() if y is not None else None,
+                                        hip.ptr(yf), C, H, W, l, hip.stream()), "sisr_blur_quant")
     return (y, yf) if want_float else y
+
+
+def random_batch_noise(batch, high, rate_cln=1.0):
+    """Noise level per sample; consumes np.random exactly as gaussian_utils.random_batch_noise (:299-304)."""
+    noise_level = np.random.uniform(size=(batch, 1)) * high
+    noise_mask = np.random.uniform(size=(batch, 1))
+    noise_mask[noise_mask < rate_cln] = 0
+    noise_mask[noise_mask >= rate_cln] = 1
+    return noise_level * noise_mask
+
+
+def noise_quant(blur, sigma):
+    """(C, H, W) fp32 blurred image on the device -> uint8 byte(255 * clamp(N(0,1) * sigma + blur, 0, 1)).  The N(0,1) field
+    comes from numpy's global stream on the host, as in the reference (b_GaussianNoising, :306-312), and is uploaded."""
+    C, H, W = blur.shape
+    field = torch.FloatTensor(np.random.normal(loc=0.0, scale=1.0, size=(1, C, H, W))).to(blur.device)
+    y = torch.empty((C, H, W), device=blur.device, dtype=torch.uint8)
+    hip.check(hip.lib().sisr_noise_quant(hip.ptr(blur), hip.ptr(field), float(sigma), y.data_ptr(), blur.numel(), hip.stream()),
+              "sisr_noise_quant")
+    return y
 
 
 def pil_bicubic_downsample(u8, scale, to_float=True):
@@ -179,13 +199,15 @@ def center_crop_box(height, width, scale):
 
 
 class OnlineDegrader:
-    """SRMDPreprocessing(pca, random=True, noise=False) + ToPILImage + downsample for one image at a time, as
-    SuperResImages.__getitem__ applies it (data_handler.py:446-456); returns device tensors."""
+    """SRMDPreprocessing(pca, random=True[, noise]) + ToPILImage + downsample for one image at a time, as
+    SuperResImages.__getitem__ applies it (data_handler.py:446-456); returns device tensors.  With `noise` (ref
+    gaussian_utils.py:371-424; the reference's own default for SRMDPreprocessing, off in the dataset's default set-up):
+    a noise level per image (random_batch_noise: uniform * noise_high, zero with probability rate_cln), Gaussian noise of
+    that level on the BLURRED full-size image, clamped to [0, 1], and 10 * level appended to the kernel code."""
 
     def __init__(self, scale=4, pca=None, kernel=21, sig_min=0.2, sig_max=4.0, rate_iso=1.0, scaling=3, noise=False,
-                 random=True, sig=2.6, para_input=10, **unused):
-        if noise:
-            raise NotImplementedError("noise injection in the online degrader is not built (the reference default is off)")
+                 random=True, sig=2.6, para_input=10, rate_cln=0.2, noise_high=0.08, **unused):
+        self.noise, self.rate_cln, self.noise_high = bool(noise), rate_cln, noise_high
         self.scale, self.l, self.random, self.sig = int(scale), int(kernel), bool(random), 2.6 if sig is None else sig
         self.sig_min, self.sig_max, self.rate_iso, self.scaling = sig_min, sig_max, rate_iso, scaling
         self.pca = pca if pca is not None else pca_matrix()
@@ -204,7 +226,13 @@ class OnlineDegrader:
         kernel (l, l) float32 CPU tensor, (top, left, rh, rw) the HR centre crop that matches lr)."""
         kernel = self.draw_kernel()
         code = encode_kernel(kernel, self.pca)
-        u8 = blur_quant(hr, kernel)
+        if self.noise:
+            level = torch.FloatTensor(random_batch_noise(1, self.noise_high, self.rate_cln))  # (1, 1) float32, as the reference
+            _, blurred = blur_quant(hr, kernel, want_float=True, want_u8=False)
+            u8 = noise_quant(blurred, float(level[0, 0]))
+            code = torch.cat([code, (level * 10).view(-1)])
+        else:
+            u8 = blur_quant(hr, kernel)
         top, left, rh, rw = center_crop_box(hr.shape[1], hr.shape[2], self.scale)
         if (rh, rw) != (hr.shape[1], hr.shape[2]):
             u8 = u8[:, top:top + rh, left:left + rw].contiguous()

@@ -114,6 +114,7 @@ _SIGS.update({  # fp32 through the bf16 matrix cores: three-way operand split, s
 _SIGS.update({  # on-the-fly degradation (csrc/degrade.hip)
     "sisr_blur_quant": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "sisr_pil_resample": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sisr_noise_quant": (c_int, [P, P, c_float, P, c_long, P]),
 })
 _SIGS.update({  # around the non-local attention (csrc/nonlocal.hip)
     "sisr_nl_project_fwd": (c_int, [P] * 8 + [c_long, P]),

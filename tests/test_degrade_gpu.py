@@ -81,3 +81,62 @@ def test_dataset_with_online_degradations_yields_the_reference_batch_schema(monk
         np.testing.assert_array_equal(it["blur_kernels"], kernel.numpy())
         assert it["metadata_keys"] == ["blur_kernel"] * 10 and it["tag"] == it["hr_tag"] == ds.base_filenames[i]
         assert it["hr"].shape[1] == 4 * it["lr"].shape[1] and it["hr"].shape[2] == 4 * it["lr"].shape[2]
+
+
+def test_online_degrader_with_noise_reproduces_the_reference():
+    """ref: gaussian_utils.py:299-312, 371-424 (SRMDPreprocessing(noise=True, noise_high=0.08, rate_cln=0.2)): same seed and
+    image as the fixture -- noise levels (one access drew a clean image, two a noisy one), 11-value codes and LR images."""
+    z = np.load(os.path.join(GOLDEN, "d_degrade.npz"))
+    np.random.seed(int(z["seed"]))
+    pca = D.pca_matrix(batch=int(z["pca_batch"]))
+    deg = D.OnlineDegrader(scale=4, pca=pca, noise=True, noise_high=0.08, rate_cln=0.2)
+    from PIL import Image
+    hr = np.asarray(Image.open(os.path.join(GOLDEN, "set5", "hr", "woman.png")).convert("RGB"))
+    x = torch.from_numpy(hr.transpose(2, 0, 1).copy()).float().div(255).cuda()
+    np.random.seed(21)
+    tails = []
+    for i in range(3):
+        lr, code, kernel, box = deg(x)
+        assert code.shape == (11,)
+        np.testing.assert_allclose(code.numpy(), z[f"n_code{i}"], rtol=0, atol=1e-6)
+        tails.append(float(code[-1]))
+        want = z[f"n_lr{i}"].transpose(2, 0, 1).astype(int)
+        got = (lr.cpu() * 255).round().numpy().astype(int)
+        d = np.abs(got - want)
+        assert got.shape == want.shape and d.max() <= 1 and (d > 0).mean() < 3e-3, (i, d.max(), (d > 0).mean())
+    assert min(tails) == 0.0 and max(tails) > 0.0  # both branches of the noise mask are on record
+
+
+def test_device_tile_loader_with_online_degradations_equals_the_dataloader_path(monkeypatch):
+    """`device_tiles` + `online_degradations`: HR images resident on the device, every batch degraded and cut there.  Under
+    the same seeds (torch: shuffle; numpy: kernels; random: flips / crops) the batches equal those of the reference-shaped
+    path, DataLoader(shuffle=True, num_workers=0) over SuperResImages.__getitem__ (ref: data_handler.py:446-456, :500-525)."""
+    import random
+    from torch.utils.data import DataLoader
+    real = D.pca_matrix
+    monkeypatch.setattr(D, "pca_matrix", lambda batch=2000, k=10: real(batch=2000, k=k))
+    hr_dir = os.path.join(GOLDEN, "set5", "hr")
+
+    def dataset():
+        np.random.seed(5)
+        return sisr_amd.data.SuperResImages(hr_dir=hr_dir, online_degradations=True, split="all", scale=4, random_crop=24,
+                                            random_augments=True)
+
+    def seed():
+        torch.manual_seed(3)
+        np.random.seed(6)
+        random.seed(7)
+
+    host_loader = DataLoader(dataset=dataset(), batch_size=2, shuffle=True, num_workers=0)
+    dev_loader = sisr_amd.data.DeviceTileLoader([dataset()], 2, torch.device("cuda:0"))
+    seed()
+    host = list(host_loader)
+    seed()
+    dev = list(dev_loader)
+    assert len(host) == len(dev) == 3
+    for a, b in zip(host, dev):
+        assert list(a["tag"]) == list(b["tag"]) and list(a["hr_tag"]) == list(b["hr_tag"])
+        assert torch.equal(a["lr"], b["lr"].cpu()) and torch.equal(a["hr"], b["hr"].cpu())
+        assert torch.equal(a["metadata"], b["metadata"]) and a["metadata"].dtype == b["metadata"].dtype
+        assert torch.equal(a["blur_kernels"], b["blur_kernels"])
+        assert [tuple(k) for k in a["metadata_keys"]] == [tuple(k) for k in b["metadata_keys"]]

@@ -44,4 +44,17 @@ if __name__ == "__main__":
         print(name, "lr", np.asarray(lr).shape, "code", code.numpy()[0][:3])
     np.random.seed(11)
     blob["aniso"] = G.random_batch_kernel(batch=3, rate_iso=0.0, tensor=False)
+    # noise on (ref gaussian_utils.py:371-424 defaults rate_cln = 0.2, noise_high = 0.08): second seed, 'woman' twice so that
+    # both a noisy and (with luck of the draw) a clean access are on record; stored: code (11 values), LR image
+    np.random.seed(21)
+    degn = G.SRMDPreprocessing(pca, random=True, kernel=21, rate_iso=1.0, sig_min=0.2, sig_max=4.0, noise=True, cuda=False,
+                               noise_high=0.08, rate_cln=0.2)
+    hr = np.asarray(Image.open(os.path.join(MF.SET5, "hr", "woman.png")).convert("RGB"))
+    x = torch.from_numpy(hr.transpose(2, 0, 1).copy()).float().div(255)
+    for i in range(3):
+        blurred, code, kernel = degn(x)
+        _, lr = downsample(G.to_pil_image(blurred.squeeze(0).cpu()), scale=4, jm=False)
+        blob[f"n_code{i}"] = code.numpy()[0]
+        blob[f"n_lr{i}"] = np.asarray(lr)
+        print("noise", i, "code tail", code.numpy()[0][-1])
     np.savez_compressed(os.path.join(MF.OUT, "d_degrade.npz"), **blob)
