@@ -1737,21 +1737,30 @@ class _SftmdHead(Function):
     def forward(ctx, x, w1, b1, w2, b2, w3, b3):
         _fp32_only("SFTMD")
         B, C, H, W = x.shape
-        if C != 3 or tuple(w1.shape) != (64, 3, 3, 3) or tuple(w2.shape) != (64, 64, 3, 3) or tuple(w3.shape) != (64, 64, 3, 3):
-            raise NotImplementedError("SFTMD head: RGB -> 64 -> 64 -> 64")
+        if (C > 64 or tuple(w1.shape) != (64, C, 3, 3) or tuple(w2.shape) != (64, 64, 3, 3) or
+                tuple(w3.shape) != (64, 64, 3, 3)):
+            raise NotImplementedError("SFTMD head: (RGB [+ metadata maps, at most 64 channels]) -> 64 -> 64 -> 64")
         dev, npix = x.device, B * H * W
         x = x.contiguous()
         v64 = hip.view_plain(H, W, 64)
         y1 = _empty_cl(B, 64, H, W, dev)
-        hip.check(hip.lib().sisr_conv3x3_cin3(hip.ptr(x), hip.ptr(w1.contiguous()), 27, 9, 0, hip.ptr(b1), hip.ptr(y1), v64, B,
-                                              H, W, 64, hip.stream()), "sisr_conv3x3_cin3")
-        _map64(y1, 64, None, 0, y1, 64, npix, 2)
+        if C == 3:
+            hip.check(hip.lib().sisr_conv3x3_cin3(hip.ptr(x), hip.ptr(w1.contiguous()), 27, 9, 0, hip.ptr(b1), hip.ptr(y1), v64,
+                                                  B, H, W, 64, hip.stream()), "sisr_conv3x3_cin3")
+            _map64(y1, 64, None, 0, y1, 64, npix, 2)
+        else:
+            # concat_strategy (ref: SFTMD_variants/handlers.py:12-14, attention_manipulators/__init__.py:97-98): the metadata
+            # maps ride in the input, conv1 is (3 + M) -> 64.  The NCHW input is laid out once as a zero-padded channels-last
+            # 64-channel map and conv1 runs on the MFMA kernel with zero-padded weights (exact zeros: same sums)
+            x = nchw_to_nhwc_pad(x.detach(), 64)
+            conv_c64(x, v64, pack_weight(_pad_oihw(w1, 64, 64), "fwd"), b1, (1, 64), y1, v64, B, H, W, 64, 64, relu=LEAKY)
         pf2, pd2 = pack_pair(w2.contiguous())
         pf3, pd3 = pack_pair(w3.contiguous())
         y2 = _empty_cl(B, 64, H, W, dev)
         conv_c64(y1, v64, pf2, b2, (1, 64), y2, v64, B, H, W, 64, 64, relu=LEAKY)
         y3 = _empty_cl(B, 64, H, W, dev)
         conv_c64(y2, v64, pf3, b3, (1, 64), y3, v64, B, H, W, 64, 64)
+        ctx.rgb = C == 3
         ctx.save_for_backward(x, y1, y2, w1, w2, w3)
         ctx.packs = (pd2, pd3)
         return y3
@@ -1776,11 +1785,17 @@ class _SftmdHead(Function):
             wgrad_c64(y1, v64, d2, v64, dw2, db2, B, H, W, 64, 64, owner=w2)
             d1 = _empty_cl(B, 64, H, W, dev)
             conv_c64(d2, v64, pd2, None, (1, 64), d1, v64, B, H, W, 64, 64, mask=y1, relu=LEAKY_MASK)
-            dw1, db1 = torch.empty_like(w1), torch.empty(64, device=dev)
-            nbytes = L.sisr_corr3x3_c3_workspace_bytes(B, H, W, 64)
-            ws = hip.workspace(dev, nbytes)
-            hip.check(L.sisr_corr3x3_c3(hip.ptr(x), hip.ptr(d1), v64, 1.0, hip.ptr(dw1), 27, 9, 0, 0, hip.ptr(db1), hip.ptr(ws),
-                                        nbytes, B, H, W, 64, hip.stream()), "sisr_corr3x3_c3(head)")
+            db1 = torch.empty(64, device=dev)
+            if ctx.rgb:
+                dw1 = torch.empty_like(w1)
+                nbytes = L.sisr_corr3x3_c3_workspace_bytes(B, H, W, 64)
+                ws = hip.workspace(dev, nbytes)
+                hip.check(L.sisr_corr3x3_c3(hip.ptr(x), hip.ptr(d1), v64, 1.0, hip.ptr(dw1), 27, 9, 0, 0, hip.ptr(db1),
+                                            hip.ptr(ws), nbytes, B, H, W, 64, hip.stream()), "sisr_corr3x3_c3(head)")
+            else:  # x is the padded 64-channel input map: full 64 x 64 weight gradient, cropped to the (3 + M) real inputs
+                dw1p = torch.empty((64, 64, 3, 3), device=dev)
+                wgrad_c64(x, v64, d1, v64, dw1p, db1, B, H, W, 64, 64)
+                dw1 = _crop_oihw(dw1p, tuple(w1.shape))
             return None, dw1, db1, dw2, db2, dw3, db3
         finally:
             IN_BACKWARD = False

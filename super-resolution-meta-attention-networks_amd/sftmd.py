@@ -105,9 +105,9 @@ class SFTMD(nn.Module):
     def __init__(self, in_nc=3, out_nc=3, num_features=64, num_blocks=16, scale=4, input_para=1, split='22',
                  SFT_type='standard', mask_para=False, repeats=None, q_injection=False, q_layers=2, **kwargs):
         super().__init__()
-        if num_features != 64 or in_nc != 3 or out_nc != 3:
-            raise NotImplementedError("SFTMD on the gfx950 kernels: 64 features, RGB in / out (the reference's configuration; "
-                                      "concat_strategy, which widens the input, is not built)")
+        if num_features != 64 or not 3 <= in_nc <= 64 or out_nc != 3:
+            raise NotImplementedError("SFTMD on the gfx950 kernels: 64 features, RGB out, RGB in (or, with the handler's "
+                                      "concat_strategy, RGB + metadata maps: at most 64 input channels)")
         if input_para > 64:
             raise NotImplementedError("SFTMD: at most 64 metadata channels")
         uses_maps = SFT_type in ('concat', 'weak') or (SFT_type == 'standard' and not mask_para)
@@ -162,10 +162,13 @@ class SFTMDHandler(QModel):
     def __init__(self, device, eval_mode=False, lr=1e-4, scheduler=None, concat_strategy=False, scheduler_params=None,
                  perceptual=None, q_injection=False, da_injection=False, in_nc=3, optimizer_params=None, **kwargs):
         super().__init__(device=device, eval_mode=eval_mode, **kwargs)
-        if concat_strategy or da_injection:
-            raise NotImplementedError("SFTMD: concat_strategy / da_injection are not built (reference defaults: off)")
+        if concat_strategy:  # ref :12-14: the metadata maps are concatenated to the RGB input (QModel.channel_concat_logic)
+            self.channel_concat = True
+            in_nc = self.num_metadata + in_nc
+        # ref :16-17: da_injection is handed to the network, whose constructor swallows it (architectures.py:108-110 **kwargs):
+        # its only effect is the metadata FORMAT below
         self.net = SFTMD(input_para=self.num_metadata, q_injection=q_injection, in_nc=in_nc, **kwargs)
-        self.vector_metadata = bool(q_injection)  # ref: handlers.py:19-22
+        self.vector_metadata = bool(q_injection or da_injection)  # ref: handlers.py:19-22
         self.colorspace = 'augmented_rgb'
         self.im_input = 'unmodified'
         self.activate_device()

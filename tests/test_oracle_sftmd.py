@@ -89,13 +89,14 @@ VARIANTS = {  # tools/make_fixtures_sftmd.py VARIANTS: SFTMD kwargs, metadata as
     "none_q": (dict(SFT_type="none", q_injection=True, q_layers=2, input_para=10), True),
     "maskpara_q3": (dict(mask_para=True, q_injection=True, q_layers=3, input_para=10), True),
     "repeats3": (dict(repeats=3, input_para=10), False),
+    "concat_input": (dict(input_para=10, in_nc=13), False),  # concat_strategy: maps also concatenated to the RGB input
 }
 
 
 def variant_net(name):
     kw, vector = VARIANTS[name]
     torch.manual_seed(8)
-    return sisr_amd.sftmd.SFTMD(in_nc=3, num_features=64, num_blocks=2, scale=2, **kw), kw, vector
+    return sisr_amd.sftmd.SFTMD(num_features=64, num_blocks=2, scale=2, **{"in_nc": 3, **kw}), kw, vector
 
 
 def variant_inputs(a, name, vector):
@@ -112,7 +113,7 @@ def test_f4_non_default_options_oracle_and_init(name):
     assert digest(net.state_dict()) == str(a[f"{name}/sd_sha256"]), "seed-8 init differs from the reference's"
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
     x, md = variant_inputs(a, name, vector)
-    cfg = {k: v for k, v in kw.items() if k != "input_para"}
+    cfg = {k: v for k, v in kw.items() if k not in ("input_para", "in_nc")}
     cfg["sft_type"] = cfg.pop("SFT_type", "standard")
     out = O.sftmd(sd, x, md, num_blocks=2, scale=2, **cfg)
     np.testing.assert_allclose(out.detach().numpy(), a[f"{name}/out"], rtol=1e-5, atol=1e-6)

@@ -263,3 +263,29 @@ def test_f3_run_train_trajectory_matches_reference():
         assert abs(float(out.mean()) - step["out_mean"]) < 5e-5 and abs(h.get_learning_rate() - step["lr_after"]) < 1e-12
     psum = float(sum(v.double().sum() for v in h.net.state_dict().values()))
     assert abs(psum - ref["final_param_sum"]) < 5e-2
+
+
+def test_handler_concat_strategy_and_da_injection():
+    """ref: SFTMD_variants/handlers.py:7-22.  concat_strategy: the handler concatenates the metadata maps to the RGB batch
+    (QModel.channel_concat_logic) and conv1 takes 3 + M channels; da_injection: the network ignores the flag (its constructor
+    swallows it), the handler switches the metadata to per-sample vectors."""
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.rand(2, 3, 16, 20, generator=g), torch.rand(2, 3, 32, 40, generator=g)
+    md = torch.rand(2, 10, generator=g, dtype=torch.float64) * 0.4
+    keys = [("blur_kernel",) * 2] * 10
+    torch.manual_seed(8)
+    h = sisr_amd.available_models["sftmd"](device=0, model_save_dir="/tmp", eval_mode=False, scale=2, lr=1e-3,
+                                           metadata=["blur_kernel"], num_blocks=2, concat_strategy=True)
+    assert h.channel_concat and tuple(h.net.conv1.weight.shape) == (64, 13, 3, 3) and not h.vector_metadata
+    l0 = float(h.run_train(x, y, metadata=md, metadata_keys=keys)[0])
+    for _ in range(8):
+        l1 = float(h.run_train(x, y, metadata=md, metadata_keys=keys)[0])
+    assert np.isfinite(l1) and l1 < l0
+    out, _, _ = h.run_eval(x, metadata=md, metadata_keys=keys)
+    assert tuple(out.shape) == (2, 3, 32, 40)
+    torch.manual_seed(8)
+    h = sisr_amd.available_models["sftmd"](device=0, model_save_dir="/tmp", eval_mode=False, scale=2, lr=1e-3,
+                                           metadata=["blur_kernel"], num_blocks=2, da_injection=True, SFT_type="none")
+    assert h.vector_metadata and not h.channel_concat
+    ch = h.generate_channels(x, md, keys)
+    assert tuple(ch.shape) == (2, 10, 1, 1)

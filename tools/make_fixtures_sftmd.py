@@ -105,6 +105,8 @@ VARIANTS = {  # name: (SFTMD kwargs, metadata is per-sample vectors (q_injection
     "none_q": (dict(SFT_type="none", q_injection=True, q_layers=2, input_para=10), True),
     "maskpara_q3": (dict(mask_para=True, q_injection=True, q_layers=3, input_para=10), True),
     "repeats3": (dict(repeats=3, input_para=10), False),
+    # concat_strategy (handlers.py:12-14): the maps are ALSO concatenated to the RGB input, conv1 is (3 + 10) -> 64
+    "concat_input": (dict(input_para=10, in_nc=13), False),
 }
 
 
@@ -112,12 +114,14 @@ def make_f4():
     blob = {}
     for name, (kw, vector) in VARIANTS.items():
         torch.manual_seed(8)
-        net = SFTMD(in_nc=3, num_features=64, num_blocks=2, scale=2, **kw)
+        net = SFTMD(num_features=64, num_blocks=2, scale=2, **{"in_nc": 3, **kw})
         M = kw["input_para"]
         x = rnd(2, 3, 9, 13, seed=91, scale=0.3, grad=False) + 0.5
         md = rnd(2, M, 1, 1, seed=92, scale=0.3, grad=False) + (1.0 if name == "weak1" else 0.0)
         if not vector:
             md = md.expand(2, M, 9, 13).contiguous()
+        if kw.get("in_nc", 3) != 3:
+            x = torch.cat((x, md), 1)  # QModel.channel_concat_logic (attention_manipulators/__init__.py:97-98)
         out = net(x, md)
         cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(93))
         out.backward(cot)
