@@ -213,6 +213,241 @@ struct WgradBatch {
 };
 __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_batch_kernel(WgradBatch bt) { wgrad3x3_c64_body(bt.job[blockIdx.z]); }
 
+// ------------------------------------------------------------------ fp32, one persistent workgroup per CU (round 3)
+// The kernel above splits a tile's OUTPUT over four workgroups (each re-reads its half of x and dY: 1.45x the algorithmic
+// traffic) and its pixels over the four waves (cross-wave reduction at the end), and it does not overlap a tile's loads with
+// anything of its own: it relies on the second resident workgroup, whose K phase serialises with it on the MFMA pipe and
+// leaves ~0.4 us holes at every hand-over (per-CU timelines of the conv kernel, tools/conv_timeline.py).  This form -- the
+// geometry of the bf16 kernel below, in exact fp32 -- gives a workgroup the whole 64 ci x 64 co of a chunk pair:
+//   wave w = quadrant (ci half w >> 1, co half w & 1), nine taps in nine persistent 32 x 32 accumulators (144 registers);
+//   all four waves walk the same staged tile (8 x 32 pixels: the 10 x 34 x 64 halo of x and 8 x 32 x 64 of dY, 152.6 KB of
+//   LDS), so every input byte is read from HBM once and no cross-wave reduction is needed;
+//   one workgroup per CU (512 registers per wave): the 38 float4 per thread of tile i + 1 are requested before the K loop
+//   of tile i and written to LDS after it, so a tile waits for memory only once per launch;
+//   the K loop is MFMA + ds_read_b32 only (both free beside each other, tools/mfma_fill.py); staging skips the padding
+//   mask on interior tiles, the affine rebuild when dY is taken as is, and the bias sums where none is wanted.
+// Slab layout, bias slabs and the second-stage reduction are the shared ones (unit = pair * 4 + quadrant).
+#define FW_X (WH_H * WH_W * 64)  // floats
+#define FW_Y (WT_H * WT_W * 64)
+
+static __device__ __forceinline__ void wgrad3x3_c64_full_body(const WgradParams& p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldx = lds;
+  float* ldy = lds + FW_X;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pair = blockIdx.y;
+  const int cq = pair % p.cout_chunks, cc = pair / p.cout_chunks;
+  const int cih = __builtin_amdgcn_readfirstlane(wave >> 1), coh = __builtin_amdgcn_readfirstlane(wave & 1);
+  const int i = lane & 31, kk = lane >> 5;
+  const int H = p.H, W = p.W;
+  const bool do_bias = p.bias_slabs && cc == 0;
+  const bool affine = p.dy_scale != nullptr || p.dy_shift != nullptr;  // scalar
+  const int Cout = p.cout_chunks * 64;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f32x16){0};
+  f32x4 bsa = {0.f, 0.f, 0.f, 0.f}, bsb = bsa;
+
+  const int tiles_per_img = p.tiles_w * p.tiles_h;
+  const int total = tiles_per_img * p.B;
+  // every XCD sweeps a contiguous eighth of the tiles (vertically adjacent tiles share two halo rows through one L2)
+  int t_begin = blockIdx.x, t_end = total, t_step = p.S;
+  if ((p.S & 7) == 0) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = (total + 7) >> 3;
+    t_begin = xcd * per + idx;
+    t_end = min(total, (xcd + 1) * per);
+    t_step = p.S >> 3;
+  }
+  struct Stage {
+    f32x4 x[WH_H][2];
+    f32x4 xe[2];
+    f32x4 y[WT_H][2];
+  };
+  Stage st;
+  const int c8 = tid & 7, pcol = tid >> 3;
+  const int eidx = tid % 160, er = eidx >> 4, eside = (eidx >> 3) & 1, ec8 = eidx & 7;
+  auto decode = [&](int tile, int& b, int& h0, int& w0) {
+    b = tile / tiles_per_img;
+    const int tr = tile - b * tiles_per_img;
+    const int th = tr / p.tiles_w;
+    h0 = th * WT_H;
+    w0 = (tr - th * p.tiles_w) * WT_W;
+  };
+  auto issue = [&](int tile) {
+    int b, h0, w0;
+    decode(tile, b, h0, w0);
+    const sisr_rsrc_t rx = sisr_rsrc(p.x + (long)b * p.xv.sB + p.xv.chunk(cc));
+    const sisr_rsrc_t ry = sisr_rsrc(p.dy + (long)b * p.yv.sB + p.yv.chunk(cq));
+    const unsigned vx = (unsigned)(min(w0 + pcol, W - 1) * (int)p.xv.sW + c8 * 8) * 4u;
+    const unsigned vy = (unsigned)(min(w0 + pcol, W - 1) * (int)p.yv.sW + c8 * 8) * 4u;
+#pragma unroll
+    for (int r = 0; r < WH_H; ++r) {
+      const unsigned so = (unsigned)(min(max(h0 - 1 + r, 0), H - 1) * (int)p.xv.sH) * 4u;  // scalar
+      st.x[r][0] = sisr_buf_load4(rx, vx, so);
+      st.x[r][1] = sisr_buf_load4(rx, vx + 16u, so);
+    }
+    {
+      const int gwe = min(max(eside ? w0 + WT_W : w0 - 1, 0), W - 1);
+      const unsigned ve = (unsigned)(min(max(h0 - 1 + er, 0), H - 1) * (int)p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8) * 4u;
+      st.xe[0] = sisr_buf_load4(rx, ve, 0u);
+      st.xe[1] = sisr_buf_load4(rx, ve + 16u, 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < WT_H; ++r) {
+      const unsigned so = (unsigned)(min(h0 + r, H - 1) * (int)p.yv.sH) * 4u;  // scalar
+      st.y[r][0] = sisr_buf_load4(ry, vy, so);
+      st.y[r][1] = sisr_buf_load4(ry, vy + 16u, so);
+    }
+  };
+  auto commit = [&](int tile) {
+    int b, h0, w0;
+    decode(tile, b, h0, w0);
+    const bool interior = h0 >= 1 && h0 + WT_H + 1 <= H && w0 >= 1 && w0 + WT_W + 1 <= W;  // scalar
+    const bool okc = w0 + pcol < W;
+    float* lx = ldx + (pcol + 1) * 64 + c8 * 8;
+    if (!interior) {
+#pragma unroll
+      for (int r = 0; r < WH_H; ++r) {
+        const int gh = h0 - 1 + r;
+        const bool ok = gh >= 0 && gh < H && okc;
+        st.x[r][0] = sisr_keep_if(st.x[r][0], ok);
+        st.x[r][1] = sisr_keep_if(st.x[r][1], ok);
+      }
+      const int gwe = eside ? w0 + WT_W : w0 - 1, ghe = h0 - 1 + er;
+      const bool oke = ghe >= 0 && ghe < H && gwe >= 0 && gwe < W;
+      st.xe[0] = sisr_keep_if(st.xe[0], oke);
+      st.xe[1] = sisr_keep_if(st.xe[1], oke);
+    }
+#pragma unroll
+    for (int r = 0; r < WH_H; ++r) {
+      *reinterpret_cast<f32x4*>(lx + r * (WH_W * 64)) = st.x[r][0];
+      *reinterpret_cast<f32x4*>(lx + r * (WH_W * 64) + 4) = st.x[r][1];
+    }
+    if (tid < 160) {
+      float* le = ldx + (er * WH_W + (eside ? WH_W - 1 : 0)) * 64 + ec8 * 8;
+      *reinterpret_cast<f32x4*>(le) = st.xe[0];
+      *reinterpret_cast<f32x4*>(le + 4) = st.xe[1];
+    }
+    if (affine) {
+      f32x4 s4a = {1.f, 1.f, 1.f, 1.f}, s4b = s4a, t4a = {0.f, 0.f, 0.f, 0.f}, t4b = t4a;
+      if (p.dy_scale) {
+        const float* sp = p.dy_scale + (long)b * Cout + cq * 64 + c8 * 8;
+        s4a = *reinterpret_cast<const f32x4*>(sp);
+        s4b = *reinterpret_cast<const f32x4*>(sp + 4);
+      }
+      if (p.dy_shift) {
+        const float* tp = p.dy_shift + (long)b * Cout + cq * 64 + c8 * 8;
+        t4a = *reinterpret_cast<const f32x4*>(tp);
+        t4b = *reinterpret_cast<const f32x4*>(tp + 4);
+      }
+#pragma unroll
+      for (int r = 0; r < WT_H; ++r) {
+        st.y[r][0] = st.y[r][0] * s4a + t4a;
+        st.y[r][1] = st.y[r][1] * s4b + t4b;
+      }
+    }
+    if (!interior) {
+#pragma unroll
+      for (int r = 0; r < WT_H; ++r) {
+        const bool ok = okc && (h0 + r < H);
+        st.y[r][0] = sisr_keep_if(st.y[r][0], ok);
+        st.y[r][1] = sisr_keep_if(st.y[r][1], ok);
+      }
+    }
+    float* ly = ldy + pcol * 64 + c8 * 8;
+#pragma unroll
+    for (int r = 0; r < WT_H; ++r) {
+      *reinterpret_cast<f32x4*>(ly + r * (WT_W * 64)) = st.y[r][0];
+      *reinterpret_cast<f32x4*>(ly + r * (WT_W * 64) + 4) = st.y[r][1];
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int r = 0; r < WT_H; ++r) {
+        bsa += st.y[r][0];
+        bsb += st.y[r][1];
+      }
+    }
+  };
+
+  if (t_begin < t_end) {
+    issue(t_begin);
+    commit(t_begin);
+  }
+  __syncthreads();
+  for (int tile = t_begin; tile < t_end; tile += t_step) {
+    const bool has_next = tile + t_step < t_end;  // uniform
+    if (has_next) issue(tile + t_step);
+    // ---- K loop: 8 rows x 16 pixel pairs x 9 taps; K index (lane >> 5) = pixel parity.  One wave per SIMD: nobody else
+    // covers an LDS round trip, so the ten operands of pair u + 1 (or of the next row's first pair) are requested before
+    // the nine MFMAs of pair u are issued.
+    {
+      const float* xa = ldx + kk * 64 + cih * 32 + i;  // tap (0,0) of pair 0, row 0
+      const float* yb = ldy + kk * 64 + coh * 32 + i;
+      float bv = yb[0], av[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) av[t] = xa[((t / 3) * WH_W + (t % 3)) * 64];
+#pragma unroll 1
+      for (int r = 0; r < WT_H; ++r) {
+        const int rn = r + 1 < WT_H ? 1 : 0;  // scalar: the last row re-reads itself (the values are not used)
+        const float* xn = xa + rn * (WH_W * 64);
+        const float* yn = yb + rn * (WT_W * 64);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          float bn, an[9];
+          if (u < 15) {
+            bn = yb[(u + 1) * 2 * 64];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) an[t] = xa[((t / 3) * WH_W + (t % 3) + 2 * (u + 1)) * 64];
+          } else {
+            bn = yn[0];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) an[t] = xn[((t / 3) * WH_W + (t % 3)) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          bv = bn;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) av[t] = an[t];
+        }
+        xa = xn;
+        yb = yn;
+      }
+    }
+    __syncthreads();  // every wave is done with this tile's LDS image
+    if (has_next) {
+      commit(tile + t_step);
+      __syncthreads();
+    }
+  }
+
+  {
+    float* out = p.slabs + ((long)blockIdx.x * ((long)gridDim.y * 4) + pair * 4 + cih * 2 + coh) * SLAB;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64 + lane] = acc[t][r];
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = lds;
+    *reinterpret_cast<f32x4*>(red + tid * 8) = bsa;
+    *reinterpret_cast<f32x4*>(red + tid * 8 + 4) = bsb;
+    __syncthreads();
+    if (tid < 64) {  // channel tid = c8 * 8 + e lives in the threads with (tid & 7) == c8
+      const int cc8 = tid >> 3, e = tid & 7;
+      float s = 0.f;
+      for (int k = 0; k < 32; ++k) s += red[(k * 8 + cc8) * 8 + e];
+      p.bias_slabs[((long)blockIdx.x * p.cout_chunks + cq) * 64 + tid] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad3x3_c64_full_kernel(WgradParams p) { wgrad3x3_c64_full_body(p); }
+__global__ __launch_bounds__(256, 1) void wgrad3x3_c64_full_batch_kernel(WgradBatch bt) { wgrad3x3_c64_full_body(bt.job[blockIdx.z]); }
+
 // ------------------------------------------------------------------ bf16 matrix-core weight gradient
 // Operands rounded to bf16 (RNE) as they are staged into LDS, products exact, fp32 accumulation; the bias
 // gradient is summed from the unrounded fp32 dY'.  A workgroup owns all 64 ci x 64 co of one (cin chunk, cout
@@ -756,12 +991,25 @@ static int wgrad_split(int B, int H, int W, int units) {
   return (int)S;
 }
 
+// K-split of the dense form (wgrad3x3_c64_full_kernel): one workgroup per CU over all chunk pairs
+static int wgrad_full_split(int B, int H, int W, int pairs) {
+  const long tiles = (long)B * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
+  long S = 256 / pairs;
+  if (S < 1) S = 1;
+  if (S > tiles) S = tiles;
+  return (int)S;
+}
+
 extern "C" size_t sisr_wgrad3x3_c64_workspace_bytes(int B, int H, int W, int cin, int cout) {
   if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || (cin & 63) || (cout & 63)) return 0;
   const int units = (cin / 64) * (cout / 64) * 4;
   const int S = wgrad_split(B, H, W, units);
-  // bias slabs sized for the finest split a masked launch can take (one active unit: S = 512)
-  return ((size_t)(S * units > 512 ? S * units : 512) * SLAB + (size_t)512 * cout) * sizeof(float);
+  const int Sf = wgrad_full_split(B, H, W, units / 4);
+  // slabs for the larger of the two forms (dense: one workgroup per CU, four quadrant slabs each; masked: the K-slices go
+  // to the active units, at most 512 workgroups); bias slabs sized for the finest split (512)
+  size_t slabs = (size_t)(S * units > 512 ? S * units : 512);
+  if ((size_t)Sf * units > slabs) slabs = (size_t)Sf * units;
+  return (slabs * SLAB + (size_t)512 * cout) * sizeof(float);
 }
 
 extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
@@ -818,12 +1066,19 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   }
   p.mapped = active_units != 0;
   r.mapped = active_units != 0;
-  p.S = wgrad_split(B, H, W, units);
+  const bool dense = !active_units && !getenv("SISR_WGRAD_QUADRANT_KERNEL");  // (the env switch: A/B of the two forms)
+  p.S = dense ? wgrad_full_split(B, H, W, units / 4) : wgrad_split(B, H, W, units);
   p.slabs = workspace;
   p.bias_slabs = dbias ? workspace + (size_t)p.S * units * SLAB : nullptr;
-  const size_t lds_bytes = (size_t)(LDS_X + LDS_Y) * sizeof(float);
-  SISR_ALLOW_LDS(wgrad3x3_c64_kernel, lds_bytes);
-  hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(p.S, units), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  if (dense) {  // one persistent workgroup per CU owning all four quadrants of its chunk pair
+    const size_t lds_full = (size_t)(FW_X + FW_Y) * sizeof(float);
+    SISR_ALLOW_LDS(wgrad3x3_c64_full_kernel, lds_full);
+    hipLaunchKernelGGL(wgrad3x3_c64_full_kernel, dim3(p.S, units / 4), dim3(256), lds_full, (hipStream_t)stream, p);
+  } else {
+    const size_t lds_bytes = (size_t)(LDS_X + LDS_Y) * sizeof(float);
+    SISR_ALLOW_LDS(wgrad3x3_c64_kernel, lds_bytes);
+    hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(p.S, units), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  }
   int rc = sisr_check_launch();
   if (rc) return rc;
   r.slabs = p.slabs;
@@ -860,7 +1115,7 @@ struct sisr_wgrad_job_host {
 };
 static int wgrad_batch_split(int njobs, int B, int H, int W) {
   const long tiles = (long)B * ((H + WT_H - 1) / WT_H) * ((W + WT_W - 1) / WT_W);
-  long S = 512 / (4 * njobs);  // 4 units per job; two workgroups per CU resident across the whole grid
+  long S = 256 / njobs;  // one persistent workgroup per CU across the whole grid (wgrad3x3_c64_full_batch_kernel)
   if (S < 1) S = 1;
   if (S > tiles) S = tiles;
   return (int)S;
@@ -928,9 +1183,9 @@ extern "C" int sisr_wgrad3x3_c64_batch(const void* jobs_host, int njobs, const i
     r.bias_q = 64;
     r.mapped = 0;
   }
-  const size_t lds_bytes = (size_t)(LDS_X + LDS_Y) * sizeof(float);
-  SISR_ALLOW_LDS(wgrad3x3_c64_batch_kernel, lds_bytes);
-  hipLaunchKernelGGL(wgrad3x3_c64_batch_kernel, dim3(S, 4, njobs), dim3(256), lds_bytes, (hipStream_t)stream, wb);
+  const size_t lds_bytes = (size_t)(FW_X + FW_Y) * sizeof(float);
+  SISR_ALLOW_LDS(wgrad3x3_c64_full_batch_kernel, lds_bytes);
+  hipLaunchKernelGGL(wgrad3x3_c64_full_batch_kernel, dim3(S, 1, njobs), dim3(256), lds_bytes, (hipStream_t)stream, wb);
   int rc = sisr_check_launch();
   if (rc) return rc;
   const long total = 4L * SLAB + 64;  // bias rows past the weights; jobs without a bias skip them inside (db == null)

@@ -102,7 +102,8 @@ def test_pure_host_queries():
     L = sisr_amd.hip.lib()
     assert L.sisr_conv3x3_c64_gap_parts(128, 128) == 32 * 4 * 2
     assert L.sisr_conv3x3_c64_gap_parts(57, 86) == 15 * 3 * 2
-    assert L.sisr_wgrad3x3_c64_workspace_bytes(4, 128, 128, 64, 64) == (128 * 4 * 9216 + 512 * 64) * 4  # 512 K-slices x units; bias slabs for the finest masked split
+    # dense form: 256 K-slices (one workgroup per CU) x 4 quadrant slabs; bias slabs for the finest masked split (512)
+    assert L.sisr_wgrad3x3_c64_workspace_bytes(4, 128, 128, 64, 64) == (256 * 4 * 9216 + 512 * 64) * 4
     assert L.sisr_wgrad3x3_c64_workspace_bytes(4, 128, 128, 60, 64) == 0
     assert L.sisr_l1_loss_workspace_bytes() == 2048
     assert L.sisr_gate_dg_parts(128 * 128) == 32
