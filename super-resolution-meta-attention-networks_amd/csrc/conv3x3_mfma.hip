@@ -760,6 +760,254 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
   }
 }
 
+// ------------------------------------------------------------------ persistent form of the fp32 kernel (round 3)
+// conv3x3_c64_v4_kernel leaves the overlap of one tile's staging / epilogue with another tile's K loop to whatever
+// workgroups happen to share the CU: per-CU timelines (tools/conv_timeline.py) show K phases running back to back at 97 % of
+// the MFMA rate with a 0.3 - 1.6 us hole at every hand-over (the waiting workgroup's last staging instructions only issue
+// once the older wave's MFMA stream stops), a ramp per launch and a ragged last round.  Here 512 workgroups (two per CU, 256
+// registers each) walk the tiles of a launch: the halo of tile i + 1 is REQUESTED before the K loop of tile i (18 float4 per
+// thread in registers, 36 with the GATE prologue's second map) and written to LDS after it, so a workgroup waits for memory
+// once per launch and its only non-MFMA time per tile is epilogue + LDS writes, which the other resident workgroup's K loop
+// covers.  Same tile geometry, LDS image, K loop, prologue / epilogue arithmetic and summation order as the per-tile kernel:
+// bit-identical results.  64 -> 64 maps only (one input chunk); grids too small to give every workgroup two tiles, gate
+// heads / tails, LeakyReLU and the sparse selections stay on the per-tile kernel.
+template <bool AFFINE, bool MASK, bool RES, bool GATE, bool DOT>
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_p4_kernel(ConvParams p, int total_tiles) {
+  constexpr int MT = 2, THv = 4, HHv = 6;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ph = __builtin_amdgcn_readfirstlane(wave >> 1), ch = __builtin_amdgcn_readfirstlane(wave & 1);
+  const int n = lane & 31, hh = lane >> 5;
+  const int H = p.H, W = p.W;
+  const int co = ch * 32 + n;
+  const float bv = p.bias ? p.bias[co * p.bias_n] : 0.f;
+
+  unsigned aoff[3][8];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      aoff[kw][j] = ((MT * ph) * HALO_W + n + kw) * 64 + (((2 * j + hh) ^ ((n + kw) & 15)) << 2);
+  const unsigned boff = hh * 256 + co * 4;
+  const sisr_rsrc_t rw = sisr_rsrc(p.w);
+
+  // tile walk: every XCD sweeps a contiguous eighth of the tiles (vertically adjacent tiles share halo rows through one L2)
+  const int G = gridDim.x;
+  int t_begin = blockIdx.x, t_end = total_tiles, t_step = G;
+  if ((G & 7) == 0) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per = (total_tiles + 7) >> 3;
+    t_begin = xcd * per + idx;
+    t_end = min(total_tiles, (xcd + 1) * per);
+    t_step = G >> 3;
+  }
+  auto decode = [&](int tile, int& b, int& h0, int& w0) {
+    const int tw = tile % p.tiles_w;
+    const int t2 = tile / p.tiles_w;
+    b = t2 / p.tiles_h;
+    h0 = (t2 - b * p.tiles_h) * THv;
+    w0 = tw * TW;
+  };
+  // staging thread map: (16-B piece c4 of a pixel, halo column pcol + {0, 16, 32}), rows 0..5
+  const int c4 = tid & 15, pcol = tid >> 4;
+  f32x4 v[HHv][3];
+  auto issue = [&](int tile) {
+    int b, h0, w0;
+    decode(tile, b, h0, w0);
+    const sisr_rsrc_t rx = sisr_rsrc(p.x + (long)b * p.xv.sB);
+#pragma unroll
+    for (int r = 0; r < HHv; ++r) {
+      const unsigned ro = (unsigned)(min(max(h0 - 1 + r, 0), H - 1) * (int)p.xv.sH) * 4u;  // scalar, bytes
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < 2 || pcol < 2) {
+          const unsigned go = (unsigned)(min(max(w0 - 1 + pcol + 16 * k, 0), W - 1) * (int)p.xv.sW + c4 * 4) * 4u;
+          v[r][k] = sisr_buf_load4(rx, go, ro);
+        }
+    }
+  };
+  auto commit = [&](int tile) {
+    int b, h0, w0;
+    decode(tile, b, h0, w0);
+    const bool interior = h0 >= 1 && h0 + THv + 1 <= H && w0 >= 1 && w0 + TW + 1 <= W;  // scalar
+    f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+    if (AFFINE || GATE) s4 = *reinterpret_cast<const f32x4*>(p.in_scale + (long)b * 64 + c4 * 4);
+    if (AFFINE && p.in_shift) t4 = *reinterpret_cast<const f32x4*>(p.in_shift + (long)b * 64 + c4 * 4);
+    const sisr_rsrc_t ro_ = sisr_rsrc(GATE ? p.gate_out + (long)b * p.xv.sB : p.y);
+    // GATE: the skip map is fetched here, not a tile ahead (two prefetched maps would not fit 256 registers beside the K
+    // loop's); its round trip is covered by the other resident workgroup's K loop
+    f32x4 u[GATE ? HHv : 1][3];
+    if (GATE) {
+      const sisr_rsrc_t ru = sisr_rsrc(p.gate_add + (long)b * p.xv.sB);
+#pragma unroll
+      for (int r = 0; r < HHv; ++r) {
+        const unsigned ro = (unsigned)(min(max(h0 - 1 + r, 0), H - 1) * (int)p.xv.sH) * 4u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < 2 || pcol < 2)
+            u[r][k] = sisr_buf_load4(ru, (unsigned)(min(max(w0 - 1 + pcol + 16 * k, 0), W - 1) * (int)p.xv.sW + c4 * 4) * 4u, ro);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < HHv; ++r) {
+      const int gh = h0 - 1 + r;
+      const bool rok = gh >= 0 && gh < H;                 // scalar
+      const bool rown = r >= 1 && r <= THv && gh < H;      // scalar: a row this tile owns
+      const unsigned ro = (unsigned)(min(max(gh, 0), H - 1) * (int)p.xv.sH) * 4u;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < 2 || pcol < 2) {
+          const int col = pcol + 16 * k, gw = w0 - 1 + col;
+          const bool cok = gw >= 0 && gw < W && col < HALO_W;
+          f32x4 t = v[r][k];
+          if (AFFINE) t = t * s4 + t4;
+          if (GATE) {
+            t = sisr_mul_add4(t, s4, u[r][k]);
+            if (rown && cok && col >= 1 && col <= TW)
+              SISR_Y_STORE4(t, ro_, (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c4 * 4) * 4u, ro);
+          }
+          if (!interior) t = sisr_keep_if(t, rok && cok);
+          *reinterpret_cast<f32x4*>(lds + r * (HALO_W * 64) + col * 64 + ((c4 ^ (col & 15)) << 2)) = t;
+        }
+    }
+  };
+
+  if (t_begin < t_end) {
+    issue(t_begin);
+    commit(t_begin);
+  }
+  __syncthreads();
+  const int Cout = 64;
+  for (int tile = t_begin; tile < t_end; tile += t_step) {
+    const bool has_next = tile + t_step < t_end;  // uniform
+    int b, h0, w0;
+    decode(tile, b, h0, w0);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = bv;
+    f32x4 bq[8];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) bq[s] = sisr_buf_load4(rw, boff * 4u, (unsigned)(s * 2048));
+    if (has_next) issue(tile + t_step);  // in flight across the K loop and the epilogue of this tile
+    {
+#define P4_LOAD_B(s) sisr_buf_load4(rw, boff * 4u, (unsigned)((s) * 2048))
+#define P4_LOAD_A(m, s) \
+  (*reinterpret_cast<const f32x4*>(lds + ((((s) >> 3) / 3 + (m)) * (HALO_W * 64)) + aoff[((s) >> 3) % 3][(s) & 7]))
+      f32x4 aq[4][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        aq[s][0] = P4_LOAD_A(0, s);
+        aq[s][1] = P4_LOAD_A(1, s);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 72; ++s) {
+        if (s + 6 < 72) bq[(s + 6) & 7] = P4_LOAD_B(s + 6);
+        if (s + 2 < 72) {
+          aq[(s + 2) & 3][0] = P4_LOAD_A(0, s + 2);
+          aq[(s + 2) & 3][1] = P4_LOAD_A(1, s + 2);
+        }
+        const f32x4 bb = bq[s & 7];
+        const f32x4 a0 = aq[s & 3][0];
+        const f32x4 a1 = aq[s & 3][1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bb[e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bb[e], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef P4_LOAD_A
+#undef P4_LOAD_B
+    }
+    __syncthreads();  // every wave is done with this tile's halo
+    // ---- epilogue (the per-tile kernel's, see there)
+    {
+      float os = p.alpha;
+      if (p.out_scale) os *= p.out_scale[(long)b * Cout + co];
+      const bool scaled = p.out_scale != nullptr || p.alpha != 1.0f;
+      const bool want_sum = p.gap != nullptr;
+      const unsigned loff_y = (unsigned)(co + 4 * hh * (int)p.yv.sW) * 4u;
+      const long tile_base = (long)b * p.yv.sB + (long)w0 * p.yv.sW;
+      const bool full = (h0 + THv <= H) && (w0 + TW <= W);
+      const unsigned swb = (unsigned)p.yv.sW * 4u;
+      const sisr_rsrc_t ry = sisr_rsrc(p.y + tile_base);
+      const sisr_rsrc_t rmk = sisr_rsrc(MASK ? p.mask + tile_base : p.y);
+      const sisr_rsrc_t rrs = sisr_rsrc(RES ? p.res + tile_base : p.y);
+      const sisr_rsrc_t rdt = sisr_rsrc(DOT ? p.dot + tile_base : p.y);
+      float grow[2] = {0.f, 0.f};
+      constexpr bool TWO_SETS = DOT && RES;
+      float mk[MT][16], rs[MT][16], dt[MT][16];
+      auto fetch = [&](int m, bool first_set, bool second_set) {
+        const int row = h0 + MT * ph + m;
+        const unsigned row_off = (unsigned)(min(row, H - 1) * (int)p.yv.sH) * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cr = (r & 3) + 8 * (r >> 2);
+          const unsigned vo = full ? loff_y : (unsigned)(co + (min(w0 + cr + 4 * hh, W - 1) - w0) * (int)p.yv.sW) * 4u;
+          const unsigned so = full ? row_off + (unsigned)cr * swb : row_off;
+          if (MASK && first_set) mk[m][r] = sisr_buf_load1(rmk, vo, so);
+          if (RES && first_set) rs[m][r] = sisr_buf_load1(rrs, vo, so);
+          if (DOT && (TWO_SETS ? second_set : first_set)) dt[m][r] = sisr_buf_load1(rdt, vo, so);
+        }
+      };
+#pragma unroll
+      for (int m = 0; m < MT; ++m) fetch(m, true, false);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        float gsum = 0.f;
+        const int row = h0 + MT * ph + m;
+        f32x16 acc = m ? acc1 : acc0;
+        const unsigned row_off = (unsigned)(row * (int)p.yv.sH) * 4u;
+        if (TWO_SETS) fetch(m, false, true);
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+        }
+        if (scaled) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] *= os;
+        }
+        if (MASK) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = mk[m][r] > 0.f ? acc[r] : 0.f;
+        }
+        if (RES) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] += rs[m][r];
+        }
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            SISR_Y_STORE1(acc[r], ry, loff_y, row_off + (unsigned)((r & 3) + 8 * (r >> 2)) * swb);
+          if (want_sum) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gsum = DOT ? __builtin_fmaf(acc[r], dt[m][r], gsum) : gsum + acc[r];
+          }
+        } else if (row < H) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int cr = (r & 3) + 8 * (r >> 2);
+            if (w0 + cr + 4 * hh < W) {
+              SISR_Y_STORE1(acc[r], ry, loff_y, row_off + (unsigned)cr * swb);
+              gsum = DOT ? __builtin_fmaf(acc[r], dt[m][r], gsum) : gsum + acc[r];
+            }
+          }
+        }
+        grow[m] = gsum + __shfl_xor(gsum, 32);
+      }
+      if (p.gap) {
+        const long parts = (long)p.tiles_w * ((H + 3) / 4) * 2;  // one partial per (2-row strip, 32 columns)
+        const int th = h0 / THv, tw = w0 / TW;
+        if (hh == 0) p.gap[(((long)b * parts) + (th * p.tiles_w + tw) * 2 + ph) * Cout + co] = grow[0] + grow[1];
+      }
+    }
+    if (has_next) {
+      commit(tile + t_step);
+      __syncthreads();
+    }
+  }
+}
+
 // ------------------------------------------------------------------ bf16 matrix-core kernel (fp32 in HBM)
 // Same tile / wave geometry, View addressing and epilogue as the fp32 kernels, but the contraction runs on
 // v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate): activations are rounded to bf16 (RNE, v_cvt_pk_bf16_f32)
@@ -1915,6 +2163,15 @@ extern "C" int sisr_pack_conv3x3_many(const void* jobs_device, int n_jobs, int t
 // (64 -> 64, 128 x 128 maps: 8 samples 85 vs 101 us, 16: 158 vs 170, 32: 296 vs 307): four resident workgroups per CU
 // instead of three and a finer last round.  SISR_CONV_TILE_ROWS=4 (read per call, no state kept) restores the old rule.
 #define SMALL_GRID_BLOCKS (sisr_small_grid_blocks())
+// the persistent form (conv3x3_c64_p4_kernel) is used from two tiles per workgroup on (select 7 forces it, 5 / 6 the
+// per-tile kernels; SISR_CONV_PERSISTENT=0 switches it off per call, for A/B measurements)
+static inline bool sisr_use_persistent(int variant, long nblk) {
+  if (variant == 7) return true;
+  if (variant != 4) return false;
+  const char* e = getenv("SISR_CONV_PERSISTENT");
+  if (e && e[0] == '0') return false;
+  return nblk >= 1024;
+}
 static inline long sisr_small_grid_blocks() {
   const char* e = getenv("SISR_CONV_TILE_ROWS");
   if (e && e[0] == '4') return 200;
@@ -1982,11 +2239,11 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   const int ksel = (select >= 8 && select <= 10) ? select - 7 : 0;
   const int variant = (select == 0 || ksel) ? 4 : select;
 #ifdef SISR_DIAG
-  if (variant != 4 && variant != 5 && variant != 6 && variant != 2 && variant != 13 &&
+  if (variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 2 && variant != 13 &&
       variant != 16)
     return SISR_ERR_ARG;
 #else
-  if (variant != 4 && variant != 5 && variant != 6 && variant != 2) return SISR_ERR_ARG;
+  if (variant != 4 && variant != 5 && variant != 6 && variant != 7 && variant != 2) return SISR_ERR_ARG;
 #endif
   if (ksel) {
     const bool shape_ok = ksel == 1 ? (cin == 64 && cout == 128) : (cin == 128 && cout == 64);
@@ -2072,8 +2329,17 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
       return SISR_ERR_UNSUPPORTED;
     if (memcmp(xview, yview, 6 * sizeof(int64_t)) != 0) return SISR_ERR_UNSUPPORTED;  // skip / dot share one layout
     hipStream_t st = (hipStream_t)stream;
-    const bool small = variant == 6 || (variant != 5 && nblk < SMALL_GRID_BLOCKS);
     const bool rs = res != nullptr;
+    if (!head && !tail && sisr_use_persistent(variant, nblk)) {
+      const dim3 gp((unsigned)(nblk < 512 ? nblk : 512));
+      const size_t lbp = HALO_H * HALO_W * 64 * sizeof(float);
+#define P4X(RS, GT, DT) hipLaunchKernelGGL((conv3x3_c64_p4_kernel<false, false, RS, GT, DT>), gp, dim3(256), lbp, st, p, (int)nblk)
+      if (gate) { if (rs) P4X(true, true, false); else P4X(false, true, false); }
+      else      { if (rs) P4X(true, false, true); else P4X(false, false, true); }
+#undef P4X
+      return sisr_check_launch();
+    }
+    const bool small = variant == 6 || (variant != 5 && nblk < SMALL_GRID_BLOCKS);
     dim3 g = grid;
     size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
     if (small) {
@@ -2098,7 +2364,7 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
 #undef V4H
     return sisr_check_launch();
   }
-  if (variant == 4 || variant == 5 || variant == 6) {
+  if (variant == 4 || variant == 5 || variant == 6 || variant == 7) {
     const bool aff = in_scale != nullptr, msk = mask != nullptr, rs = res != nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (ksel) {
@@ -2125,6 +2391,19 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
       if (ksel == 1) { if (small) V4K(false, 1, false, 1); else V4K(false, 2, false, 1); }
       else { if (small) V4K(false, 1, true, 2); else V4K(false, 2, true, 2); }
 #undef V4K
+      return sisr_check_launch();
+    }
+    if (!(in_shift && !in_scale) && !(aff && !msk) && !(msk && rs) && !leaky && !head && !tail && cin == 64 && cout == 64 &&
+        memcmp(xview, yview, 6 * sizeof(int64_t)) == 0 && p.xv.clo == 64 && p.xv.chi == 0 && sisr_use_persistent(variant, nblk)) {
+      // persistent form (plain 64 -> 64 maps): see conv3x3_c64_p4_kernel
+      const dim3 gp((unsigned)(nblk < 512 ? nblk : 512));
+      const size_t lbp = HALO_H * HALO_W * 64 * sizeof(float);
+#define P4K(AF, MK, RS) hipLaunchKernelGGL((conv3x3_c64_p4_kernel<AF, MK, RS, false, false>), gp, dim3(256), lbp, st, p, (int)nblk)
+      if (aff) P4K(true, true, false);
+      else if (msk) P4K(false, true, false);
+      else if (rs) P4K(false, false, true);
+      else P4K(false, false, false);
+#undef P4K
       return sisr_check_launch();
     }
     if (!(in_shift && !in_scale) && !(aff && !msk) && !(msk && rs)) {

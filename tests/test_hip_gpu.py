@@ -67,10 +67,12 @@ def test_conv64_fwd_bwd(B, H, W):
     close(bg.grad, b.grad, 2e-4, 2e-5, "db")
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 16, 16), (1, 13, 9), (1, 57, 86), (2, 4, 32), (1, 5, 33), (1, 128, 128)])
+@pytest.mark.parametrize("B,H,W", [(2, 16, 16), (1, 13, 9), (1, 57, 86), (2, 4, 32), (1, 5, 33), (1, 128, 128), (9, 128, 128)])
 def test_conv_tile_heights_are_bit_identical(B, H, W):
-    """The issue-lean conv picks 2-row tiles on small grids and 4-row tiles on large ones (variant 4); forcing
-    either (variants 6 / 5) must give the same bits for outputs and GAP partials, for every epilogue it serves."""
+    """The fp32 conv's kernel forms -- 4-row tiles (variant 5), 2-row tiles (6), and the persistent two-workgroups-per-CU form
+    that prefetches its next tile (7; the automatic choice from two tiles per workgroup on) -- must give the same bits for
+    outputs and GAP partials, for every epilogue they serve (the 9 x 128 x 128 case walks 2 - 3 tiles per persistent
+    workgroup, ragged last round included)."""
     if ops.PRECISION != "fp32":
         pytest.skip("tile-height selection is an argument of the fp32 kernel family only")
     hip = sisr_amd.hip
@@ -86,7 +88,7 @@ def test_conv_tile_heights_are_bit_identical(B, H, W):
     cases = [dict(bias=b, relu=True, gap=True), dict(res=res, alpha=0.3), dict(mask=mask),
              dict(mask=mask, in_scale=sc, in_shift=sh)]
     outs = {}
-    for variant in (5, 6):  # per-call kernel selection (the library keeps no state)
+    for variant in (5, 6, 7):  # per-call kernel selection (the library keeps no state)
         for i, kw in enumerate(cases):
             kw = dict(kw)
             y = torch.zeros(B, 64, H, W, device=DEV).contiguous(memory_format=cl)
@@ -95,10 +97,11 @@ def test_conv_tile_heights_are_bit_identical(B, H, W):
             outs[(variant, i)] = (y, gap)
     for i in range(len(cases)):
         y5, g5 = outs[(5, i)]
-        y6, g6 = outs[(6, i)]
-        assert torch.equal(y5, y6), f"case {i}: outputs differ between tile heights"
-        if g5 is not None:
-            assert torch.equal(g5, g6), f"case {i}: GAP partials differ between tile heights"
+        for other in (6, 7):
+            y6, g6 = outs[(other, i)]
+            assert torch.equal(y5, y6), f"case {i}: outputs differ between kernel forms 5 and {other}"
+            if g5 is not None:
+                assert torch.equal(g5, g6), f"case {i}: GAP partials differ between kernel forms 5 and {other}"
     want = F.relu(F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1))
     close(outs[(5, 0)][0], want, 2e-5, 2e-6, "4-row tile vs ATen")
 
