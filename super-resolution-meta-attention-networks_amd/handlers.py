@@ -395,8 +395,8 @@ class QModel(BaseModel):
     def train_step(self, x, y, metadata=None, extra_channels=None, metadata_keys=None, **kwargs):
         if extra_channels is None and metadata is None:
             raise RuntimeError('Metadata needs to be specified for this network to run properly.')
-        if extra_channels is None or self.channel_concat:  # (with channel_concat the input itself carries the maps: ref :97-98)
-            x, extra_channels = self.channel_concat_logic(x, extra_channels, metadata, metadata_keys)
+        if extra_channels is None:  # (callers that pass ready-made channels have also prepared the input: run_train above)
+            x, extra_channels = self.channel_concat_logic(x, None, metadata, metadata_keys)
         return super().train_step(x, y, extra_channels=extra_channels, **kwargs)
 
     def run_eval(self, x, y=None, request_loss=False, metadata=None, metadata_keys=None, extra_channels=None, *args,

@@ -1906,6 +1906,10 @@ def sftmd_forward(net, x, metadata):
     (B, M, H, W) maps -- or, with q_injection, the (B, M, 1, 1) vectors the reference's handler then supplies (:19-22)."""
     _fp32_only("SFTMD")
     B, _, H, W = x.shape
+    if metadata.device != x.device:
+        # concat_strategy: the handler concatenates the maps to the input on the host and hands the network the host copy
+        # (ref: attention_manipulators/__init__.py:94-98 moves them only when they are NOT concatenated)
+        metadata = metadata.to(x.device)
     if net.uses_maps:
         if metadata.dim() != 4 or metadata.shape[0] != B or metadata.shape[1] != net.para or tuple(metadata.shape[2:]) != (H, W):
             raise RuntimeError(f"SFTMD: metadata maps must be (B, {net.para}, H, W); got {tuple(metadata.shape)}")
