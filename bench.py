@@ -366,7 +366,7 @@ def main():
         # second line asked for by the round-1 review: the same step with the convs as bf16x3 splits
         sisr.ops.set_precision("bf16x3")
         try:
-            s3 = measure(sisr, workload, B, max(2, min(args.steps, 5)), min(args.warmup, 2), False, rank, world, local, dev)
+            s3 = measure(sisr, workload, B, max(2, min(args.steps, 5)), max(args.warmup, 3), False, rank, world, local, dev)
         finally:
             sisr.ops.set_precision("fp32")
         x3 = {"dtype": "f32 via bf16x3 split (six bf16 MFMA products per f32 product), f32 accumulate and storage",
