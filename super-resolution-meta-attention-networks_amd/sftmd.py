@@ -6,8 +6,9 @@ ref: Code/SISR/models/SFTMD_variants/architectures.py:25-176 (StandardSft, SFT_L
 
 Covered: SFT_type 'standard' (the sample config's default), 'concat', 'weak' (1 or 64 maps) and 'none'; mask_para; repeats;
 q_injection (meta-attention gates after the SFT layers -- with SFT layers that take no maps, as the reference's handler then
-supplies metadata vectors); scale 2 / 3 / 4.  Not built: concat_strategy (widens the RGB input), da_injection.  How the
-default configuration maps onto the gfx950 kernels (ops.sft_* / ops.sftmd_forward):
+supplies metadata vectors); scale 2 / 3 / 4; the handler's concat_strategy (metadata maps concatenated to the RGB input: the
+head conv takes 3 + M <= 64 channels) and da_injection (metadata as vectors).  How the default configuration maps onto the
+gfx950 kernels (ops.sft_* / ops.sftmd_forward):
 
   * An SFT layer's four convs run as two MFMA convs over a 128-channel map (chunk 0 = the 64 features, chunk 1 = the
     metadata maps zero-padded to 64): A = [mul_conv1 | add_conv1] merged along the outputs (128 -> 64, LeakyReLU 0.2 in
