@@ -74,28 +74,81 @@ __device__ __forceinline__ float block_sum_parts_t(const float* __restrict__ pp,
   return r;
 }
 
+// Four wave sums at once: the same six exchange steps per value, interleaved (a wave sum is six dependent cross-lane
+// exchanges; the gate's hidden units are independent of each other).  Bit-identical to four calls of wave_sum.
+__device__ __forceinline__ void wave_sum4(float (&v)[4]) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = __shfl_xor(v[j], o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += t[j];
+  }
+}
+
+// g_lds (optional, 64 floats of LDS outside `red`): the gate is left there too, for a caller that consumes it in the same
+// launch (the conv kernels' gate heads: no store -> load round trip through L2 on the serial path).
 template <bool NT>
 __device__ __forceinline__ void ca_gate_fwd_sample(const float* __restrict__ part, int parts, float inv_hw, int b,
                                                    const float* __restrict__ w1, const float* __restrict__ b1,
                                                    const float* __restrict__ w2, const float* __restrict__ b2, int R,
                                                    const float* __restrict__ mul, float* __restrict__ s_out,
                                                    float* __restrict__ hid_out, float* __restrict__ ca_out,
-                                                   float* __restrict__ g_out, float* red) {
+                                                   float* __restrict__ g_out, float* red, float* g_lds = nullptr) {
   const int c = threadIdx.x & 63;
+  // the MLP's operands are requested BEFORE the partial sums (they do not depend on them): one memory round trip on the
+  // serial path between two convs instead of two.  R <= 4 (64 channels / reduction 16) takes this path; any other R the loop
+  const bool pre = R <= 4 && threadIdx.x < 64;
+  float w1r[4] = {0.f, 0.f, 0.f, 0.f}, w2r[4] = {0.f, 0.f, 0.f, 0.f}, b1r[4] = {0.f, 0.f, 0.f, 0.f}, b2c = 0.f, mc = 1.f;
+  if (pre) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < R) {
+        w1r[j] = w1[j * 64 + c];
+        w2r[j] = w2[c * R + j];
+        b1r[j] = b1[j];
+      }
+    b2c = b2[c];
+    if (mul) mc = mul[b * 64 + c];
+  }
   float s = block_sum_parts_t<NT>(part + (long)b * parts * 64, parts, red);
   if (threadIdx.x >= 64) return;
   s *= inv_hw;
   s_out[b * 64 + c] = s;
-  float z = b2[c];
+  float z, ca;
+  if (pre) {
+    float h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = w1r[j] * s;
+    wave_sum4(h);
+    z = b2c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < R) {
+        const float hj = fmaxf(h[j] + b1r[j], 0.f);
+        if (c == 0) hid_out[b * R + j] = hj;
+        z += w2r[j] * hj;
+      }
+    ca = sigmoidf(z);
+    const float g = mul ? ca * mc : ca;
+    ca_out[b * 64 + c] = ca;
+    g_out[b * 64 + c] = g;
+    if (g_lds) g_lds[c] = g;
+    return;
+  }
+  z = b2[c];
   for (int j = 0; j < R; ++j) {
     float h = wave_sum(w1[j * 64 + c] * s) + b1[j];
     h = fmaxf(h, 0.f);
     if (c == 0) hid_out[b * R + j] = h;
     z += w2[c * R + j] * h;
   }
-  const float ca = sigmoidf(z);
+  ca = sigmoidf(z);
   ca_out[b * 64 + c] = ca;
-  g_out[b * 64 + c] = mul ? ca * mul[b * 64 + c] : ca;
+  const float g = mul ? ca * mul[b * 64 + c] : ca;
+  g_out[b * 64 + c] = g;
+  if (g_lds) g_lds[c] = g;
 }
 
 // ---- backward, per sample (whole workgroup):  dg = sum of the partials of sum_hw dOut*t;  dca = dg*mul;
@@ -106,26 +159,56 @@ __device__ __forceinline__ void ca_gate_bwd_sample(const float* __restrict__ dgp
                                                    const float* __restrict__ w1, const float* __restrict__ w2, int R,
                                                    const float* __restrict__ hid, const float* __restrict__ ca_in,
                                                    const float* __restrict__ mul, float* __restrict__ shift,
-                                                   float* __restrict__ dmul, float* dz2_out, float* dz1_out, float* red) {
+                                                   float* __restrict__ dmul, float* dz2_out, float* dz1_out, float* red,
+                                                   float* shift_lds = nullptr) {
   const int c = threadIdx.x & 63;
+  // operands first, partial sums second (see ca_gate_fwd_sample)
+  const bool pre = R <= 4 && threadIdx.x < 64;
+  float w1r[4] = {0.f, 0.f, 0.f, 0.f}, w2r[4] = {0.f, 0.f, 0.f, 0.f}, hr[4] = {0.f, 0.f, 0.f, 0.f}, cac = 0.f, mc = 1.f;
+  if (pre) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < R) {
+        w1r[j] = w1[j * 64 + c];
+        w2r[j] = w2[c * R + j];
+        hr[j] = hid[b * R + j];
+      }
+    cac = ca_in[b * 64 + c];
+    if (mul) mc = mul[b * 64 + c];
+  }
   const float dg = block_sum_parts_t<NT>(dgpart + (long)b * parts * 64, parts, red);
   if (threadIdx.x < 64) {
-    const float ca = ca_in[b * 64 + c];
+    const float ca = pre ? cac : ca_in[b * 64 + c];
     float dca = dg;
     if (mul) {
       dmul[b * 64 + c] = dg * ca;
-      dca = dg * mul[b * 64 + c];
+      dca = dg * (pre ? mc : mul[b * 64 + c]);
     }
     const float dz2 = dca * ca * (1.f - ca);
     dz2_out[b * 64 + c] = dz2;
     float ds = 0.f;
-    for (int j = 0; j < R; ++j) {
-      const float dh = wave_sum(w2[c * R + j] * dz2);
-      const float dz1 = hid[b * R + j] > 0.f ? dh : 0.f;
-      if (c == 0) dz1_out[b * R + j] = dz1;
-      ds += w1[j * 64 + c] * dz1;
+    if (pre) {
+      float dh[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dh[j] = w2r[j] * dz2;
+      wave_sum4(dh);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < R) {
+          const float dz1 = hr[j] > 0.f ? dh[j] : 0.f;
+          if (c == 0) dz1_out[b * R + j] = dz1;
+          ds += w1r[j] * dz1;
+        }
+    } else {
+      for (int j = 0; j < R; ++j) {
+        const float dh = wave_sum(w2[c * R + j] * dz2);
+        const float dz1 = hid[b * R + j] > 0.f ? dh : 0.f;
+        if (c == 0) dz1_out[b * R + j] = dz1;
+        ds += w1[j * 64 + c] * dz1;
+      }
     }
     shift[b * 64 + c] = ds * inv_hw;
+    if (shift_lds) shift_lds[c] = ds * inv_hw;
   }
 }
 

@@ -315,6 +315,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
 // skip being rebuilt is computed here from the previous conv's GAP partial sums (ca_gate_fwd_sample, every workgroup for
 // its own sample; all write the same s / hid / ca / g); 2 = with AFFINE + MASK, the GAP-backward shift is computed here from
 // the previous conv's DOT partial sums (ca_gate_bwd_sample).  Same device functions as the stand-alone gate kernels.
+#define SISR_HEAD_LDS 256  // bytes behind the halo in the launches with a gate head: the 64 gate / shift values of the sample
 template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false, bool LEAKY = false, int KSEL = 0, int HEAD = 0>
 __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_WGS : 4) : 3)) void conv3x3_c64_v4_kernel(ConvParams p) {
   constexpr int THv = 2 * MT, HHv = THv + 2;
@@ -366,13 +367,14 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
   if constexpr (HEAD == 1) {
     ca_gate_fwd_sample<false>(p.head_part, p.head_parts, p.fwd_tail.inv_hw, b, p.fwd_tail.w1, p.fwd_tail.b1, p.fwd_tail.w2,
                               p.fwd_tail.b2, p.fwd_tail.R, p.fwd_tail.mul, p.fwd_tail.s, p.fwd_tail.hid, p.fwd_tail.ca,
-                              p.fwd_tail.g, lds);
-    __syncthreads();  // g (= p.in_scale of this launch) is in L2 for the whole workgroup; the LDS scratch is free again
+                              p.fwd_tail.g, lds, lds + HHv * HALO_W * 64);
+    __syncthreads();  // g (= p.in_scale of this launch): 64 floats of LDS behind the halo (launched with SISR_HEAD_LDS more
+                      // bytes) hand it to the staging below -- no store -> load round trip; the scratch is free again
   } else if constexpr (HEAD == 2) {
     ca_gate_bwd_sample<false>(p.head_part, p.head_parts, p.bwd_tail.inv_hw, b, p.bwd_tail.w1, p.bwd_tail.w2, p.bwd_tail.R,
                               p.bwd_tail.hid, p.bwd_tail.ca, p.bwd_tail.mul, p.bwd_tail.shift, p.bwd_tail.dmul,
-                              p.bwd_tail.dz2, p.bwd_tail.dz1, lds);
-    __syncthreads();  // shift (= p.in_shift of this launch)
+                              p.bwd_tail.dz2, p.bwd_tail.dz1, lds, lds + HHv * HALO_W * 64);
+    __syncthreads();  // shift (= p.in_shift of this launch), handed over the same way
   }
   int c_begin = 0;
   if constexpr (KSEL == 3) {
@@ -428,7 +430,8 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
       f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
       if (AFFINE) {
         s4 = *reinterpret_cast<const f32x4*>(p.in_scale + ((long)b * p.cin_chunks + c) * 64 + c4 * 4);
-        if (p.in_shift) t4 = *reinterpret_cast<const f32x4*>(p.in_shift + ((long)b * p.cin_chunks + c) * 64 + c4 * 4);
+        if constexpr (HEAD == 2) t4 = *reinterpret_cast<const f32x4*>(lds + HHv * HALO_W * 64 + c4 * 4);
+        else if (p.in_shift) t4 = *reinterpret_cast<const f32x4*>(p.in_shift + ((long)b * p.cin_chunks + c) * 64 + c4 * 4);
       }
       unsigned goff[3], loff[3];
       bool cok[3];
@@ -476,7 +479,8 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
           }
         }
       } else {  // y = t * gate + skip on the fly; rows in batches of HHv / 2 (two operand tensors in flight)
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.in_scale + (long)b * 64 + c4 * 4);
+        const f32x4 g4 = HEAD == 1 ? *reinterpret_cast<const f32x4*>(lds + HHv * HALO_W * 64 + c4 * 4)
+                                   : *reinterpret_cast<const f32x4*>(p.in_scale + (long)b * 64 + c4 * 4);
         const sisr_rsrc_t ru = sisr_rsrc(p.gate_add + (long)b * p.xv.sB);
         const sisr_rsrc_t ro_ = sisr_rsrc(p.gate_out + (long)b * p.xv.sB);
         // 2-row tiles with three resident workgroups (168 registers): both operand maps of all four halo rows are requested
@@ -2349,7 +2353,7 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
     }
 #define V4X(RS, MTV, GT, DT) hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, RS, MTV, GT, DT>), g, dim3(256), lb, st, p)
     if (head && (!gate || head->backward)) return SISR_ERR_ARG;
-#define V4H(RS, MTV) hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, RS, MTV, true, false, false, 0, 1>), g, dim3(256), lb, st, p)
+#define V4H(RS, MTV) hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, RS, MTV, true, false, false, 0, 1>), g, dim3(256), lb + SISR_HEAD_LDS, st, p)
     if (gate && head) {
       if (small) { if (rs) V4H(true, 1); else V4H(false, 1); }
       else       { if (rs) V4H(true, 2); else V4H(false, 2); }
@@ -2419,7 +2423,7 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
         else if (leaky)
           hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, 1, false, false, true>), grid2, dim3(256), lb2, st, p);
         else if (aff && head)
-          hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 1, false, false, false, 0, 2>), grid2, dim3(256), lb2, st, p);
+          hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 1, false, false, false, 0, 2>), grid2, dim3(256), lb2 + SISR_HEAD_LDS, st, p);
         else if (aff)
           hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 1>), grid2, dim3(256), lb2, st, p);
         else if (msk)
@@ -2436,7 +2440,7 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
       else if (leaky)
         hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, 2, false, false, true>), grid, dim3(256), lb, st, p);
       else if (aff && head)
-        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 2, false, false, false, 0, 2>), grid, dim3(256), lb, st, p);
+        hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 2, false, false, false, 0, 2>), grid, dim3(256), lb + SISR_HEAD_LDS, st, p);
       else if (aff)
         hipLaunchKernelGGL((conv3x3_c64_v4_kernel<true, true, false, 2>), grid, dim3(256), lb, st, p);
       else if (msk)

@@ -79,6 +79,12 @@ PY
       local tag=$1; shift
       prof "$O" "$tag" "$R/bench.py" "$@"
       head -14 "$O/kernel_stats_$tag.csv" | cut -c1-170 ;;
+    anatomy)    # anatomy TAG script args...: kernel trace of `python script args` -> where the last step's wall time goes
+      local tag=$1; shift
+      ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d "$O/prof_$tag" -o p -- python "$R/$1" "${@:2}" > "$O/prof_$tag.log" 2>&1 )
+      python tools/rocpd_step.py "$O/prof_$tag/p_results.db" > "$O/anatomy_$tag.txt"
+      python tools/rocpd_stats.py "$O/prof_$tag/p_results.db" > "$O/kernel_stats_$tag.csv"
+      rm -rf "$O/prof_$tag"; cat "$O/anatomy_$tag.txt" | cut -c1-160 ;;
     pmc)        # pmc TAG COUNTER kbench-args...: one rocprofv3 --pmc pass over tools/kbench.py -> per-kernel mean of the counter
       local tag=$1 ctr=$2; shift 2
       ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$O/pmc_${tag}_$ctr" -o p -- python "$R/tools/kbench.py" "$@" > "$O/pmc_${tag}_$ctr.log" 2>&1 )
