@@ -395,6 +395,35 @@ int sisr_noise_quant(const float* blur, const float* noise, float sigma, unsigne
 int sisr_pil_resample(const unsigned char* in, void* out, const int* bounds, const int* coef, int ksize, int C, int Hin,
                       int Win, int Hout, int Wout, int vertical, int to_float, void* stream);
 
+/* ---- SPARNet / QSPARNet pieces (csrc/sparnet.hip) --------------------------------------------------------------
+ * ref: SPARNet/blocks.py:69-103 ConvLayer ([nearest x2] -> ReflectionPad2d(1) -> Conv2d(3x3, stride 1 | 2) -> [BatchNorm2d]
+ * -> [LeakyReLU(0.2)]), :106-174 ResidualBlock, :177-243 HourGlassBlock.  Maps are NHWC with C a multiple of 64 (channels
+ * >= C_real zero).  The convs themselves are sisr_conv3x3_c64 / sisr_wgrad3x3_c64 on the padded geometry.
+ * sisr_pad_reflect_up: adjoint == 0: x (B,H,W,C) -> y (B, up H + 2, up W + 2, C) = ReflectionPad2d(1)(nearest_up(x)), up 1 | 2;
+ *   adjoint != 0: x is the gradient of that padded map, y (B,H,W,C) its fold back (sums in index order).
+ * sisr_crop_stride: embed == 0: src (B,Hf,Wf,C) -> dst (B,Ho,Wo,C), dst[h][w] = src[1 + s h][1 + s w], Ho = (Hf-3)/s + 1 --
+ *   the interior of the "same" conv over the padded map = the reference's unpadded (strided) conv; embed != 0: the adjoint.
+ * sisr_bn_act_fwd: y = act(BatchNorm2d(x)), act = LeakyReLU(slope) (slope 1: none).  training != 0: batch statistics
+ *   (biased variance, two passes), mean_out / invstd_out [C] saved for the backward, running_mean / running_var (nullable)
+ *   updated with `momentum` and the unbiased variance as torch does; training == 0: the running statistics.
+ * sisr_bn_act_bwd: dx, dgamma [C_real], dbeta [C_real] from x, dy (gradient AFTER the activation), mean, invstd.
+ *   workspace: sisr_bn_workspace_bytes(npix, C) for both.
+ * sisr_spar_combine_fwd: y = identity (nullable) + x * a, a = sigmoid(logits[p][0]) (logits NHWC with C_logits channels),
+ *   att[p] = a.  _bwd: dx = dy * a; dlogits[p][0] = (sum_c dy x) a (1 - a), the other channels of dlogits zero. */
+size_t sisr_bn_workspace_bytes(long npix, int C);
+int sisr_pad_reflect_up(const float* x, float* y, int B, int H, int W, int C, int up, int adjoint, void* stream);
+int sisr_crop_stride(const float* src, float* dst, int B, int Hf, int Wf, int C, int stride, int embed, void* stream);
+int sisr_bn_act_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float* mean_out, float* invstd_out, long npix, int C, int C_real, int training,
+                    float momentum, float eps, float slope, float* workspace, size_t workspace_bytes, void* stream);
+int sisr_bn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
+                    const float* invstd, float* dx, float* dgamma, float* dbeta, long npix, int C, int C_real, float slope,
+                    float* workspace, size_t workspace_bytes, void* stream);
+int sisr_spar_combine_fwd(const float* x, const float* logits, const float* identity, float* y, float* att, long npix, int C,
+                          int C_logits, void* stream);
+int sisr_spar_combine_bwd(const float* dy, const float* x, const float* att, float* dx, float* dlogits, long npix, int C,
+                          int C_logits, void* stream);
+
 /* ---- SFTMD pieces (csrc/sft.hip) ------------------------------------------------------------------------------
  * ref: SFTMD_variants/architectures.py:25-56 StandardSft (x * sigmoid(mul) + add), :110-176 SFTMD (LeakyReLU(0.2),
  * 9x9 64 -> 3 output conv, clamp).  The network's 3x3 convs run on sisr_conv3x3_c64 with `relu` = 2 (LeakyReLU(0.2)

@@ -699,3 +699,83 @@ def sftmd(sd, x, para_maps, num_blocks=16, scale=4, sft_type="standard", mask_pa
 
 NETS["sftmd"] = sftmd
 META_NETS = META_NETS + ("sftmd",)
+
+
+# ----------------------------------------------------------------------------- SPARNet / QSPARNet
+# ref: SISR/models/SPARNet/blocks.py:10-243, SPARNet/architectures.py:7-155.  Batch norm: `training` selects batch
+# statistics (biased variance; the running statistics in `sd` are updated in place with momentum 0.1 and the unbiased
+# variance, as nn.BatchNorm2d does) or the running statistics.
+def _sp_conv_layer(sd, key, x, scale="none", norm=False, slope=1.0, training=True):
+    """ref: blocks.py:69-103 ConvLayer.forward: [nearest x2] -> ReflectionPad2d(1) -> Conv2d(3x3, stride) -> norm -> relu."""
+    if scale == "up":
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    x = F.pad(x, (1, 1, 1, 1), mode="reflect")
+    x = F.conv2d(x, sd[key + ".conv2d.weight"], sd.get(key + ".conv2d.bias"), stride=2 if scale == "down" else 1)
+    if norm:
+        x = _sp_bn(sd, key + ".norm.norm", x, training)
+    return x if slope == 1.0 else F.leaky_relu(x, slope)
+
+
+def _sp_bn(sd, key, x, training):
+    return F.batch_norm(x, sd[key + ".running_mean"], sd[key + ".running_var"], sd[key + ".weight"], sd[key + ".bias"],
+                        training=training, momentum=0.1, eps=1e-5)
+
+
+def _sp_hourglass(sd, key, x, depth, slope, training):
+    """ref: blocks.py:177-243"""
+    if depth == 0:
+        return x
+
+    def level(lv, t):
+        up1 = _sp_conv_layer(sd, f"{key}.b1_{lv}", t, "none", True, slope, training)
+        low1 = _sp_conv_layer(sd, f"{key}.b2_{lv}", t, "down", True, slope, training)
+        low2 = level(lv - 1, low1) if lv > 1 else _sp_conv_layer(sd, f"{key}.b2_plus_{lv}", low1, "none", True, slope, training)
+        up2 = _sp_conv_layer(sd, f"{key}.b3_{lv}", low2, "up", True, slope, training)
+        if up1.shape[2:] != up2.shape[2:]:
+            up2 = F.interpolate(up2, up1.shape[2:])
+        return up1 + up2
+
+    att = torch.sigmoid(_sp_conv_layer(sd, key + ".out_block.0", level(depth, x)))
+    return x * att
+
+
+def _sp_block(sd, key, x, scale, depth, slope, training, md=None):
+    """ref: blocks.py:106-174 ResidualBlock.forward (metadata_attention when its parameters are present)"""
+    identity = _sp_conv_layer(sd, key + ".shortcut_func", x, scale) if (key + ".shortcut_func.conv2d.weight") in sd else x
+    out = F.leaky_relu(_sp_bn(sd, key + ".preact_func.0.norm", x, training), slope)
+    s1, s2 = {"down": ("none", "down"), "up": ("up", "none"), "none": ("none", "none")}[scale]
+    out = _sp_conv_layer(sd, key + ".conv1", out, s1, True, slope, training)
+    out = _sp_conv_layer(sd, key + ".conv2", out, s2, True, 1.0, training)
+    out = identity + _sp_hourglass(sd, key + ".att_func", out, depth, slope, training)
+    if md is not None and (key + ".metadata_attention.attribute_integrator.0.weight") in sd:
+        out = para_ca_layer(sd, key + ".metadata_attention", out, md, True)
+    return out
+
+
+def sparnet(sd, x, md=None, in_size=128, out_size=128, min_feat_size=16, res_depth=10, bottleneck_size=4, slope=0.2,
+            training=False):
+    """ref: architectures.py:7-76 (SPARNet) / :79-155 (QSPARNet: md = (B, M, 1, 1) metadata).  Channel counts come from the
+    state dict; the layer plan (which blocks scale, the hourglass depths) from the size arguments as in the constructors."""
+    down_steps = int(np.log2(in_size // min_feat_size))
+    up_steps = int(np.log2(out_size // min_feat_size))
+    hg = int(np.log2(64 / bottleneck_size))
+    out = _sp_conv_layer(sd, "encoder.0", x)
+    for i in range(down_steps):
+        out = _sp_block(sd, f"encoder.{i + 1}", out, "down", hg, slope, training, md)
+        hg -= 1
+    hg += 1
+    for i in range(res_depth + 3 - down_steps):
+        out = _sp_block(sd, f"res_layers.{i}", out, "none", hg, slope, training, md)
+    for i in range(up_steps):
+        hg += 1
+        out = _sp_block(sd, f"decoder.{i}", out, "up", hg, slope, training, md)
+    return _sp_conv_layer(sd, "out_conv", out)
+
+
+def qsparnet(sd, x, md, **cfg):
+    return sparnet(sd, x, md, **cfg)
+
+
+NETS["sparnet"] = sparnet
+NETS["qsparnet"] = qsparnet
+META_NETS = META_NETS + ("qsparnet",)

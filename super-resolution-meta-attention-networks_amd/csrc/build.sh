@@ -7,7 +7,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRCS=(conv3x3_mfma.hip wgrad3x3_mfma.hip conv3x3_small.hip attention.hip misc.hip han.hip san.hip degrade.hip sft.hip nonlocal.hip)
+SRCS=(conv3x3_mfma.hip wgrad3x3_mfma.hip conv3x3_small.hip attention.hip misc.hip han.hip san.hip degrade.hip sft.hip nonlocal.hip sparnet.hip)
 
 build() {  # $1 = output, $2 = object dir, $3... = extra flags / sources
   local out=$1 odir=$2; shift 2

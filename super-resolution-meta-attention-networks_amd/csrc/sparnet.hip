@@ -1,0 +1,441 @@
+// SPARNet / QSPARNet (ref: Code/SISR/models/SPARNet/blocks.py:10-243, architectures.py:7-155): everything around the 3x3
+// convolutions, which run on the MFMA conv kernels of conv3x3_mfma.hip / wgrad3x3_mfma.hip.
+//
+// A reference ConvLayer (blocks.py:69-103) is  [nearest x2] -> ReflectionPad2d(1) -> Conv2d(3x3, stride 1 | 2, no padding)
+// -> [BatchNorm2d] -> [LeakyReLU(0.2)].  Here:
+//   pad_reflect_up     gathers the (optionally 2x nearest-upsampled) map with its reflected ring in one pass: (H, W) ->
+//                      (up H + 2, up W + 2); the zero-padded "same" MFMA conv over that map equals the reference's unpadded
+//                      conv on every pixel of its interior;
+//   crop_stride        takes that interior, every `stride`-th pixel (a stride-2 conv is the stride-1 conv subsampled);
+//   the adjoints       embed_stride (gradient placed back into a zero map of the padded size; the MFMA input-gradient and
+//                      weight-gradient kernels then run on the padded geometry unchanged) and pad_reflect_up_bwd (folds the
+//                      ring and the 2 x 2 replicas back onto the source pixel, in index order);
+//   bn_*               BatchNorm2d over (B, H, W) per channel with the LeakyReLU folded in: two-pass statistics (mean, then
+//                      centred squares: no E[x^2] - E[x]^2 cancellation), partial sums per workgroup added in index order
+//                      (deterministic), running statistics updated as torch does (momentum, unbiased variance);
+//   spar_combine_*     the spatial-attention product of HourGlassBlock.forward (blocks.py:236-243) with the block's residual
+//                      sum (blocks.py:166):  out = identity + x * sigmoid(logit),  logit = channel 0 of the 64 -> 1 conv's
+//                      zero-padded 64-channel result.
+// Maps are channels-last with the channel count zero-padded to a multiple of 64 (C_real <= C: the padded channels stay zero
+// through every kernel here).  HBM-bound passes over small maps (the network works at 128^2 ... 4^2 pixels): one thread per
+// 16-byte piece, coalesced; nothing here is on the headline path.
+#include "sisr_common.h"
+
+static inline unsigned sp_blocks(long n) {
+  long b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 65535 ? 65535 : b));
+}
+
+// padded index i (0 .. up*n + 1) -> source index in the un-upsampled map of n rows / columns
+__device__ __forceinline__ int sp_src(int i, int n, int up) {
+  const int nu = n * up;
+  int u = i - 1;
+  if (u < 0) u = -u;
+  if (u >= nu) u = 2 * nu - 2 - u;
+  return up == 2 ? (u >> 1) : u;
+}
+
+__global__ __launch_bounds__(256) void pad_reflect_up_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int H, int W,
+                                                             int c4n, int up, long total) {
+  const int Hp = up * H + 2, Wp = up * W + 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int pw = (int)(t % Wp);
+    t /= Wp;
+    const int ph = (int)(t % Hp);
+    const long b = t / Hp;
+    y[i] = x[((b * H + sp_src(ph, H, up)) * W + sp_src(pw, W, up)) * c4n + c4];
+  }
+}
+
+// adjoint: dx[b][h][w] = sum of dy over the padded positions that read (h, w); rows then columns in ascending order
+__global__ __launch_bounds__(256) void pad_reflect_up_bwd_kernel(const f32x4* __restrict__ dy, f32x4* __restrict__ dx, int H,
+                                                                 int W, int c4n, int up, long total) {
+  const int Hp = up * H + 2, Wp = up * W + 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const long b = t / H;
+    // candidates: the ring positions 0 and n_p - 1, and the up interior positions up*h + 1 .. up*h + up
+    int ri[4], rj[4], nr = 0, nc = 0;
+    if (sp_src(0, H, up) == h) ri[nr++] = 0;
+    for (int k = 1; k <= up; ++k) ri[nr++] = up * h + k;
+    if (sp_src(Hp - 1, H, up) == h) ri[nr++] = Hp - 1;
+    if (sp_src(0, W, up) == w) rj[nc++] = 0;
+    for (int k = 1; k <= up; ++k) rj[nc++] = up * w + k;
+    if (sp_src(Wp - 1, W, up) == w) rj[nc++] = Wp - 1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < nr; ++a)
+      for (int c = 0; c < nc; ++c) acc += dy[((b * Hp + ri[a]) * Wp + rj[c]) * c4n + c4];
+    dx[i] = acc;
+  }
+}
+
+// y[b][h][w] = yf[b][1 + s h][1 + s w]  (embed == 0)   |   yf = 0 except those positions <- y  (embed == 1)
+__global__ __launch_bounds__(256) void crop_stride_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int Hf,
+                                                          int Wf, int Ho, int Wo, int s, int c4n, long total, int embed) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    if (!embed) {
+      const int w = (int)(t % Wo);
+      t /= Wo;
+      const int h = (int)(t % Ho);
+      const long b = t / Ho;
+      dst[i] = src[((b * Hf + 1 + s * h) * Wf + 1 + s * w) * c4n + c4];
+    } else {
+      const int j = (int)(t % Wf);
+      t /= Wf;
+      const int r = (int)(t % Hf);
+      const long b = t / Hf;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int h = (r - 1) / s, w = (j - 1) / s;
+      if (r >= 1 && j >= 1 && (r - 1) % s == 0 && (j - 1) % s == 0 && h < Ho && w < Wo)
+        v = src[((b * Ho + h) * Wo + w) * c4n + c4];
+      dst[i] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm (+ LeakyReLU)
+// x: [npix][C] (C = 64 or 128 ... multiple of 64, at most SP_MAXC).  A workgroup = (C / 4) channel lanes x (1024 / C) pixel
+// lanes; workgroup k owns pixels [k * chunk, (k + 1) * chunk).
+#define SP_MAXC 256
+#define SP_MAXBLK 64
+
+// z = x * sc + sh, the pre-activation value of the forward.  The backward needs its SIGN (the LeakyReLU mask) and must get the
+// forward's: a value recomputed as xhat * gamma + beta rounds differently, and an element within an ulp of zero then takes
+// slope 1 one way and `slope` the other -- one such element in 16 k moves the block's input gradient by 1e-3 (found with
+// the float64 oracle).  So forward and backward share these three explicit operations, fma included.
+__device__ __forceinline__ void sp_bn_coeffs(float g, float b, float mean, float inv, float& sc, float& sh) {
+  sc = g * inv;
+  sh = __builtin_fmaf(-mean, sc, b);
+}
+__device__ __forceinline__ float sp_bn_z(float x, float sc, float sh) { return __builtin_fmaf(x, sc, sh); }
+
+// MODE 0: sum of x.  MODE 1: sum of (x - mean)^2, mean from the MODE-0 partials (every workgroup adds them in index order).
+// MODE 2 (backward): sums of dz and dz * xhat,  dz = dy * act'(xhat * gamma + beta).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ mean_in, const float* __restrict__ invstd_in,
+                                                         const float* __restrict__ part_in, float* __restrict__ part_out,
+                                                         long npix, int C, int C_real, float slope, long chunk) {
+  __shared__ float stat[2 * SP_MAXC];
+  __shared__ __attribute__((aligned(16))) float red[2 * 256 * 4];
+  const int c4n = C >> 2, rows = 256 / c4n;
+  const int c4 = threadIdx.x % c4n, row = threadIdx.x / c4n;
+  const int nblk = gridDim.x;
+  if (MODE == 1) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float s = 0.f;
+      for (int k = 0; k < nblk; ++k) s += part_in[(long)k * C + c];
+      stat[c] = s / (float)npix;
+    }
+    __syncthreads();
+  }
+  f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, i4 = m4, sc4 = m4, sh4 = m4;
+  if (MODE == 1) m4 = *reinterpret_cast<const f32x4*>(stat + c4 * 4);
+  if (MODE == 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c4 * 4 + e;
+      m4[e] = mean_in[c];
+      i4[e] = invstd_in[c];
+      float a, b;
+      sp_bn_coeffs(c < C_real ? gamma[c] : 0.f, c < C_real ? beta[c] : 0.f, m4[e], i4[e], a, b);
+      sc4[e] = a;
+      sh4[e] = b;
+    }
+  }
+  const long p0 = (long)blockIdx.x * chunk, p1 = min(npix, p0 + chunk);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, a2 = a;
+  for (long p = p0 + row; p < p1; p += rows) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + p * C + c4 * 4);
+    if (MODE == 0) a += v;
+    if (MODE == 1) {
+      const f32x4 d = v - m4;
+      a += d * d;
+    }
+    if (MODE == 2) {
+      const f32x4 xh = (v - m4) * i4;
+      f32x4 dz = *reinterpret_cast<const f32x4*>(dy + p * C + c4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!(sp_bn_z(v[e], sc4[e], sh4[e]) > 0.f)) dz[e] *= slope;
+      a += dz;
+      a2 += dz * xh;
+    }
+  }
+  *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = a;
+  if (MODE == 2) *reinterpret_cast<f32x4*>(red + 1024 + threadIdx.x * 4) = a2;
+  __syncthreads();
+  for (int c = threadIdx.x; c < (MODE == 2 ? 2 : 1) * C; c += 256) {
+    const int which = c / C, cc = c - which * C;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += red[which * 1024 + (r * c4n + (cc >> 2)) * 4 + (cc & 3)];
+    part_out[((long)blockIdx.x * (MODE == 2 ? 2 : 1) + which) * C + cc] = s;
+  }
+}
+
+// y = act(xhat * gamma + beta).  TRAIN: statistics from the partials (every workgroup adds them in index order; workgroup 0
+// also writes mean / invstd and updates the running statistics); else from running_mean / running_var.
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ part_sum, const float* __restrict__ part_sq,
+                                                       int nblk, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                       float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                       float momentum, float eps, float slope, long npix, int C, int C_real) {
+  __shared__ __attribute__((aligned(16))) float sc[SP_MAXC], sh[SP_MAXC];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float mean, var;
+    if (TRAIN) {
+      float s = 0.f, q = 0.f;
+      for (int k = 0; k < nblk; ++k) s += part_sum[(long)k * C + c];
+      for (int k = 0; k < nblk; ++k) q += part_sq[(long)k * C + c];
+      mean = s / (float)npix;
+      var = q / (float)npix;
+    } else {
+      mean = c < C_real ? running_mean[c] : 0.f;
+      var = c < C_real ? running_var[c] : 1.f;
+    }
+    const float inv = 1.f / sqrtf(var + eps);
+    if (TRAIN && blockIdx.x == 0) {
+      mean_out[c] = mean;
+      invstd_out[c] = inv;
+      if (running_mean && c < C_real) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        const float unbiased = npix > 1 ? var * ((float)npix / (float)(npix - 1)) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
+    }
+    sp_bn_coeffs(c < C_real ? gamma[c] : 0.f, c < C_real ? beta[c] : 0.f, mean, inv, sc[c], sh[c]);
+  }
+  __syncthreads();
+  const int c4n = C >> 2;
+  const long total = npix * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc + c4 * 4), t4 = *reinterpret_cast<const f32x4*>(sh + c4 * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = sp_bn_z(v[e], s4[e], t4[e]);
+      v[e] = z > 0.f ? z : z * slope;
+    }
+    reinterpret_cast<f32x4*>(y)[i] = v;
+  }
+}
+
+// dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat));  workgroup 0 writes dgamma = sum(dz * xhat), dbeta = sum(dz)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean_in, const float* __restrict__ invstd_in,
+                                                           const float* __restrict__ part, int nblk, float* __restrict__ dx,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float slope,
+                                                           long npix, int C, int C_real) {
+  __shared__ __attribute__((aligned(16))) float s1[SP_MAXC], s2[SP_MAXC], mn[SP_MAXC], iv[SP_MAXC], gm[SP_MAXC], sc[SP_MAXC], sh[SP_MAXC];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nblk; ++k) a += part[((long)k * 2) * C + c];
+    for (int k = 0; k < nblk; ++k) b += part[((long)k * 2 + 1) * C + c];
+    if (blockIdx.x == 0 && c < C_real) {
+      dbeta[c] = a;
+      dgamma[c] = b;
+    }
+    s1[c] = a / (float)npix;
+    s2[c] = b / (float)npix;
+    mn[c] = mean_in[c];
+    iv[c] = invstd_in[c];
+    gm[c] = c < C_real ? gamma[c] : 0.f;
+    sp_bn_coeffs(gm[c], c < C_real ? beta[c] : 0.f, mn[c], iv[c], sc[c], sh[c]);
+  }
+  __syncthreads();
+  const int c4n = C >> 2;
+  const long total = npix * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c0 = (int)(i % c4n) * 4;
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 dz = reinterpret_cast<const f32x4*>(dy)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e;
+      const float xh = (v[e] - mn[c]) * iv[c];
+      float d = dz[e];
+      if (!(sp_bn_z(v[e], sc[c], sh[c]) > 0.f)) d *= slope;
+      dz[e] = gm[c] * iv[c] * (d - s1[c] - xh * s2[c]);
+    }
+    reinterpret_cast<f32x4*>(dx)[i] = dz;
+  }
+}
+
+static inline void sp_bn_geometry(long npix, int C, int* nblk, long* chunk) {
+  const int rows = 1024 / C;                  // pixel lanes of a workgroup
+  long want = (npix + rows * 8 - 1) / (rows * 8);  // at least eight pixels per lane
+  int n = (int)(want < 1 ? 1 : (want > SP_MAXBLK ? SP_MAXBLK : want));
+  *nblk = n;
+  *chunk = (npix + n - 1) / n;
+}
+
+extern "C" size_t sisr_bn_workspace_bytes(long npix, int C) {
+  if (npix <= 0 || C <= 0 || (C & 63) || C > SP_MAXC) return 0;
+  return (size_t)SP_MAXBLK * 2 * C * sizeof(float);
+}
+
+extern "C" int sisr_bn_act_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float* mean_out, float* invstd_out, long npix, int C, int C_real,
+                               int training, float momentum, float eps, float slope, float* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (!x || !y || !gamma || !beta || npix <= 0 || C <= 0 || (C & 63) || C > SP_MAXC || C_real <= 0 || C_real > C)
+    return SISR_ERR_ARG;
+  if (!sisr_aligned16(x) || !sisr_aligned16(y)) return SISR_ERR_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned ga = sp_blocks(npix * (C >> 2));
+  if (!training) {
+    if (!running_mean || !running_var) return SISR_ERR_ARG;
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ga), dim3(256), 0, st, x, y, gamma, beta, nullptr, nullptr, 0, nullptr,
+                       nullptr, running_mean, running_var, 0.f, eps, slope, npix, C, C_real);
+    return sisr_check_launch();
+  }
+  if (!mean_out || !invstd_out || !workspace || workspace_bytes < sisr_bn_workspace_bytes(npix, C)) return SISR_ERR_ARG;
+  int nblk;
+  long chunk;
+  sp_bn_geometry(npix, C, &nblk, &chunk);
+  float* psum = workspace;
+  float* psq = workspace + (size_t)SP_MAXBLK * C;
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     psum, npix, C, C_real, 1.f, chunk);
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, psum,
+                     psq, npix, C, C_real, 1.f, chunk);
+  hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(ga), dim3(256), 0, st, x, y, gamma, beta, psum, psq, nblk, mean_out,
+                     invstd_out, running_mean, running_var, momentum, eps, slope, npix, C, C_real);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_bn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
+                               const float* invstd, float* dx, float* dgamma, float* dbeta, long npix, int C, int C_real,
+                               float slope, float* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !dy || !gamma || !beta || !mean || !invstd || !dx || !dgamma || !dbeta || !workspace || npix <= 0 || C <= 0 ||
+      (C & 63) || C > SP_MAXC || C_real <= 0 || C_real > C || workspace_bytes < sisr_bn_workspace_bytes(npix, C))
+    return SISR_ERR_ARG;
+  if (!sisr_aligned16(x) || !sisr_aligned16(dy) || !sisr_aligned16(dx)) return SISR_ERR_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  int nblk;
+  long chunk;
+  sp_bn_geometry(npix, C, &nblk, &chunk);
+  hipLaunchKernelGGL(bn_partial_kernel<2>, dim3(nblk), dim3(256), 0, st, x, dy, gamma, beta, mean, invstd, nullptr, workspace,
+                     npix, C, C_real, slope, chunk);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(sp_blocks(npix * (C >> 2))), dim3(256), 0, st, x, dy, gamma, beta, mean, invstd,
+                     workspace, nblk, dx, dgamma, dbeta, slope, npix, C, C_real);
+  return sisr_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------ spatial attention product
+// y = idn + x * a,  a = sigmoid(logits[p][0]);  att[p] = a.  One thread per 16-byte piece; the C / 4 threads of a pixel are
+// consecutive lanes of one wave (C / 4 = 16 or 32 ...: a power of two up to 64).
+__global__ __launch_bounds__(256) void spar_combine_fwd_kernel(const f32x4* __restrict__ x, const float* __restrict__ logits,
+                                                               const f32x4* __restrict__ idn, f32x4* __restrict__ y,
+                                                               float* __restrict__ att, int c4n, int Cl, long total) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / c4n;
+    const float a = 1.f / (1.f + expf(-logits[p * Cl]));
+    f32x4 v = x[i] * a;
+    if (idn) v += idn[i];
+    y[i] = v;
+    if (i % c4n == 0) att[p] = a;
+  }
+}
+
+// dx = dy * a;  dlogits[p][0] = (sum_c dy * x) * a * (1 - a), every other channel of dlogits 0.  total is a multiple of c4n
+// and the grid-stride a multiple of 64, so the c4n lanes of a pixel stay together in one wave.
+__global__ __launch_bounds__(256) void spar_combine_bwd_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x,
+                                                               const float* __restrict__ att, f32x4* __restrict__ dx,
+                                                               f32x4* __restrict__ dlogits, int c4n, int cl4n, long total) {
+  for (long i0 = (long)blockIdx.x * 256; i0 < total; i0 += (long)gridDim.x * 256) {
+    const long i = i0 + threadIdx.x;
+    const bool on = i < total;
+    const long p = on ? i / c4n : 0;
+    const int c4 = on ? (int)(i % c4n) : 0;
+    const float a = on ? att[p] : 0.f;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f}, v = g;
+    if (on) {
+      g = dy[i];
+      v = x[i];
+      dx[i] = g * a;
+    }
+    float s = (g[0] * v[0] + g[1] * v[1]) + (g[2] * v[2] + g[3] * v[3]);
+    for (int o = 1; o < c4n; o <<= 1) s += __shfl_xor(s, o);
+    if (on) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      for (int q = c4; q < cl4n; q += c4n) {
+        f32x4 d = z;
+        if (q == 0) d[0] = s * a * (1.f - a);
+        dlogits[p * cl4n + q] = d;
+      }
+    }
+  }
+}
+
+extern "C" int sisr_pad_reflect_up(const float* x, float* y, int B, int H, int W, int C, int up, int adjoint, void* stream) {
+  // adjoint == 0: x (B, H, W, C) -> y (B, up H + 2, up W + 2, C);  adjoint == 1: x is the padded gradient, y (B, H, W, C)
+  if (!x || !y || B <= 0 || H < 2 || W < 2 || C <= 0 || (C & 3) || (up != 1 && up != 2)) return SISR_ERR_ARG;
+  if (!sisr_aligned16(x) || !sisr_aligned16(y)) return SISR_ERR_ALIGN;
+  const int c4n = C >> 2;
+  if (!adjoint) {
+    const long total = (long)B * (up * H + 2) * (up * W + 2) * c4n;
+    hipLaunchKernelGGL(pad_reflect_up_kernel, dim3(sp_blocks(total)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), H, W, c4n, up, total);
+  } else {
+    const long total = (long)B * H * W * c4n;
+    hipLaunchKernelGGL(pad_reflect_up_bwd_kernel, dim3(sp_blocks(total)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), H, W, c4n, up, total);
+  }
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_crop_stride(const float* src, float* dst, int B, int Hf, int Wf, int C, int stride, int embed,
+                                void* stream) {
+  // embed == 0: src (B, Hf, Wf, C) -> dst (B, Ho, Wo, C), Ho = (Hf - 3) / stride + 1;  embed == 1: the adjoint (src is the
+  // small map, dst the zero-filled large one)
+  if (!src || !dst || B <= 0 || Hf < 3 || Wf < 3 || C <= 0 || (C & 3) || (stride != 1 && stride != 2)) return SISR_ERR_ARG;
+  if (!sisr_aligned16(src) || !sisr_aligned16(dst)) return SISR_ERR_ALIGN;
+  const int Ho = (Hf - 3) / stride + 1, Wo = (Wf - 3) / stride + 1, c4n = C >> 2;
+  const long total = embed ? (long)B * Hf * Wf * c4n : (long)B * Ho * Wo * c4n;
+  hipLaunchKernelGGL(crop_stride_kernel, dim3(sp_blocks(total)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst), Hf, Wf, Ho, Wo, stride, c4n, total,
+                     embed);
+  return sisr_check_launch();
+}
+
+static inline bool sp_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+extern "C" int sisr_spar_combine_fwd(const float* x, const float* logits, const float* identity, float* y, float* att,
+                                     long npix, int C, int C_logits, void* stream) {
+  if (!x || !logits || !y || !att || npix <= 0 || C <= 0 || (C & 3) || C_logits <= 0) return SISR_ERR_ARG;
+  if (!sisr_aligned16(x) || !sisr_aligned16(y) || (identity && !sisr_aligned16(identity))) return SISR_ERR_ALIGN;
+  const int c4n = C >> 2;
+  const long total = npix * c4n;
+  hipLaunchKernelGGL(spar_combine_fwd_kernel, dim3(sp_blocks(total)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4*>(x), logits, reinterpret_cast<const f32x4*>(identity),
+                     reinterpret_cast<f32x4*>(y), att, c4n, C_logits, total);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_spar_combine_bwd(const float* dy, const float* x, const float* att, float* dx, float* dlogits, long npix,
+                                     int C, int C_logits, void* stream) {
+  if (!dy || !x || !att || !dx || !dlogits || npix <= 0 || C <= 0 || (C & 3) || C_logits <= 0 || (C_logits & 3))
+    return SISR_ERR_ARG;
+  const int c4n = C >> 2;
+  if (!sp_pow2(c4n) || c4n > 64) return SISR_ERR_UNSUPPORTED;
+  if (!sisr_aligned16(dy) || !sisr_aligned16(x) || !sisr_aligned16(dx) || !sisr_aligned16(dlogits)) return SISR_ERR_ALIGN;
+  const long total = npix * c4n;
+  hipLaunchKernelGGL(spar_combine_bwd_kernel, dim3(sp_blocks(total)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4*>(dy), reinterpret_cast<const f32x4*>(x), att, reinterpret_cast<f32x4*>(dx),
+                     reinterpret_cast<f32x4*>(dlogits), c4n, C_logits >> 2, total);
+  return sisr_check_launch();
+}

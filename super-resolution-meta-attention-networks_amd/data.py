@@ -288,8 +288,14 @@ class SuperResImages(Dataset):
         super().__init__()
         if split not in ['train', 'eval', 'test', 'all', None]:
             raise RuntimeError('"Split" must be one of: train | eval | test | all | None')
-        if input != 'unmodified' or 'rgb' not in colorspace:
-            raise NotImplementedError('only unmodified RGB inputs are in scope (EDSR/RCAN/HAN families)')
+        if input not in ['interp', 'unmodified']:
+            raise RuntimeError('"lr_type" must be one of: interp | unmodified')  # ref: data_handler.py:193-194
+        if 'rgb' not in colorspace:
+            raise NotImplementedError('only RGB inputs are in scope (the Y-channel models SRCNN / VDSR are not)')
+        if input == 'interp' and online_degradations:
+            raise NotImplementedError("online degradations produce low-resolution images: input = 'interp' (LR images stored "
+                                      "at HR size, SPARNet) does not go with them")
+        self.lr_type = input
         for k in ('mask_data', 'halfway_data', 'blacklist', 'data_attributes', 'image_shortlist',
                   'legacy_blur_kernels', 'request_crops', 'group_select', 'attribute_amplification'):
             if unsupported.get(k):
@@ -342,7 +348,10 @@ class SuperResImages(Dataset):
         metadata = self.metadata[index] if self.metadata is not None else np.array(0)
         if self.hr_base is not None:
             hr_im = read_image(os.path.join(self.hr_base, base_name))
-            h, w = lr_im.height * self.scale, lr_im.width * self.scale
+            if self.lr_type == 'interp':  # ref: data_handler.py:473-476: the LR images are stored already interpolated
+                h, w = lr_im.height, lr_im.width
+            else:
+                h, w = lr_im.height * self.scale, lr_im.width * self.scale
             if hr_im.width != w or hr_im.height != h:
                 hr_im = center_crop(hr_im, height=h, width=w)
             hr_im = to_tensor(hr_im)

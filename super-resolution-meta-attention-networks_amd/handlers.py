@@ -507,6 +507,11 @@ try:  # SFTMD (sftmd.py)
     HANDLERS += [SFTMDHandler]
 except ImportError:
     pass
+try:  # SPARNet / QSPARNet (sparnet.py)
+    from .sparnet import SPARNetHandler, QSPARNetHandler
+    HANDLERS += [SPARNetHandler, QSPARNetHandler]
+except ImportError:
+    pass
 # registry key = class name minus 'Handler', lower-cased (ref: models/__init__.py:26-30)
 available_models = {h.__name__.split('Handler')[0].lower(): h for h in HANDLERS}
 

@@ -126,6 +126,15 @@ _SIGS.update({  # around the non-local attention (csrc/nonlocal.hip)
     "sisr_nl_output_bwd_parts": (c_int, [P]),
     "sisr_nl_output_bwd": (c_int, [P, P, P, P, P, P, P]),
 })
+_SIGS.update({  # SPARNet pieces (csrc/sparnet.hip)
+    "sisr_bn_workspace_bytes": (c_size_t, [c_long, c_int]),
+    "sisr_pad_reflect_up": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sisr_crop_stride": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sisr_bn_act_fwd": (c_int, [P] * 8 + [c_long, c_int, c_int, c_int, c_float, c_float, c_float, P, c_size_t, P]),
+    "sisr_bn_act_bwd": (c_int, [P] * 9 + [c_long, c_int, c_int, c_float, P, c_size_t, P]),
+    "sisr_spar_combine_fwd": (c_int, [P, P, P, P, P, c_long, c_int, c_int, P]),
+    "sisr_spar_combine_bwd": (c_int, [P, P, P, P, P, c_long, c_int, c_int, P]),
+})
 _SIGS.update({  # SFTMD pieces (csrc/sft.hip)
     "sisr_sft_compose": (c_int, [P] * 12 + [c_int, c_int, P]),
     "sisr_sft_compose_record_bytes": (c_size_t, []),

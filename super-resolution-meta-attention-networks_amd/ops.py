@@ -1496,6 +1496,169 @@ def nchw_to_nhwc_pad(x, cp=None):
     return y
 
 
+# ----------------------------------------------------------------------------- SPARNet pieces (csrc/sparnet.hip)
+class _ReflConv(Function):
+    """The conv of one reference ConvLayer as one autograd node (ref: SPARNet/blocks.py:69-103):
+    [nearest x2] -> ReflectionPad2d(1) -> Conv2d(3x3, stride 1 | 2, no padding).  x: channels-last map zero-padded to a
+    multiple of 64 channels; weight / bias keep their reference shapes (zero-padded per call); y: (B, pad64(cout), Ho, Wo).
+    The padded, upsampled map is materialised by one gather; the zero-padded MFMA conv over it equals the reference's conv on
+    its interior, which a second gather takes (every stride-th pixel).  Backward: the adjoint gathers around the MFMA
+    input-gradient / weight-gradient kernels on the padded geometry."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, up, stride):
+        B, Cp, H, W = x.shape
+        co, ci = weight.shape[0], weight.shape[1]
+        if Cp % 64 or ci > Cp or tuple(weight.shape[2:]) != (3, 3):
+            raise NotImplementedError(f"reflection-padded conv: 3x3 weights on a 64-multiple map (got {tuple(weight.shape)} on {Cp})")
+        if H < 2 or W < 2:
+            raise NotImplementedError("ReflectionPad2d(1) needs at least 2 x 2 pixels")
+        dev, L = x.device, hip.lib()
+        x = _cl(x)
+        cop = _pad64(co)
+        Hp, Wp = up * H + 2, up * W + 2
+        xp = _empty_cl(B, Cp, Hp, Wp, dev)
+        hip.check(L.sisr_pad_reflect_up(hip.ptr(x), hip.ptr(xp), B, H, W, Cp, up, 0, hip.stream()), "sisr_pad_reflect_up")
+        wp = _pad_oihw(weight, cop, Cp)
+        bp = _pad_oihw(bias.reshape(co, 1), cop, 1).reshape(cop) if bias is not None else None
+        if ctx.needs_input_grad[0]:
+            pf, ctx.pd = pack_pair(wp)
+        else:
+            pf, ctx.pd = pack_weight(wp, "fwd"), None
+        yf = _empty_cl(B, cop, Hp, Wp, dev)
+        conv_c64(xp, hip.view_plain(Hp, Wp, Cp), pf, bp, (1, 64), yf, hip.view_plain(Hp, Wp, cop), B, Hp, Wp, Cp, cop)
+        Ho, Wo = (Hp - 3) // stride + 1, (Wp - 3) // stride + 1
+        y = _empty_cl(B, cop, Ho, Wo, dev)
+        hip.check(L.sisr_crop_stride(hip.ptr(yf), hip.ptr(y), B, Hp, Wp, cop, stride, 0, hip.stream()), "sisr_crop_stride")
+        ctx.save_for_backward(xp, weight)
+        ctx.bias = bias
+        ctx.geom = (B, H, W, Cp, cop, Hp, Wp, up, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, weight = ctx.saved_tensors
+        B, H, W, Cp, cop, Hp, Wp, up, stride = ctx.geom
+        dev, L = dy.device, hip.lib()
+        dy = _cl(dy)
+        dyf = _empty_cl(B, cop, Hp, Wp, dev)
+        hip.check(L.sisr_crop_stride(hip.ptr(dy), hip.ptr(dyf), B, Hp, Wp, cop, stride, 1, hip.stream()), "sisr_crop_stride(embed)")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dxp = _empty_cl(B, Cp, Hp, Wp, dev)
+            conv_c64(dyf, hip.view_plain(Hp, Wp, cop), ctx.pd, None, (1, 64), dxp, hip.view_plain(Hp, Wp, Cp), B, Hp, Wp, cop, Cp)
+            dx = _empty_cl(B, Cp, H, W, dev)
+            hip.check(L.sisr_pad_reflect_up(hip.ptr(dxp), hip.ptr(dx), B, H, W, Cp, up, 1, hip.stream()), "sisr_pad_reflect_up(adjoint)")
+        if ctx.needs_input_grad[1] or (ctx.bias is not None and ctx.needs_input_grad[2]):
+            padded = (cop, Cp) != tuple(weight.shape[:2])
+            dwp = torch.empty((cop, Cp, 3, 3), device=dev) if padded else _grad_buf(weight)
+            has_b = ctx.bias is not None
+            dbp = (torch.empty(cop, device=dev) if padded else _grad_buf(ctx.bias)) if has_b else None
+            wgrad_c64(xp, hip.view_plain(Hp, Wp, Cp), dyf, hip.view_plain(Hp, Wp, cop), dwp, dbp, B, Hp, Wp, Cp, cop)
+            dw = _crop_oihw(dwp, tuple(weight.shape))
+            if has_b:
+                co = weight.shape[0]
+                db = _crop_oihw(dbp.reshape(-1, 1), (co, 1)).reshape(co)
+        return dx, dw, db, None, None
+
+
+def refl_conv(x, weight, bias=None, up=1, stride=1):
+    return _ReflConv.apply(x, weight, bias, int(up), int(stride))
+
+
+class _BatchNormAct(Function):
+    """LeakyReLU(slope)(BatchNorm2d(x)) on a channels-last map whose channels >= C_real are zero padding (ref: NormLayer +
+    ReluLayer, SPARNet/blocks.py:10-66; slope 1 = no activation).  training: batch statistics, running statistics updated in
+    place as torch does; else the running statistics (forward only)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+        B, C, H, W = x.shape
+        Cr = gamma.shape[0]
+        if C % 64 or Cr > C or C > 256:
+            raise NotImplementedError("batch norm kernels: a 64-multiple map of at most 256 channels")
+        dev, L = x.device, hip.lib()
+        x = _cl(x)
+        y = torch.empty_like(x)
+        npix = B * H * W
+        nbytes = L.sisr_bn_workspace_bytes(npix, C)
+        ws = hip.workspace(dev, nbytes)
+        mean, invstd = (torch.empty(C, device=dev), torch.empty(C, device=dev)) if training else (None, None)
+        g, b = gamma.contiguous(), beta.contiguous()
+        hip.check(L.sisr_bn_act_fwd(hip.ptr(x), hip.ptr(y), hip.ptr(g), hip.ptr(b), hip.ptr(running_mean),
+                                    hip.ptr(running_var), hip.ptr(mean), hip.ptr(invstd), npix, C, Cr, int(training),
+                                    float(momentum), float(eps), float(slope), hip.ptr(ws), nbytes, hip.stream()),
+                  "sisr_bn_act_fwd")
+        ctx.training, ctx.slope, ctx.geom = training, slope, (npix, C, Cr)
+        if training:
+            ctx.save_for_backward(x, g, b, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise NotImplementedError("batch norm backward in eval mode (running statistics) is not built: the reference "
+                                      "trains in train() mode and evaluates under no_grad")
+        x, g, b, mean, invstd = ctx.saved_tensors
+        npix, C, Cr = ctx.geom
+        dev, L = dy.device, hip.lib()
+        dy = _cl(dy)
+        dx = torch.empty_like(x)
+        dg, db = torch.empty(Cr, device=dev), torch.empty(Cr, device=dev)
+        nbytes = L.sisr_bn_workspace_bytes(npix, C)
+        ws = hip.workspace(dev, nbytes)
+        hip.check(L.sisr_bn_act_bwd(hip.ptr(x), hip.ptr(dy), hip.ptr(g), hip.ptr(b), hip.ptr(mean), hip.ptr(invstd),
+                                    hip.ptr(dx), hip.ptr(dg), hip.ptr(db), npix, C, Cr, float(ctx.slope), hip.ptr(ws), nbytes,
+                                    hip.stream()), "sisr_bn_act_bwd")
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def batch_norm_act(x, bn, slope=1.0):
+    """bn: an nn.BatchNorm2d (parameter / buffer holder); slope: LeakyReLU slope folded in (1 = none)."""
+    training = bn.training or bn.running_mean is None
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1  # as nn.BatchNorm2d.forward does (momentum is a number here: the average is exponential)
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not built")
+    return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training), float(bn.momentum),
+                               float(bn.eps), float(slope))
+
+
+class _SparCombine(Function):
+    """out = identity + x * sigmoid(logits[:, 0])  (ref: HourGlassBlock.forward, SPARNet/blocks.py:236-243, and the residual sum
+    of ResidualBlock.forward :166).  logits: the 64 -> 1 attention conv's zero-padded 64-channel result."""
+
+    @staticmethod
+    def forward(ctx, x, logits, identity):
+        B, C, H, W = x.shape
+        dev, L = x.device, hip.lib()
+        x, logits = _cl(x), _cl(logits)
+        idn = _cl(identity) if identity is not None else None
+        y = torch.empty_like(x)
+        att = torch.empty(B * H * W, device=dev)
+        hip.check(L.sisr_spar_combine_fwd(hip.ptr(x), hip.ptr(logits), hip.ptr(idn), hip.ptr(y), hip.ptr(att), B * H * W, C,
+                                          logits.shape[1], hip.stream()), "sisr_spar_combine_fwd")
+        ctx.save_for_backward(x, att)
+        ctx.cl, ctx.has_idn = logits.shape[1], identity is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, att = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dev, L = dy.device, hip.lib()
+        dy = _cl(dy)
+        dx = torch.empty_like(x)
+        dl = _empty_cl(B, ctx.cl, H, W, dev)
+        hip.check(L.sisr_spar_combine_bwd(hip.ptr(dy), hip.ptr(x), hip.ptr(att), hip.ptr(dx), hip.ptr(dl), B * H * W, C, ctx.cl,
+                                          hip.stream()), "sisr_spar_combine_bwd")
+        return dx, dl, (dy if ctx.has_idn else None)
+
+
+def spar_combine(x, logits, identity=None):
+    return _SparCombine.apply(x, logits, identity)
+
+
 class _ShuffleRGB(Function):
     """PixelShuffle(r) of the first C r^2 channels of a channels-last map into an NCHW (B, C, rH, rW) image."""
 

@@ -152,3 +152,14 @@ def test_two_rank_cli_training_reproduces_the_reference_run(tmp_path):
     np.testing.assert_allclose(total["train-loss"], ref["train-loss"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(total["val-loss"], ref["val-loss"], rtol=5e-4, atol=5e-5)
     np.testing.assert_allclose(total["val-PSNR"], ref["val-PSNR"], rtol=0, atol=5e-3)
+
+
+def test_interp_input_keeps_hr_at_lr_size():
+    """ref: sr_tools/data_handler.py:473-476: with input = 'interp' (SPARNet: LR images stored already interpolated) the HR
+    image is cropped to the LR image's own size, not scale times it."""
+    d = os.path.join(GOLDEN, "set5")
+    ds = sisr_amd.data.SuperResImages(os.path.join(d, "hr"), os.path.join(d, "hr"), split="all", scale=4, input="interp")
+    item = ds[0]
+    assert item["lr"].shape == item["hr"].shape and item["lr"].shape[0] == 3
+    with pytest.raises(RuntimeError):
+        sisr_amd.data.SuperResImages(os.path.join(d, "hr"), os.path.join(d, "hr"), split="all", input="bicubic")

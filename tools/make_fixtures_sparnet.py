@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""SPARNet / QSPARNet golden vectors (SURVEY.md 8f-4 "then SPARNet"), produced by RUNNING THE REFERENCE on CPU (build
+container only):  python tools/make_fixtures_sparnet.py  ->  tests/golden/p*.npz, p_sparnet.json
+
+P1  p1_block_{none,down,up}      one ResidualBlock each (ref SPARNet/blocks.py:106-174) in train() mode: output, input
+                                 gradient, every parameter gradient (in full for 'none'; norm + 64 leading values for the other two), the
+                                 running statistics after the forward
+P2  p2_sparnet_reduced           reduced SPARNet (32 -> 32 pixels, two down / up steps, 42 / 84 / 128 channels -- the channel
+                                 plan the constructor derives -- res_depth 1): train()-mode output and every parameter
+                                 gradient (norm + leading values), running statistics after it, then the eval()-mode output
+P3  p3_qsparnet_reduced          the same for QSPARNet with 10 metadata values
+P4  p_sparnet.json               full default SPARNet: seed-8 state-dict SHA-256 + key list, eval()-mode output statistics
+                                 and a centre crop for one 128 x 128 input; three handler.run_train steps (losses, gradient
+                                 norms) of the default network on 2 x 3 x 128 x 128 batches
+Weights: the tests re-create them by seeding (torch.manual_seed(8)) and check the state-dict digest.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_fixtures as M  # noqa: E402  (installs the reference import shims)
+
+from SISR.models import ModelInterface  # noqa: E402
+from SISR.models.SPARNet import architectures as SA  # noqa: E402
+from SISR.models.SPARNet import blocks as SB  # noqa: E402
+
+REDUCED = dict(min_ch=32, max_ch=128, in_size=32, out_size=32, min_feat_size=8, res_depth=1, bottleneck_size=16)
+
+
+def bn_buffers(module):
+    return {k: M._np(v) for k, v in module.state_dict().items() if "running_" in k}
+
+
+def grads_light(module, blob):
+    for k, p in module.named_parameters():
+        blob["pgn/" + k] = np.array(float(p.grad.double().norm()))
+        blob["pgh/" + k] = M._np(p.grad.reshape(-1)[:64])
+
+
+def make_block(name, cin, cout, scale, depth, shape, seed, light=False):
+    torch.manual_seed(8)
+    blk = SB.ResidualBlock(cin, cout, relu_type="leakyrelu", norm_type="bn", scale=scale, hg_depth=depth)
+    blk.train()
+    x = M.rnd(*shape, seed=seed, scale=0.7)
+    out = blk(x)
+    cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(seed + 1))
+    out.backward(cot)
+    blob = {"in0": M._np(x), "gin0": M._np(x.grad), "out": M._np(out), "cot": M._np(cot),
+            "sd_sha256": np.array(M.sd_digest({k: v for k, v in blk.state_dict().items() if "running_" not in k and "num_batches" not in k})),
+            "meta": np.array(json.dumps({"c_in": cin, "c_out": cout, "scale": scale, "hg_depth": depth}))}
+    if light:
+        grads_light(blk, blob)
+    else:
+        for k, p in blk.named_parameters():
+            blob["pg/" + k] = M._np(p.grad)
+    for k, v in bn_buffers(blk).items():
+        blob["buf/" + k] = v
+    path = os.path.join(M.OUT, name + ".npz")
+    np.savez_compressed(path, **blob)
+    print(f"{name:24s} {os.path.getsize(path) / 1e3:8.1f} KB out{tuple(out.shape)}")
+
+
+def make_net(name, q):
+    torch.manual_seed(8)
+    net = SA.QSPARNet(metadata_count=10, **REDUCED) if q else SA.SPARNet(**REDUCED)
+    sha = M.sd_digest({k: v for k, v in net.state_dict().items() if "running_" not in k and "num_batches" not in k})
+    net.train()
+    x = M.rnd(2, 3, 32, 32, seed=91, scale=0.5, grad=False).abs()
+    md = M.rnd(2, 10, 1, 1, seed=92, scale=0.3, grad=False)
+    out = net(x, md) if q else net(x)
+    cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(93))
+    out.backward(cot)
+    blob = {"in0": M._np(x), "md": M._np(md), "out": M._np(out), "cot": M._np(cot), "sd_sha256": np.array(sha),
+            "meta": np.array(json.dumps(REDUCED))}
+    grads_light(net, blob)
+    for k, v in bn_buffers(net).items():
+        blob["buf/" + k] = v
+    net.eval()
+    with torch.no_grad():
+        blob["out_eval"] = M._np(net(x, md) if q else net(x))
+    path = os.path.join(M.OUT, name + ".npz")
+    np.savez_compressed(path, **blob)
+    print(f"{name:24s} {os.path.getsize(path) / 1e3:8.1f} KB out{tuple(out.shape)}")
+
+
+def make_full():
+    torch.manual_seed(8)
+    model = ModelInterface.define_model("sparnet", device=torch.device("cpu"), model_save_dir="/tmp", eval_mode=False,
+                                        scale=4, lr=1e-4)
+    sd = model.net.state_dict()
+    entry = {"sha256": M.sd_digest({k: v for k, v in sd.items() if "running_" not in k and "num_batches" not in k}),
+             "n_tensors": len(sd), "n_params": int(sum(p.numel() for p in model.net.parameters())), "keys": list(sd)}
+    g = torch.Generator().manual_seed(55)
+    x = torch.rand(1, 3, 128, 128, generator=g)
+    model.net.eval()
+    with torch.no_grad():
+        o = model.net(x).numpy()[0]
+    entry["eval"] = {"mean": float(o.mean()), "std": float(o.std())}
+    np.savez_compressed(os.path.join(M.OUT, "p4_sparnet_full.npz"), x=x.numpy(), crop=o[:, 48:80, 48:80].copy())
+    steps = []
+    for it in range(3):
+        xb = torch.rand(2, 3, 128, 128, generator=g)
+        yb = torch.rand(2, 3, 128, 128, generator=g)
+        loss, ob = model.run_train(xb, yb)
+        gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.net.parameters())))
+        steps.append({"loss": float(loss), "grad_norm": gn, "out_mean": float(ob.mean()), "out_std": float(ob.std())})
+        print(f"p4 step {it} loss={float(loss):.6f} gn={gn:.5f}")
+    entry["train_steps"] = steps
+    with open(os.path.join(M.OUT, "p_sparnet.json"), "w") as f:
+        json.dump(entry, f, indent=1)
+
+
+if __name__ == "__main__":
+    make_block("p1_block_none", 64, 64, "none", 2, (2, 64, 16, 16), 81)
+    make_block("p1_block_down", 32, 64, "down", 2, (2, 32, 32, 32), 83, light=True)
+    make_block("p1_block_up", 128, 64, "up", 3, (2, 128, 8, 8), 85, light=True)
+    make_net("p2_sparnet_reduced", False)
+    make_net("p3_qsparnet_reduced", True)
+    make_full()
