@@ -71,6 +71,10 @@ WORKLOADS = {
     # conv at 16 HR pixels (498k) = 9.80 Mflop per LR pixel forward; x3 for forward + both gradients, x 16384 pixels.
     "srmd": ("srmd", {"metadata": ["blur_kernel"], "nc": 128, "nb": 12, "maps": True}, 0.152),
     "sftmd": ("sftmd", {"metadata": ["blur_kernel"], "num_blocks": 16, "num_features": 64, "in_nc": 3, "maps": True}, 0.482),
+    # SPARNet (SURVEY.md 8f-4 "then SPARNet"): interp-input model, 128 x 128 in AND out; 14.26 GFLOP forward per image in
+    # its 3x3 convs (counted conv by conv over the default plan: 32 / 64 / 128 channels at 128^2 .. 4^2 pixels), x3
+    "sparnet": ("sparnet", {"hr_same": True}, 0.0428),
+    "qsparnet": ("qsparnet", {"metadata": ["blur_kernel"], "hr_same": True}, 0.0428),
 }
 GRAPH_MAX_BATCH = 8  # --graph auto: per-GPU batches up to this replay forward+backward from a hipGraph
 
@@ -141,6 +145,7 @@ def cpu_baseline(workload, seconds_budget=30.0):
     name, params, _ = WORKLOADS[workload]
     params = dict(params)
     maps = params.pop("maps", False)
+    hr = 128 if params.pop("hr_same", False) else 512
     torch.set_num_threads(min(16, os.cpu_count() or 1))  # the GPU box grants 16 host cores per GPU
     torch.manual_seed(8)
     h = sisr.available_models[name](device=torch.device("cpu"), model_save_dir="/tmp", eval_mode=False, scale=4, **params)
@@ -150,10 +155,10 @@ def cpu_baseline(workload, seconds_budget=30.0):
            "qedsr": dict(num_blocks=16, scale=4, res_scale=0.1, q_layer_nonlinearity=False),
            "han": dict(n_resgroups=10, n_resblocks=20, scale=4), "qhan": dict(n_resgroups=10, n_resblocks=20, scale=4),
            "san": dict(n_resgroups=20, n_resblocks=10, scale=4), "qsan": dict(n_resgroups=20, n_resblocks=10, scale=4),
-           "srmd": {}, "sftmd": {}}[name]
+           "srmd": {}, "sftmd": {}, "sparnet": dict(training=True), "qsparnet": dict(training=True)}[name]
     tr = O.Trainer(name, h.net.state_dict(), lr=1e-4, **cfg)
     g = torch.Generator().manual_seed(8)
-    x, y = torch.rand(1, 3, 128, 128, generator=g), torch.rand(1, 3, 512, 512, generator=g)
+    x, y = torch.rand(1, 3, 128, 128, generator=g), torch.rand(1, 3, hr, hr, generator=g)
     md = (torch.rand(1, 10, 1, 1, generator=g) * 0.4) if name in O.META_NETS else None
     if maps:
         md = O.sft_channels(x, (torch.rand(1, 10, generator=g, dtype=torch.float64) * 0.4))
@@ -184,6 +189,7 @@ def measure(sisr, workload, B, steps, warmup, use_graph, rank, world, local, dev
     name, params, tflop_per_patch = WORKLOADS[workload]
     params = dict(params)
     maps = params.pop("maps", False)
+    hr = 128 if params.pop("hr_same", False) else 512
     if name not in sisr.available_models:
         raise SystemExit(f"workload {name} is not built yet")
     torch.manual_seed(8)
@@ -195,7 +201,7 @@ def measure(sisr, workload, B, steps, warmup, use_graph, rank, world, local, dev
     h.use_graph = use_graph
     g = torch.Generator().manual_seed(8 + rank)
     x = torch.rand(B, 3, 128, 128, generator=g).to(dev)
-    y = torch.rand(B, 3, 512, 512, generator=g).to(dev)
+    y = torch.rand(B, 3, hr, hr, generator=g).to(dev)
     kw = {}
     if "metadata" in params:
         code = torch.rand(B, 10, 1, 1, generator=g) * 0.4

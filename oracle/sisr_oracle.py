@@ -613,8 +613,11 @@ class Trainer:
     def __init__(self, name, state_dict, lr=1e-4, scheduler=None, scheduler_params=None, grad_clip=None,
                  betas=(0.9, 0.999), **cfg):
         self.name, self.cfg = name, cfg
-        self.sd = {k: v.detach().clone().float().requires_grad_(True) for k, v in state_dict.items()}
-        self.opt = torch.optim.Adam(list(self.sd.values()), lr=lr, betas=betas)
+        # parameters are optimised; batch-norm buffers (SPARNet) ride along and are updated in place by the forward
+        buf = lambda k: "running_" in k or "num_batches_tracked" in k  # noqa: E731
+        self.sd = {k: (v.detach().clone() if buf(k) else v.detach().clone().float().requires_grad_(True))
+                   for k, v in state_dict.items()}
+        self.opt = torch.optim.Adam([v for v in self.sd.values() if v.requires_grad], lr=lr, betas=betas)
         self.sched = None
         if scheduler == "cosine_annealing_warm_restarts":
             self.sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(
@@ -636,7 +639,7 @@ class Trainer:
         self.opt.zero_grad()
         loss.backward()
         if self.grad_clip is not None:
-            torch.nn.utils.clip_grad_norm_(list(self.sd.values()), self.grad_clip)
+            torch.nn.utils.clip_grad_norm_([v for v in self.sd.values() if v.requires_grad], self.grad_clip)
         gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in self.sd.values()
                                if p.grad is not None)).item()  # post-clip; SAN holds parameters its forward never uses
         self.opt.step()
