@@ -393,8 +393,10 @@ def main():
             "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands, f32 accumulate and storage",
                       "bf16x3": "f32 via bf16x3 split (six bf16 MFMA products per f32 product), f32 accumulate and storage"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"{label} x4 full depth, 128x128 LR -> 512x512 tiles, train step = "
-                                   f"fwd + L1 + bwd + Adam + scheduler", "per_gpu_batch": B, "global_batch": B * world,
+            "config": {"workload": (f"{label} full depth, 128x128 interpolated input -> 128x128 output, train step = "
+                                    f"fwd + L1 + bwd + Adam + scheduler" if WORKLOADS[workload][1].get("hr_same") else
+                                    f"{label} x4 full depth, 128x128 LR -> 512x512 tiles, train step = "
+                                    f"fwd + L1 + bwd + Adam + scheduler"), "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"dp{world}" + (" (one-rank RCCL world)" if args.force_dp and world == 1 else ""),
                        "hip_graph": bool(use_graph), "final_loss": main_res["loss"],
                        "algorithmic_tflops": value * tflop_per_patch},

@@ -21,9 +21,9 @@
 // 16-byte piece, coalesced; nothing here is on the headline path.
 #include "sisr_common.h"
 
-static inline unsigned sp_blocks(long n) {
+static inline unsigned sp_blocks(long n, long cap = 65535) {
   long b = (n + 255) / 256;
-  return (unsigned)(b < 1 ? 1 : (b > 65535 ? 65535 : b));
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 // padded index i (0 .. up*n + 1) -> source index in the un-upsampled map of n rows / columns
@@ -117,6 +117,22 @@ __device__ __forceinline__ void sp_bn_coeffs(float g, float b, float mean, float
 }
 __device__ __forceinline__ float sp_bn_z(float x, float sc, float sh) { return __builtin_fmaf(x, sc, sh); }
 
+// sum over k < n of part[k * stride + c], added in index order; sixteen loads in flight (the kernels below do this once per
+// workgroup on the way to their real work: dependent loads one at a time cost 64 memory round trips)
+__device__ __forceinline__ float sp_sum_parts(const float* __restrict__ part, int n, long stride, int c) {
+  float s = 0.f;
+  int k = 0;
+  for (; k + 16 <= n; k += 16) {
+    float t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = part[(long)(k + u) * stride + c];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += t[u];
+  }
+  for (; k < n; ++k) s += part[(long)k * stride + c];
+  return s;
+}
+
 // MODE 0: sum of x.  MODE 1: sum of (x - mean)^2, mean from the MODE-0 partials (every workgroup adds them in index order).
 // MODE 2 (backward): sums of dz and dz * xhat,  dz = dy * act'(xhat * gamma + beta).
 template <int MODE>
@@ -132,9 +148,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   const int nblk = gridDim.x;
   if (MODE == 1) {
     for (int c = threadIdx.x; c < C; c += 256) {
-      float s = 0.f;
-      for (int k = 0; k < nblk; ++k) s += part_in[(long)k * C + c];
-      stat[c] = s / (float)npix;
+      stat[c] = sp_sum_parts(part_in, nblk, C, c) / (float)npix;
     }
     __syncthreads();
   }
@@ -195,11 +209,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   for (int c = threadIdx.x; c < C; c += 256) {
     float mean, var;
     if (TRAIN) {
-      float s = 0.f, q = 0.f;
-      for (int k = 0; k < nblk; ++k) s += part_sum[(long)k * C + c];
-      for (int k = 0; k < nblk; ++k) q += part_sq[(long)k * C + c];
-      mean = s / (float)npix;
-      var = q / (float)npix;
+      mean = sp_sum_parts(part_sum, nblk, C, c) / (float)npix;
+      var = sp_sum_parts(part_sq, nblk, C, c) / (float)npix;
     } else {
       mean = c < C_real ? running_mean[c] : 0.f;
       var = c < C_real ? running_var[c] : 1.f;
@@ -241,9 +252,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            long npix, int C, int C_real) {
   __shared__ __attribute__((aligned(16))) float s1[SP_MAXC], s2[SP_MAXC], mn[SP_MAXC], iv[SP_MAXC], gm[SP_MAXC], sc[SP_MAXC], sh[SP_MAXC];
   for (int c = threadIdx.x; c < C; c += 256) {
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < nblk; ++k) a += part[((long)k * 2) * C + c];
-    for (int k = 0; k < nblk; ++k) b += part[((long)k * 2 + 1) * C + c];
+    const float a = sp_sum_parts(part, nblk, 2L * C, c), b = sp_sum_parts(part + C, nblk, 2L * C, c);
     if (blockIdx.x == 0 && c < C_real) {
       dbeta[c] = a;
       dgamma[c] = b;
@@ -295,7 +304,7 @@ extern "C" int sisr_bn_act_fwd(const float* x, float* y, const float* gamma, con
     return SISR_ERR_ARG;
   if (!sisr_aligned16(x) || !sisr_aligned16(y)) return SISR_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  const unsigned ga = sp_blocks(npix * (C >> 2));
+  const unsigned ga = sp_blocks(npix * (C >> 2), 2048);  // every workgroup first reduces the partials: not too many of them
   if (!training) {
     if (!running_mean || !running_var) return SISR_ERR_ARG;
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(ga), dim3(256), 0, st, x, y, gamma, beta, nullptr, nullptr, 0, nullptr,
@@ -330,7 +339,7 @@ extern "C" int sisr_bn_act_bwd(const float* x, const float* dy, const float* gam
   sp_bn_geometry(npix, C, &nblk, &chunk);
   hipLaunchKernelGGL(bn_partial_kernel<2>, dim3(nblk), dim3(256), 0, st, x, dy, gamma, beta, mean, invstd, nullptr, workspace,
                      npix, C, C_real, slope, chunk);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(sp_blocks(npix * (C >> 2))), dim3(256), 0, st, x, dy, gamma, beta, mean, invstd,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(sp_blocks(npix * (C >> 2), 2048)), dim3(256), 0, st, x, dy, gamma, beta, mean, invstd,
                      workspace, nblk, dx, dgamma, dbeta, slope, npix, C, C_real);
   return sisr_check_launch();
 }

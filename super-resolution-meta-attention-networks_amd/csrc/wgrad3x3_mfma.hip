@@ -1066,7 +1066,11 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   }
   p.mapped = active_units != 0;
   r.mapped = active_units != 0;
-  const bool dense = !active_units && !getenv("SISR_WGRAD_QUADRANT_KERNEL");  // (the env switch: A/B of the two forms)
+  // The dense form gives a whole tile (8 rows x 32 pixels, all four channel quadrants: 31 us of MFMA work on one CU) to one
+  // workgroup.  A launch with fewer tiles than half the CUs (SPARNet's maps of 4^2 .. 32^2 pixels) leaves the chip idle for
+  // that long; the quadrant form splits each tile over four workgroups: 62 -> ~35 us per launch there.
+  const long tiles_all = (long)B * p.tiles_h * p.tiles_w * (units / 4);
+  const bool dense = !active_units && !getenv("SISR_WGRAD_QUADRANT_KERNEL") && tiles_all >= 128;  // (env: A/B of the forms)
   p.S = dense ? wgrad_full_split(B, H, W, units / 4) : wgrad_split(B, H, W, units);
   p.slabs = workspace;
   p.bias_slabs = dbias ? workspace + (size_t)p.S * units * SLAB : nullptr;

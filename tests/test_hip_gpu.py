@@ -1021,9 +1021,12 @@ def test_deferred_wgrad_block_flushes_on_exceptional_exit():
     hold their values (not uninitialised memory) when the block has closed."""
     assert ops.WgradQueue.wanted(2, 24, 40)
     plain = _two_conv_grads(False, False)
+    normal = _two_conv_grads(False, True)
     died = _two_conv_grads(False, True, fail=True)
-    for a, b in zip(plain, died):
-        assert torch.equal(a, b)
+    for a, b, c in zip(plain, normal, died):
+        assert torch.equal(b, c)  # the same batched launches either way: bit-identical
+        # single launches of this size run the quadrant form of the kernel, the batch the full-tile form: another summation order
+        assert torch.allclose(a, c, rtol=2e-5, atol=2e-5 * float(a.abs().max()))
 
 
 def test_deferred_wgrad_queue_takes_a_weight_once_per_pass():
@@ -1032,6 +1035,6 @@ def test_deferred_wgrad_queue_takes_a_weight_once_per_pass():
     plain = _two_conv_grads(True, False)
     queued = _two_conv_grads(True, True)
     for a, b in zip(plain, queued):
-        assert torch.equal(a, b)
+        assert torch.allclose(a, b, rtol=2e-5, atol=2e-5 * float(a.abs().max()))  # (kernel forms differ: see above)
     ref_w = plain[0].double()
     assert torch.isfinite(ref_w).all() and ref_w.abs().max() > 0
