@@ -298,7 +298,8 @@ def main():
             raise SystemExit(f"global batch {G} is not divisible by {world} GPUs")
         B = G // world
         scaling = "weak" if (world == 1 and args.global_batch is None) else "strong"
-    use_graph = args.graph == "on" or (args.graph == "auto" and B <= GRAPH_MAX_BATCH)
+    # (SPARNet: ~3 000 launches of a few microseconds per step at any batch: always launch-bound)
+    use_graph = args.graph == "on" or (args.graph == "auto" and (B <= GRAPH_MAX_BATCH or WORKLOADS[workload][1].get("hr_same")))
 
     main_res = measure(sisr, workload, B, args.steps, args.warmup, use_graph, rank, world, local, dev,
                        families=not args.no_kernel_timing and args.precision == "fp32", dp=args.force_dp)
