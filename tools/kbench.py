@@ -124,6 +124,13 @@ def main():
     run("conv_dgrad2", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1, in_scale=sc,
                                             in_shift=sh), flop, "TFLOP/s")
     run("conv_res", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, res=x), flop, "TFLOP/s")
+    y2 = torch.empty_like(x)
+    # the GATE prologue (forward of a gated block: builds and stores the gated skip while staging) and the DOT epilogue
+    # (its backward: residual + gate-gradient partial sums), as the fused group node launches them
+    run("conv_gate", lambda: ops.conv_c64(dy, v, pk, b, (1, 64), y, v, B, H, W, 64, 64, relu=True, in_scale=sc, gate_add=t1,
+                                          gate_out=y2), flop, "TFLOP/s")
+    run("conv_dot", lambda: ops.conv_c64(dy, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, res=x, dot=t1, gap=gap), flop,
+        "TFLOP/s")
     run("wgrad", lambda: ops.wgrad_c64(x, v, dy, v, dw, db, B, H, W, 64, 64), flop, "TFLOP/s")
     run("wgrad_affine", lambda: ops.wgrad_c64(x, v, dy, v, dw, db, B, H, W, 64, 64, dy_scale=sc, dy_shift=sh), flop,
         "TFLOP/s")
