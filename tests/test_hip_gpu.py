@@ -443,8 +443,9 @@ def test_edsr_reduced_vs_oracle(scale):
 @pytest.mark.parametrize("shape,njobs", [((4, 128, 128), 8), ((2, 37, 45), 5), ((1, 16, 32), 1), ((3, 9, 70), 3), ((2, 64, 64), 41)])
 def test_batched_weight_gradients_equal_single_launches(shape, njobs):
     """ops.WgradQueue (eight 64 -> 64 weight gradients of one geometry per launch; 41 jobs = six launches, csrc/wgrad3x3_mfma.hip
-    wgrad3x3_c64_batch_kernel): every job equals its own single launch -- bit for bit when the K-split is the same (one job),
-    to summation-order rounding otherwise; jobs with and without the dY * scale + shift rebuild and with / without a bias."""
+    wgrad3x3_c64_batch_kernel): every job equals its own single launch to summation-order rounding (the K-split differs with
+    the job count, and single launches of few tiles run the quadrant form of the kernel); jobs with and without the
+    dY * scale + shift rebuild and with / without a bias."""
     B, H, W = shape
     dev = torch.device(DEV)
     cl = torch.channels_last
@@ -467,12 +468,9 @@ def test_batched_weight_gradients_equal_single_launches(shape, njobs):
         q.add(x, dy, dw, db, dy_scale=sc, dy_shift=sh)
     q.flush()
     for (x, dy, sc, sh, dw, db), (dw1, db1) in zip(jobs, want):
-        if njobs == 1:
-            assert torch.equal(dw, dw1) and torch.equal(db, db1)
-        else:
-            close(dw, dw1, 2e-5, 2e-6, "dw")
-            if db is not None:
-                close(db, db1, 2e-5, 2e-6, "db")
+        close(dw, dw1, 2e-5, 2e-6, "dw")
+        if db is not None:
+            close(db, db1, 2e-5, 2e-6, "db")
 
 
 @pytest.mark.parametrize("L,M,nl", [(1, 10, 1), (3, 10, 1), (3, 20, 0), (4, 1, 1), (4, 20, 1)])
