@@ -410,6 +410,9 @@ int sisr_pil_resample(const unsigned char* in, void* out, const int* bounds, con
  *   workspace: sisr_bn_workspace_bytes(npix, C) for both.
  * sisr_spar_combine_fwd: y = identity (nullable) + x * a, a = sigmoid(logits[p][0]) (logits NHWC with C_logits channels),
  *   att[p] = a.  _bwd: dx = dy * a; dlogits[p][0] = (sum_c dy x) a (1 - a), the other channels of dlogits zero. */
+/* sisr_nearest_up: nn.Upsample(scale_factor = up, 'nearest') on an NHWC map, up 1 .. 4 (ref: advanced/SRMD_blocks.py:58-63, the
+ * 'upconv' tail of SRMD); adjoint != 0: the gradient summed back over the up x up replicas. */
+int sisr_nearest_up(const float* src, float* dst, int B, int H, int W, int C, int up, int adjoint, void* stream);
 size_t sisr_bn_workspace_bytes(long npix, int C);
 int sisr_pad_reflect_up(const float* x, float* y, int B, int H, int W, int C, int up, int adjoint, void* stream);
 int sisr_crop_stride(const float* src, float* dst, int B, int Hf, int Wf, int C, int stride, int embed, void* stream);

@@ -510,13 +510,31 @@ def chop_forward(run, x, scale, max_pixels=160000, shave=10):
     return out
 
 
-def srmd(sd, x, nb=12, scale=4):
-    """ref: advanced/architectures.py:380-425 with advanced/SRMD_blocks.py:33-126: x is the (3+M)-channel input
-    (RGB + metadata maps); model = [conv, ReLU] x (nb-1), conv, PixelShuffle(scale) -- flat Sequential indices."""
+def srmd(sd, x, nb=12, scale=4, act_mode="R", upsample_mode="pixelshuffle", training=True):
+    """ref: advanced/architectures.py:380-425 with advanced/SRMD_blocks.py:33-142: x is the (3+M)-channel input (RGB + metadata
+    maps).  The model is a flat Sequential with one module per character of the mode strings: head 'C' + act_mode[-1], body
+    ('C' + act_mode) x (nb - 2), tail 'C' + str(scale) (conv + PixelShuffle) or Upsample(nearest) + conv ('upconv').  'B' is
+    BatchNorm2d(momentum=0.9, eps=1e-4): batch statistics when `training` (running statistics in `sd` updated in place)."""
+    tail = "C" + str(scale) if upsample_mode == "pixelshuffle" else {2: "UC", 3: "uC", 4: "vC"}[scale]
     y = x
-    for k in range(nb - 1):
-        y = F.relu(conv(sd, f"model.{2 * k}", y))
-    return F.pixel_shuffle(conv(sd, f"model.{2 * (nb - 1)}", y), scale)
+    for i, t in enumerate("C" + act_mode[-1] + ("C" + act_mode) * (nb - 2) + tail):
+        key = f"model.{i}"
+        if t == "C":
+            y = conv(sd, key, y)
+        elif t == "B":
+            y = F.batch_norm(y, sd[key + ".running_mean"], sd[key + ".running_var"], sd[key + ".weight"], sd[key + ".bias"],
+                             training=training, momentum=0.9, eps=1e-4)
+        elif t in "Rr":
+            y = F.relu(y)
+        elif t in "Ll":
+            y = F.leaky_relu(y, 0.2)
+        elif t in "234":
+            y = F.pixel_shuffle(y, int(t))
+        elif t in "Uuv":
+            y = F.interpolate(y, scale_factor={"U": 2, "u": 3, "v": 4}[t], mode="nearest")
+        else:
+            raise NotImplementedError(t)
+    return y
 
 
 def sft_channels(x, metadata):

@@ -421,6 +421,44 @@ extern "C" int sisr_crop_stride(const float* src, float* dst, int B, int Hf, int
   return sisr_check_launch();
 }
 
+// nearest-neighbour upsampling by an integer factor (ref: SRMD_blocks.py:58-63 nn.Upsample(scale_factor = 2 | 3 | 4, 'nearest')
+// in front of SRMD's 'upconv' tail): y[b][i][j] = x[b][i / up][j / up]; adjoint: dx = sum of the up x up replicas, row-major.
+__global__ __launch_bounds__(256) void nearest_up_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int H, int W,
+                                                         int c4n, int up, long total, int adjoint) {
+  const int Ho = H * up, Wo = W * up;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    long t = i / c4n;
+    if (!adjoint) {
+      const int j = (int)(t % Wo);
+      t /= Wo;
+      const int r = (int)(t % Ho);
+      const long b = t / Ho;
+      dst[i] = src[((b * H + r / up) * W + j / up) * c4n + c4];
+    } else {
+      const int w = (int)(t % W);
+      t /= W;
+      const int h = (int)(t % H);
+      const long b = t / H;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int a = 0; a < up; ++a)
+        for (int c = 0; c < up; ++c) acc += src[((b * Ho + h * up + a) * Wo + w * up + c) * c4n + c4];
+      dst[i] = acc;
+    }
+  }
+}
+
+extern "C" int sisr_nearest_up(const float* src, float* dst, int B, int H, int W, int C, int up, int adjoint, void* stream) {
+  // adjoint == 0: src (B, H, W, C) -> dst (B, up H, up W, C);  adjoint != 0: src is the gradient of the large map, dst (B, H, W, C)
+  if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || up < 1 || up > 4) return SISR_ERR_ARG;
+  if (!sisr_aligned16(src) || !sisr_aligned16(dst)) return SISR_ERR_ALIGN;
+  const int c4n = C >> 2;
+  const long total = adjoint ? (long)B * H * W * c4n : (long)B * H * up * W * up * c4n;
+  hipLaunchKernelGGL(nearest_up_kernel, dim3(sp_blocks(total)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst), H, W, c4n, up, total, adjoint);
+  return sisr_check_launch();
+}
+
 static inline bool sp_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 extern "C" int sisr_spar_combine_fwd(const float* x, const float* logits, const float* identity, float* y, float* att,

@@ -1409,13 +1409,13 @@ class _ConvChain(Function):
             pf, pd = pack_pair(wp)
             y = _empty_cl(B, cop, H, W, dev)
             conv_c64(cur, hip.view_plain(H, W, cin_p), pf, bp, (1, 64), y, hip.view_plain(H, W, cop), B, H, W, cin_p, cop,
-                     relu=bool(relus[k]))
+                     relu=int(relus[k]))  # 0 linear, 1 ReLU, 2 LeakyReLU(0.2)
             maps.append(cur)
             packs.append(pd)
             geo.append((cin_p, cop, tuple(w.shape), b is not None))
             cur, cin_p = y, cop
-        if relus[-1]:
-            raise NotImplementedError("conv chain: the last layer must be linear (its gradient arrives unmasked)")
+        if relus[-1]:  # an activated last layer: its mask is applied to the incoming gradient by one elementwise pass
+            maps.append(cur)
         ctx.save_for_backward(*maps, *[params[2 * k] for k in range(n)])
         ctx.cfg = (n, tuple(relus), (B, H, W), geo)
         ctx.packs = packs
@@ -1428,9 +1428,14 @@ class _ConvChain(Function):
         try:
             n, relus, (B, H, W), geo = ctx.cfg
             sv = list(ctx.saved_tensors)
-            maps, ws = sv[:n], sv[n:]
+            nm = n + (1 if relus[-1] else 0)
+            maps, ws = sv[:nm], sv[nm:]
             dev = dy.device
             g = _cl(dy)
+            if relus[-1]:  # g <- dy * act'(last output): ReLU' (op 6) or LeakyReLU' (op 3) over the 64-channel blocks
+                gm = torch.empty_like(g)
+                _map64(maps[n], 64, g, 64, gm, 64, g.numel() // 64, 3 if relus[-1] == 2 else 6)
+                g = gm
             side = _side_ok(*ws)
             grads = [None] * (2 * n)
             for k in range(n - 1, -1, -1):
@@ -1452,7 +1457,8 @@ class _ConvChain(Function):
                 if k > 0 or ctx.needs_input_grad[0]:
                     gin = _empty_cl(B, cin_p, H, W, dev)
                     conv_c64(g, hip.view_plain(H, W, cop), ctx.packs[k], None, (1, 64), gin, hip.view_plain(H, W, cin_p), B, H,
-                             W, cop, cin_p, mask=(xin if (k > 0 and relus[k - 1]) else None))
+                             W, cop, cin_p, mask=(xin if (k > 0 and relus[k - 1]) else None),
+                             relu=(LEAKY_MASK if (k > 0 and relus[k - 1] == 2) else 0))
                 else:
                     gin = None
                 if padded:  # the crop reads what the (possibly side-stream) weight gradient wrote
@@ -1477,11 +1483,12 @@ class _ConvChain(Function):
 
 
 def conv_chain(x, layers):
-    """layers: [(weight, bias, relu)] -> channels-last map with the last layer's (64-padded) channel count."""
+    """layers: [(weight, bias, act)] with act 0 / False linear, 1 / True ReLU, 2 LeakyReLU(0.2) -> channels-last map with the
+    last layer's (64-padded) channel count."""
     flat = []
     for w, b, _ in layers:
         flat += [w, b]
-    return _ConvChain.apply(x, tuple(bool(r) for _, _, r in layers), *flat)
+    return _ConvChain.apply(x, tuple(int(r) for _, _, r in layers), *flat)
 
 
 def nchw_to_nhwc_pad(x, cp=None):
@@ -1622,6 +1629,31 @@ def batch_norm_act(x, bn, slope=1.0):
         raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not built")
     return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training), float(bn.momentum),
                                float(bn.eps), float(slope))
+
+
+class _NearestUp(Function):
+    """nn.Upsample(scale_factor=up, mode='nearest') on a channels-last map (ref: advanced/SRMD_blocks.py:58-63)."""
+
+    @staticmethod
+    def forward(ctx, x, up):
+        B, C, H, W = x.shape
+        x = _cl(x)
+        y = _empty_cl(B, C, H * up, W * up, x.device)
+        hip.check(hip.lib().sisr_nearest_up(hip.ptr(x), hip.ptr(y), B, H, W, C, up, 0, hip.stream()), "sisr_nearest_up")
+        ctx.geom = (B, C, H, W, up)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, up = ctx.geom
+        dy = _cl(dy)
+        dx = _empty_cl(B, C, H, W, dy.device)
+        hip.check(hip.lib().sisr_nearest_up(hip.ptr(dy), hip.ptr(dx), B, H, W, C, up, 1, hip.stream()), "sisr_nearest_up(adjoint)")
+        return dx, None
+
+
+def nearest_up(x, up):
+    return _NearestUp.apply(x, int(up))
 
 
 class _SparCombine(Function):

@@ -5,7 +5,8 @@ ref: Code/SISR/models/advanced/architectures.py:380-425 (SRMD), advanced/SRMD_bl
      attention_manipulators/__init__.py:53-80 (generate_sft_channels).
 
 The reference concatenates the blur-kernel code, stretched to H x W maps, to the RGB input and runs a plain stack
-conv(3+M -> nc) ReLU [conv(nc -> nc) ReLU] x (nb-2) conv(nc -> 3 r^2) PixelShuffle(r).  Here the (3+M)-channel NCHW
+conv(3+M -> nc) ReLU [conv(nc -> nc) ReLU] x (nb-2) conv(nc -> 3 r^2) PixelShuffle(r) (act_mode 'R'; 'L', 'BR', 'BL' put a
+LeakyReLU / BatchNorm2d(momentum 0.9, eps 1e-4) there, upsample_mode 'upconv' ends in nearest upsample + conv).  Here the (3+M)-channel NCHW
 input is laid out once as a zero-padded channels-last map (HIP), the whole conv stack is one autograd node on the MFMA
 3x3 kernels (ops.conv_chain: zero-padded head / tail weights, ReLU masks applied by the input-gradient epilogues) and
 the tail's result is shuffled into the NCHW image by a HIP gather.  `model` keeps the reference's flat nn.Sequential
@@ -19,32 +20,89 @@ from . import ops
 from .handlers import QModel
 
 
+def _layers(in_channels, out_channels, mode, negative_slope=0.2):
+    """ref: advanced/SRMD_blocks.py:33-68 `conv`: one module per character of `mode`, in order (so the flat Sequential indices,
+    hence the state-dict keys, are the reference's)."""
+    out = []
+    for t in mode:
+        if t == 'C':
+            out.append(nn.Conv2d(in_channels, out_channels, 3, 1, 1, bias=True))
+        elif t == 'B':
+            out.append(nn.BatchNorm2d(out_channels, momentum=0.9, eps=1e-04, affine=True))
+        elif t in 'Rr':
+            out.append(nn.ReLU(inplace=t == 'R'))
+        elif t in 'Ll':
+            out.append(nn.LeakyReLU(negative_slope=negative_slope, inplace=t == 'L'))
+        elif t in '234':
+            out.append(nn.PixelShuffle(upscale_factor=int(t)))
+        elif t in 'Uuv':
+            out.append(nn.Upsample(scale_factor={'U': 2, 'u': 3, 'v': 4}[t], mode='nearest'))
+        elif t == 'I':
+            raise NotImplementedError("SRMD act_mode with InstanceNorm ('IR' / 'IL') is not built on the HIP kernels")
+        else:
+            raise NotImplementedError('Undefined type: ' + t)
+    return out
+
+
 class SRMD(nn.Module):
+    """ref: advanced/architectures.py:380-425.  act_mode 'R' (the reference default), 'L', 'BR', 'BL' (and the non-inplace 'r' /
+    'l' spellings); upsample_mode 'pixelshuffle' (default) and 'upconv' (nearest upsample + conv)."""
+
     def __init__(self, in_nc=18, out_nc=3, nc=128, nb=12, scale=4, act_mode='R', upsample_mode='pixelshuffle', **kwargs):
         super().__init__()
         assert 'R' in act_mode or 'L' in act_mode, 'Examples of activation function: R, L, BR, BL, IR, IL'
-        if act_mode != 'R':
-            raise NotImplementedError("SRMD on the HIP kernels implements the reference's default act_mode='R' "
-                                      "(no BatchNorm / LeakyReLU variants)")
-        if upsample_mode != 'pixelshuffle':
-            raise NotImplementedError("upsample mode [%s] is not built (the reference default is 'pixelshuffle')" % upsample_mode)
-        if nc % 64:
-            raise NotImplementedError("SRMD: nc must be a multiple of 64 for the gfx950 conv kernels (reference default 128)")
-        layers = [nn.Conv2d(in_nc, nc, 3, 1, 1, bias=True), nn.ReLU(inplace=True)]
+        if upsample_mode == 'convtranspose':
+            raise NotImplementedError("upsample mode [convtranspose] is not built on the HIP kernels ('pixelshuffle', the "
+                                      "reference default, and 'upconv' are)")
+        if upsample_mode not in ('pixelshuffle', 'upconv'):
+            raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
+        if nc % 64 or nc > 256:
+            raise NotImplementedError("SRMD: nc must be a multiple of 64 (at most 256) for the gfx950 kernels (reference default 128)")
+        layers = _layers(in_nc, nc, 'C' + act_mode[-1])
         for _ in range(nb - 2):
-            layers += [nn.Conv2d(nc, nc, 3, 1, 1, bias=True), nn.ReLU(inplace=True)]
-        layers += [nn.Conv2d(nc, out_nc * scale ** 2, 3, 1, 1, bias=True), nn.PixelShuffle(upscale_factor=scale)]
+            layers += _layers(nc, nc, 'C' + act_mode)
+        if upsample_mode == 'pixelshuffle':  # ref SRMD_blocks.py:123-126: conv(nc -> out_nc r^2) + PixelShuffle(r)
+            layers += _layers(nc, out_nc * scale ** 2, 'C' + str(scale))
+        else:  # ref SRMD_blocks.py:132-142: Upsample(nearest, r) + conv(nc -> out_nc)
+            layers += _layers(nc, out_nc, {2: 'UC', 3: 'uC', 4: 'vC'}[scale])
         self.model = nn.Sequential(*layers)
         self.scale, self.out_nc = scale, out_nc
 
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("SRMD: this network only runs on a HIP device (no CPU fallback); got a CPU tensor")
-        mods = list(self.model)
-        convs = [m for m in mods if isinstance(m, nn.Conv2d)]
         feat = ops.nchw_to_nhwc_pad(x)
-        chain = [(c.weight, c.bias, i < len(convs) - 1) for i, c in enumerate(convs)]
-        return ops.shuffle_rgb(ops.conv_chain(feat, chain), self.out_nc, self.scale)
+        mods, chain, shuffle = list(self.model), [], 1
+
+        def flush(t):
+            nonlocal chain
+            if chain:
+                t = ops.conv_chain(t, [tuple(c) for c in chain])
+                chain = []
+            return t
+
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Conv2d):
+                chain.append([m.weight, m.bias, 0])
+            elif isinstance(m, (nn.ReLU, nn.LeakyReLU)):
+                if isinstance(m, nn.LeakyReLU) and abs(m.negative_slope - 0.2) > 1e-12:
+                    raise NotImplementedError("LeakyReLU slope 0.2 only")
+                chain[-1][2] = 2 if isinstance(m, nn.LeakyReLU) else 1
+            elif isinstance(m, nn.BatchNorm2d):  # conv -> BN -> activation: the activation is folded into the batch-norm op
+                feat = flush(feat)
+                act = mods[i + 1] if i + 1 < len(mods) else None
+                slope = 0.2 if isinstance(act, nn.LeakyReLU) else (0.0 if isinstance(act, nn.ReLU) else 1.0)
+                feat = ops.batch_norm_act(feat, m, slope=slope)
+                if slope != 1.0:
+                    i += 1
+            elif isinstance(m, nn.Upsample):
+                feat = ops.nearest_up(flush(feat), int(m.scale_factor))
+            elif isinstance(m, nn.PixelShuffle):
+                shuffle = m.upscale_factor
+            i += 1
+        return ops.shuffle_rgb(flush(feat), self.out_nc, shuffle)
 
 
 class SRMDHandler(QModel):

@@ -72,3 +72,55 @@ def test_m3_oracle_trajectory_matches_the_reference():
         assert abs(loss - step["loss"]) < 2e-6 and abs(gn / step["grad_norm"] - 1) < 1e-4
         assert abs(float(out.mean()) - step["out_mean"]) < 1e-5 and abs(tr.lr - step["lr_after"]) < 1e-12
     assert abs(float(sum(v.double().sum() for v in tr.sd.values())) - ref["final_param_sum"]) < 1e-3
+
+
+# ---- the non-default act_mode / upsample_mode variants (ref advanced/architectures.py:385-411; fixtures m4)
+M4 = ["m4_srmd_BL_upconv", "m4_srmd_L", "m4_srmd_BR", "m4_srmd_R_upconv"]
+
+
+def _m4_digest(sd):
+    return digest({k: v for k, v in sd.items() if "running_" not in k and "num_batches" not in k})
+
+
+def _check_light(a, grads, rtol_norm, atol_rel, rtol_head):
+    # (a conv bias in front of a batch norm has an exactly zero gradient: what the fixture holds there is the reference's
+    # rounding noise, ~1e-6 of the other gradients -- hence the floor relative to the largest gradient norm)
+    floor = 1e-5 * max(float(a[k]) for k in a if k.startswith("pgn/"))
+    for k in [k[4:] for k in a if k.startswith("pgn/")]:
+        g = grads[k].detach().double().cpu()
+        n_ref = float(a["pgn/" + k])
+        assert abs(float(g.norm()) - n_ref) <= rtol_norm * n_ref + floor, (k, float(g.norm()), n_ref)
+        head = a["pgh/" + k]
+        np.testing.assert_allclose(g.reshape(-1)[:head.size].float().numpy(), head, rtol=rtol_head,
+                                   atol=atol_rel * float(np.abs(head).max()) + floor, err_msg=k)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("name", M4)
+def test_m4_variants_module_tree_and_oracle(name):
+    a, meta = load_golden(name)
+    torch.manual_seed(8)
+    net = sisr_amd.srmd.SRMD(**meta)
+    assert _m4_digest(net.state_dict()) == str(a["sd_sha256"]), "keys / seed-8 weights differ from the reference's"
+    sd = {}
+    for k, v in net.state_dict().items():
+        v = v.detach().clone()
+        sd[k] = v.requires_grad_(True) if v.dtype == torch.float32 and "running_" not in k else v
+    cfg = dict(nb=meta["nb"], scale=meta["scale"], act_mode=meta["act_mode"], upsample_mode=meta["upsample_mode"])
+    out = O.srmd(sd, torch.from_numpy(a["in0"]), training=True, **cfg)
+    np.testing.assert_allclose(out.detach().numpy(), a["out"], rtol=1e-5, atol=2e-6)
+    out.backward(torch.from_numpy(a["cot"]))
+    _check_light(a, {k: v.grad for k, v in sd.items() if v.requires_grad}, 2e-5, 1e-5, 1e-3)
+    for k in [k[4:] for k in a if k.startswith("buf/")]:
+        np.testing.assert_allclose(sd[k].numpy(), a["buf/" + k], rtol=1e-6, atol=1e-7, err_msg=k)
+    with torch.no_grad():
+        np.testing.assert_allclose(O.srmd(sd, torch.from_numpy(a["in0"]), training=False, **cfg).numpy(), a["out_eval"],
+                                   rtol=1e-5, atol=2e-6)
+
+
+def test_srmd_variants_that_are_not_built_say_so():
+    for kw in (dict(act_mode="IR"), dict(upsample_mode="convtranspose")):
+        with pytest.raises(NotImplementedError):
+            sisr_amd.srmd.SRMD(**kw)

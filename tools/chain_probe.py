@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--links", type=int, default=200)
     ap.add_argument("--bufs", type=int, default=8)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--weights", type=int, default=1, help="cycle over this many different packed weights (a step never reuses one)")
+    ap.add_argument("--forms", default="plain,mask", help="plain, mask, alt (the two alternating link by link)")
     a = ap.parse_args()
     B, H, W = a.batch, 128, 128
     dev = torch.device("cuda:0")
@@ -37,12 +39,13 @@ def main():
     b = torch.zeros(64).to(dev)
     sc, sh = torch.rand(B, 64, generator=g).to(dev), torch.rand(B, 64, generator=g).to(dev)
     v = hip.view_plain(H, W, 64)
-    pk = ops.pack_weight(w, "fwd")
+    pks = [ops.pack_weight(w + 0.001 * k, "fwd") for k in range(a.weights)]
     flop = 2.0 * B * H * W * 64 * 64 * 9
 
     def link(i, form, same):
         x, y = (maps[0], maps[1]) if same else (maps[i % a.bufs], maps[(i + 1) % a.bufs])
-        if form == "plain":
+        pk = pks[i % a.weights]
+        if form == "plain" or (form == "alt" and i % 2 == 0):
             ops.conv_c64(x, v, pk, b, (1, 64), y, v, B, H, W, 64, 64)
         else:
             ops.conv_c64(x, v, pk, None, (1, 64), y, v, B, H, W, 64, 64, mask=t1, in_scale=sc, in_shift=sh)
@@ -63,8 +66,8 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / a.reps / a.links
 
-    for form in ("plain", "mask"):
-        for same in (True, False):
+    for form in a.forms.split(","):
+        for same in (False,):
             us_eager = timed(lambda: chain(form, same))
             s = torch.cuda.Stream()
             gr = torch.cuda.CUDAGraph()
@@ -75,7 +78,7 @@ def main():
                     chain(form, same)
             torch.cuda.synchronize()
             us_graph = timed(gr.replay)
-            print(json.dumps({"batch": B, "form": form, "buffers": "same two" if same else "chain over %d" % a.bufs,
+            print(json.dumps({"batch": B, "form": form, "buffers": "same two" if same else "chain over %d" % a.bufs, "weights": a.weights,
                               "eager_us_per_link": round(us_eager, 2), "graph_us_per_link": round(us_graph, 2),
                               "graph_frac_of_peak": round(flop / us_graph / 1e6 / 157.3, 3)}), flush=True)
 

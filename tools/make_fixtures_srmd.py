@@ -6,6 +6,8 @@
 m1  reduced net (nc = 64, nb = 4) on an odd-sized 13-channel input: output, every parameter gradient
 m2  full-depth (nc = 128, nb = 12) seed-8 init digest + handler.run_eval on the Set5 images with their blur-kernel
     metadata (the handler builds the metadata maps itself: generate_sft_channels + channel concatenation)
+m4  reduced nets of the non-default variants: act_mode 'BL' / 'L' / 'BR' / 'R' with upsample_mode 'upconv' / 'pixelshuffle'
+    (python tools/make_fixtures_srmd.py m4 regenerates these alone)
 m3  five handler.run_train steps (Adam 1e-4, cosine warm restarts every 3 batches)
 """
 import json
@@ -43,6 +45,40 @@ def make_m1():
     blob["meta"] = np.array(json.dumps({"in_nc": 13, "nc": 64, "nb": 4, "scale": 4}))
     np.savez_compressed(os.path.join(OUT, "m1_srmd_reduced.npz"), **blob)
     print("m1_srmd_reduced out", tuple(out.shape))
+
+
+VARIANTS = {"m4_srmd_BL_upconv": dict(act_mode="BL", upsample_mode="upconv", scale=4),
+            "m4_srmd_L": dict(act_mode="L", upsample_mode="pixelshuffle", scale=2),
+            "m4_srmd_BR": dict(act_mode="BR", upsample_mode="pixelshuffle", scale=3),
+            "m4_srmd_R_upconv": dict(act_mode="R", upsample_mode="upconv", scale=2)}
+
+
+def make_m4():
+    """the non-default act_mode / upsample_mode variants (ref architectures.py:385-411), reduced nets in train() mode: output,
+    parameter gradients (norm + 64 leading values), batch-norm running statistics after the forward; seed-8 weights by SHA"""
+    for name, cfg in VARIANTS.items():
+        torch.manual_seed(8)
+        net = A.SRMD(in_nc=13, nc=64, nb=4, **cfg)
+        net.train()
+        sha = MF.sd_digest({k: v for k, v in net.state_dict().items() if "running_" not in k and "num_batches" not in k})
+        x = rnd(2, 13, 10, 12, seed=71, scale=0.5, grad=False)
+        out = net(x)
+        cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(72))
+        out.backward(cot)
+        blob = {"in0": _np(x), "out": _np(out), "cot": _np(cot), "sd_sha256": np.array(sha),
+                "meta": np.array(json.dumps(dict(in_nc=13, nc=64, nb=4, **cfg)))}
+        for k, p in net.named_parameters():
+            blob["pgn/" + k] = np.array(float(p.grad.double().norm()))
+            blob["pgh/" + k] = _np(p.grad.reshape(-1)[:64])
+        for k, v in net.state_dict().items():
+            if "running_" in k:
+                blob["buf/" + k] = _np(v)
+        net.eval()
+        with torch.no_grad():
+            blob["out_eval"] = _np(net(x))
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(f"{name:22s} {os.path.getsize(path) / 1e3:7.1f} KB out{tuple(out.shape)}")
 
 
 def make_m2():
@@ -94,7 +130,11 @@ def make_m3():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "m4":
+        make_m4()
+        sys.exit(0)
     make_m1()
+    make_m4()
     doc = {"full_depth": make_m2(), "train_steps": make_m3(), "params": PARAMS}
     with open(os.path.join(OUT, "m_srmd.json"), "w") as f:
         json.dump(doc, f, indent=1)
