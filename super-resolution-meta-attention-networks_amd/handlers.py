@@ -522,53 +522,28 @@ class ModelInterface:
 
     def __init__(self, model_loc, experiment, gpu='off', sp_gpu=0, mode='eval', new_params=None, load_epoch=None,
                  scale=None, save_subdir=None, new_branch=False):
-        if save_subdir is not None:
-            log_dir, save_dir = os.path.join('result_outputs', save_subdir), os.path.join('saved_models', save_subdir)
-        else:
-            log_dir, save_dir = 'result_outputs', 'saved_models'
-        self.experiment = experiment
-        self.base_folder = os.path.abspath(os.path.join(model_loc, experiment))
-        self.logs = os.path.abspath(os.path.join(self.base_folder, log_dir))
-        self.saved_models = os.path.abspath(os.path.join(self.base_folder, save_dir))
-        self.mode = mode
-        load_override = os.path.dirname(self.saved_models) if new_branch else None
-        if mode == 'train':
-            create_dir_if_empty(self.base_folder, self.logs, self.saved_models)
-            if new_params is None and load_epoch is None:
-                raise RuntimeError('Need to specify model parameters to train a new model.')
-        elif mode == 'eval':
-            if load_epoch is None:
-                raise RuntimeError('Need to specify which model epoch to load.')
-        if load_epoch is None:
-            self.model_epoch = 0
-            self.metadata = new_params
-        else:
-            if not glob.glob(os.path.join(self.base_folder, '*.toml')):
-                raise RuntimeError('No config.toml in %s - model structure unknown.' % self.base_folder)
-            import tomli
-            with open(os.path.join(self.base_folder, 'config.toml'), 'rb') as f:
-                self.metadata = tomli.load(f)['model']
-        self.name = self.metadata['name']
-        if self.name == 'qpircan':
-            self.name = 'qrcan'
-        if scale is not None and scale != self.metadata['internal_params']['scale']:
+        """Same contract as the reference's constructor: experiment folder layout (<model_loc>/<experiment>/{result_outputs,
+        saved_models}[/<save_subdir>]), parameters from `new_params` (new model) or the folder's config.toml (load_epoch given,
+        a number or 'best' / 'last'), the same refusals with the same messages."""
+        self.experiment, self.mode = experiment, mode
+        resuming = load_epoch is not None
+        self._lay_out(model_loc, experiment, save_subdir, create=mode == 'train')
+        if mode == 'train' and new_params is None and not resuming:
+            raise RuntimeError('Need to specify model parameters to train a new model.')
+        if mode == 'eval' and not resuming:
+            raise RuntimeError('Need to specify which model epoch to load.')
+        self.metadata = self._stored_parameters() if resuming else new_params
+        self.name = {'qpircan': 'qrcan'}.get(self.metadata['name'], self.metadata['name'])  # (a legacy spelling)
+        if scale not in (None, self.metadata['internal_params']['scale']):
             raise Exception('The model loaded has been trained for a different scale, '
                             'and cannot produce the requested images.')
-        if gpu != 'off' and torch.cuda.is_available():
-            self.device = sp_gpu
-        else:
-            self.device = torch.device('cpu')
+        self.device = sp_gpu if (gpu != 'off' and torch.cuda.is_available()) else torch.device('cpu')
         self.model = self.define_model(name=self.name, model_save_dir=self.saved_models, device=self.device,
-                                       eval_mode=True if mode == 'eval' else False,
-                                       **self.metadata['internal_params'])
-        if load_epoch is not None:
-            if load_epoch in ('best', 'last'):
-                import pandas as pd
-                col = pd.read_csv(os.path.join(self.logs, 'summary.csv'))['val-PSNR']
-                load_epoch = col.idxmax() if load_epoch == 'best' else len(col) - 1
-            self.model_epoch = load_epoch
-            self.model.load_model(model_save_name='train_model', model_idx=load_epoch, legacy=self.model.legacy_load,
-                                  load_override=load_override)
+                                       eval_mode=mode == 'eval', **self.metadata['internal_params'])
+        self.model_epoch = self._epoch_number(load_epoch) if resuming else 0
+        if resuming:
+            self.model.load_model(model_save_name='train_model', model_idx=self.model_epoch, legacy=self.model.legacy_load,
+                                  load_override=os.path.dirname(self.saved_models) if new_branch else None)
         else:
             self.model.pre_training_model_load()
         self.full_name = '%s_%d' % (experiment, self.model_epoch)
@@ -576,6 +551,28 @@ class ModelInterface:
             self.model.set_multi_gpu()
         self.configuration = {'input': self.model.im_input, 'colorspace': self.model.colorspace}
         self.print_overview()
+
+    def _lay_out(self, model_loc, experiment, save_subdir, create):
+        sub = (save_subdir,) if save_subdir is not None else ()
+        self.base_folder = os.path.abspath(os.path.join(model_loc, experiment))
+        self.logs = os.path.join(self.base_folder, 'result_outputs', *sub)
+        self.saved_models = os.path.join(self.base_folder, 'saved_models', *sub)
+        if create:
+            create_dir_if_empty(self.base_folder, self.logs, self.saved_models)
+
+    def _stored_parameters(self):
+        if not glob.glob(os.path.join(self.base_folder, '*.toml')):
+            raise RuntimeError('No config.toml in %s - model structure unknown.' % self.base_folder)
+        import tomli
+        with open(os.path.join(self.base_folder, 'config.toml'), 'rb') as f:
+            return tomli.load(f)['model']
+
+    def _epoch_number(self, load_epoch):
+        if load_epoch not in ('best', 'last'):
+            return load_epoch
+        import pandas as pd
+        psnr = pd.read_csv(os.path.join(self.logs, 'summary.csv'))['val-PSNR']
+        return psnr.idxmax() if load_epoch == 'best' else len(psnr) - 1
 
     def train_batch(self, lr, hr, **kwargs):
         return self.model.run_train(x=lr, y=hr, **kwargs)
