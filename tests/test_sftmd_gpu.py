@@ -212,11 +212,11 @@ def test_f4_non_default_options_vs_reference(name):
     """SFT_type 'concat' / 'weak' / 'none', mask_para, repeats, q_injection with 2 and 3 FC layers (fixture f4: the reference's
     output and per-parameter gradient norms / leading values on reduced x2 nets).
 
-    'weak1' is compared at 1e-3: one of the 59 904 pre-activations of the upscale stage's LeakyReLU lies within 2.3e-7 of zero
-    (|x| up to 0.24) and the MFMA conv's summation order lands on the other side of it than the reference's (measured: 1 sign
-    flip vs a float64 evaluation, torch fp32 0; the kernels fed the reference's own activations agree to 2e-7).  With 74 % of
-    the outputs clamped the gradient is sparse, and that single mask element moves every upstream gradient by 2e-3."""
-    tol = 1e-3 if name == "weak1" else 2e-4
+    'weak1': its input is the one of 100 candidates whose closest LeakyReLU pre-activation lies furthest from zero (4.2e-6;
+    tools/make_fixtures_sftmd.py) -- with round 2's input one of 59 904 lay 2.3e-7 from the kink, the MFMA conv's summation
+    order landed on the other side of it than the reference's, and that single mask bit moved every upstream gradient by
+    2e-3.  Same tolerance as the other variants now."""
+    tol = 2e-4
     a = np.load(f"{sisr_amd.__path__[0]}/../tests/golden/f4_sftmd_variants.npz")
     net, kw, vector = variant_net(name)
     net.to("cuda:0")

@@ -110,6 +110,20 @@ VARIANTS = {  # name: (SFTMD kwargs, metadata is per-sample vectors (q_injection
 }
 
 
+def _min_preactivation(net, x, md):
+    """smallest |input| any LeakyReLU of the net sees on (x, md): a value within ~1e-6 of the kink takes either slope depending
+    on the last bit of a conv's summation order -- inputs are chosen away from it (see make_f4)"""
+    lo, hooks = [float("inf")], []
+    for m in net.modules():
+        if isinstance(m, torch.nn.LeakyReLU):
+            hooks.append(m.register_forward_pre_hook(lambda mod, inp: lo.__setitem__(0, min(lo[0], float(inp[0].abs().min())))))
+    with torch.no_grad():
+        net(x.clone(), md.clone())
+    for h in hooks:
+        h.remove()
+    return lo[0]
+
+
 def make_f4():
     blob = {}
     for name, (kw, vector) in VARIANTS.items():
@@ -117,6 +131,16 @@ def make_f4():
         net = SFTMD(num_features=64, num_blocks=2, scale=2, **{"in_nc": 3, **kw})
         M = kw["input_para"]
         x = rnd(2, 3, 9, 13, seed=91, scale=0.3, grad=False) + 0.5
+        if name == "weak1":
+            # seed 91 puts one of this variant's 59 904 upscale-stage pre-activations 2.3e-7 from zero (found in round 2: the
+            # HIP path and the reference then disagree on one mask bit).  With ~300 k LeakyReLU inputs the closest to zero is
+            # typically 1e-6 away; of 100 candidate inputs take the one whose closest is furthest (fp32 summation-order
+            # differences at these magnitudes are ~2e-8)
+            md0 = (rnd(2, M, 1, 1, seed=92, scale=0.3, grad=False) + 1.0).expand(2, M, 9, 13).contiguous()
+            best = max(range(91, 191), key=lambda sd_: _min_preactivation(
+                net, rnd(2, 3, 9, 13, seed=sd_, scale=0.3, grad=False) + 0.5, md0))
+            x = rnd(2, 3, 9, 13, seed=best, scale=0.3, grad=False) + 0.5
+            print("f4 weak1: input seed", best, "closest LeakyReLU input to zero", _min_preactivation(net, x, md0))
         md = rnd(2, M, 1, 1, seed=92, scale=0.3, grad=False) + (1.0 if name == "weak1" else 0.0)
         if not vector:
             md = md.expand(2, M, 9, 13).contiguous()
