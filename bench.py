@@ -359,13 +359,18 @@ def main():
         finally:
             sisr.ops.set_precision("fp32")
         gbs = sh["value"] * HBM_GB_PER_PATCH["han"]
+        tfam16 = None
+        tj16 = os.path.join(ROOT, "profiles", "traffic_conv3x3_c64_bf16.json")
+        if os.path.exists(tj16):
+            with open(tj16) as f:
+                tfam16 = json.load(f).get("families_b32")  # measured / algorithmic HBM bytes per launch of the bf16 kernels
         han16 = {"workload": "HAN x4 full depth, 16 tiles of 128x128, train step (BASELINE config 5)",
                  "dtype": "bf16 MFMA operands (rounded while staged into LDS), f32 accumulate, f32 feature maps / gradients / "
                           "optimiser state in HBM", "value": sh["value"], "unit": "patches/s", "ms_per_step": sh["ms_per_step"],
                  "final_loss": sh["loss"],
                  "roofline": {"bound": "hbm", "what": "whole step: algorithmic bytes per patch of the storage format in use "
                               "(fp32 maps, 17.0 GB per patch fwd+bwd) x patches/s", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic_families": tfam16,
                               "secondary": {"bound": "mfma", "achieved": sh["value"] * sh["tflop_per_patch"], "peak": 2500.0,
                                             "unit": "TFLOP/s", "frac": sh["value"] * sh["tflop_per_patch"] / 2500.0}},
                  "parity": "unpinned against the reference (it has no reduced-precision mode); pinned against the oracle's "
