@@ -513,9 +513,9 @@ def chop_forward(run, x, scale, max_pixels=160000, shave=10):
 def srmd(sd, x, nb=12, scale=4, act_mode="R", upsample_mode="pixelshuffle", training=True):
     """ref: advanced/architectures.py:380-425 with advanced/SRMD_blocks.py:33-142: x is the (3+M)-channel input (RGB + metadata
     maps).  The model is a flat Sequential with one module per character of the mode strings: head 'C' + act_mode[-1], body
-    ('C' + act_mode) x (nb - 2), tail 'C' + str(scale) (conv + PixelShuffle) or Upsample(nearest) + conv ('upconv').  'B' is
+    ('C' + act_mode) x (nb - 2), tail 'C' + str(scale) (conv + PixelShuffle), Upsample(nearest) + conv ('upconv') or one ConvTranspose2d ('convtranspose').  'B' is
     BatchNorm2d(momentum=0.9, eps=1e-4): batch statistics when `training` (running statistics in `sd` updated in place)."""
-    tail = "C" + str(scale) if upsample_mode == "pixelshuffle" else {2: "UC", 3: "uC", 4: "vC"}[scale]
+    tail = {"pixelshuffle": "C" + str(scale), "upconv": {2: "UC", 3: "uC", 4: "vC"}[scale], "convtranspose": "T"}[upsample_mode]
     y = x
     for i, t in enumerate("C" + act_mode[-1] + ("C" + act_mode) * (nb - 2) + tail):
         key = f"model.{i}"
@@ -524,6 +524,10 @@ def srmd(sd, x, nb=12, scale=4, act_mode="R", upsample_mode="pixelshuffle", trai
         elif t == "B":
             y = F.batch_norm(y, sd[key + ".running_mean"], sd[key + ".running_var"], sd[key + ".weight"], sd[key + ".bias"],
                              training=training, momentum=0.9, eps=1e-4)
+        elif t == "I":  # nn.InstanceNorm2d(affine=True): per-sample statistics in train() and eval() alike
+            y = F.instance_norm(y, weight=sd[key + ".weight"], bias=sd[key + ".bias"], eps=1e-5)
+        elif t == "T":  # ConvTranspose2d(kernel = stride = scale, padding 0)
+            y = F.conv_transpose2d(y, sd[key + ".weight"], sd[key + ".bias"], stride=scale)
         elif t in "Rr":
             y = F.relu(y)
         elif t in "Ll":

@@ -111,8 +111,10 @@ def _side_ok(*weights, pixels=None):
     on the main stream).
     Weight gradients may be produced on the side stream (which re-joins the main stream only at the end of the
     backward pass) iff autograd will merely ADOPT them: with an existing .grad AccumulateGrad would run
-    `p.grad += dw` on the main stream before the side-stream kernel has written dw."""
-    if not (WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False and all(w.grad is None for w in weights)):
+    `p.grad += dw` on the main stream before the side-stream kernel has written dw.  The same holds for a weight that is not a
+    leaf (one computed from parameters, e.g. SRMD's transposed-conv tail): its gradient is consumed by further backward nodes
+    on the main stream at once."""
+    if not (WGRAD_SIDE_STREAM and torch.is_grad_enabled() is False and all(w.is_leaf and w.grad is None for w in weights)):
         return False
     if _DEFERRED is not None and pixels is not None and PRECISION == "fp32" and pixels <= BATCH_WGRAD_MAX_PIXELS:
         return False
@@ -1654,6 +1656,19 @@ class _NearestUp(Function):
 
 def nearest_up(x, up):
     return _NearestUp.apply(x, int(up))
+
+
+def instance_norm_act(x, norm, slope=1.0):
+    """LeakyReLU(slope)(InstanceNorm2d(x)) (ref: advanced/SRMD_blocks.py:44-45 'I': nn.InstanceNorm2d(affine=True), statistics per
+    sample and channel over H x W, in train() and eval() alike -- it tracks no running statistics).  Instance norm of a batch =
+    batch norm of each sample on its own: the batch-norm kernels run once per sample (the affine parameters' gradients add up
+    over the samples in autograd), and the normalised samples are concatenated."""
+    if getattr(norm, "track_running_stats", False):
+        raise NotImplementedError("InstanceNorm2d(track_running_stats=True) is not built")
+    eps = float(norm.eps)
+    outs = [_BatchNormAct.apply(x[b:b + 1], norm.weight, norm.bias, None, None, True, 0.0, eps, float(slope))
+            for b in range(x.shape[0])]
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
 class _SparCombine(Function):

@@ -38,23 +38,21 @@ def _layers(in_channels, out_channels, mode, negative_slope=0.2):
         elif t in 'Uuv':
             out.append(nn.Upsample(scale_factor={'U': 2, 'u': 3, 'v': 4}[t], mode='nearest'))
         elif t == 'I':
-            raise NotImplementedError("SRMD act_mode with InstanceNorm ('IR' / 'IL') is not built on the HIP kernels")
+            out.append(nn.InstanceNorm2d(out_channels, affine=True))
         else:
             raise NotImplementedError('Undefined type: ' + t)
     return out
 
 
 class SRMD(nn.Module):
-    """ref: advanced/architectures.py:380-425.  act_mode 'R' (the reference default), 'L', 'BR', 'BL' (and the non-inplace 'r' /
-    'l' spellings); upsample_mode 'pixelshuffle' (default) and 'upconv' (nearest upsample + conv)."""
+    """ref: advanced/architectures.py:380-425.  act_mode 'R' (the reference default), 'L', 'BR', 'BL', 'IR', 'IL' (and the
+    non-inplace 'r' / 'l' spellings); upsample_mode 'pixelshuffle' (default), 'upconv' (nearest upsample + conv) and
+    'convtranspose' (ConvTranspose2d with kernel = stride = scale)."""
 
     def __init__(self, in_nc=18, out_nc=3, nc=128, nb=12, scale=4, act_mode='R', upsample_mode='pixelshuffle', **kwargs):
         super().__init__()
         assert 'R' in act_mode or 'L' in act_mode, 'Examples of activation function: R, L, BR, BL, IR, IL'
-        if upsample_mode == 'convtranspose':
-            raise NotImplementedError("upsample mode [convtranspose] is not built on the HIP kernels ('pixelshuffle', the "
-                                      "reference default, and 'upconv' are)")
-        if upsample_mode not in ('pixelshuffle', 'upconv'):
+        if upsample_mode not in ('pixelshuffle', 'upconv', 'convtranspose'):
             raise NotImplementedError('upsample mode [{:s}] is not found'.format(upsample_mode))
         if nc % 64 or nc > 256:
             raise NotImplementedError("SRMD: nc must be a multiple of 64 (at most 256) for the gfx950 kernels (reference default 128)")
@@ -63,8 +61,10 @@ class SRMD(nn.Module):
             layers += _layers(nc, nc, 'C' + act_mode)
         if upsample_mode == 'pixelshuffle':  # ref SRMD_blocks.py:123-126: conv(nc -> out_nc r^2) + PixelShuffle(r)
             layers += _layers(nc, out_nc * scale ** 2, 'C' + str(scale))
-        else:  # ref SRMD_blocks.py:132-142: Upsample(nearest, r) + conv(nc -> out_nc)
+        elif upsample_mode == 'upconv':  # ref SRMD_blocks.py:132-142: Upsample(nearest, r) + conv(nc -> out_nc)
             layers += _layers(nc, out_nc, {2: 'UC', 3: 'uC', 4: 'vC'}[scale])
+        else:  # ref SRMD_blocks.py:148-154: ConvTranspose2d(nc, out_nc, kernel_size = stride = r, padding 0)
+            layers.append(nn.ConvTranspose2d(nc, out_nc, kernel_size=scale, stride=scale, padding=0, bias=True))
         self.model = nn.Sequential(*layers)
         self.scale, self.out_nc = scale, out_nc
 
@@ -90,13 +90,24 @@ class SRMD(nn.Module):
                 if isinstance(m, nn.LeakyReLU) and abs(m.negative_slope - 0.2) > 1e-12:
                     raise NotImplementedError("LeakyReLU slope 0.2 only")
                 chain[-1][2] = 2 if isinstance(m, nn.LeakyReLU) else 1
-            elif isinstance(m, nn.BatchNorm2d):  # conv -> BN -> activation: the activation is folded into the batch-norm op
+            elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d)):  # conv -> norm -> activation: one op (activation folded in)
                 feat = flush(feat)
                 act = mods[i + 1] if i + 1 < len(mods) else None
                 slope = 0.2 if isinstance(act, nn.LeakyReLU) else (0.0 if isinstance(act, nn.ReLU) else 1.0)
-                feat = ops.batch_norm_act(feat, m, slope=slope)
+                feat = (ops.batch_norm_act if isinstance(m, nn.BatchNorm2d) else ops.instance_norm_act)(feat, m, slope=slope)
                 if slope != 1.0:
                     i += 1
+            elif isinstance(m, nn.ConvTranspose2d):
+                # kernel = stride = r, no padding: every LR pixel maps its nc features to r x r output pixels of out_nc channels
+                # -- a 1 x 1 conv to out_nc r^2 channels in PixelShuffle order.  It runs as the centre tap of a 3 x 3 conv on the
+                # MFMA kernel (the eight zero taps are wasted arithmetic on one small layer; gradients reach m.weight through the
+                # index arithmetic below), followed by the same shuffle gather as the default tail.
+                r, co = m.stride[0], m.out_channels
+                w1 = m.weight.permute(1, 2, 3, 0).reshape(co * r * r, m.in_channels)  # [(o, i, j), c] = W[c, o, i, j]
+                w3 = torch.zeros(co * r * r, m.in_channels, 3, 3, device=w1.device, dtype=w1.dtype)
+                w3[:, :, 1, 1] = w1
+                chain.append([w3, m.bias.repeat_interleave(r * r) if m.bias is not None else None, 0])
+                shuffle = r
             elif isinstance(m, nn.Upsample):
                 feat = ops.nearest_up(flush(feat), int(m.scale_factor))
             elif isinstance(m, nn.PixelShuffle):

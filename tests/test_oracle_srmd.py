@@ -75,7 +75,7 @@ def test_m3_oracle_trajectory_matches_the_reference():
 
 
 # ---- the non-default act_mode / upsample_mode variants (ref advanced/architectures.py:385-411; fixtures m4)
-M4 = ["m4_srmd_BL_upconv", "m4_srmd_L", "m4_srmd_BR", "m4_srmd_R_upconv"]
+M4 = ["m4_srmd_BL_upconv", "m4_srmd_L", "m4_srmd_BR", "m4_srmd_R_upconv", "m4_srmd_IL_convtranspose", "m4_srmd_IR_convtranspose"]
 
 
 def _m4_digest(sd):
@@ -120,7 +120,8 @@ def test_m4_variants_module_tree_and_oracle(name):
                                    rtol=1e-5, atol=2e-6)
 
 
-def test_srmd_variants_that_are_not_built_say_so():
-    for kw in (dict(act_mode="IR"), dict(upsample_mode="convtranspose")):
-        with pytest.raises(NotImplementedError):
-            sisr_amd.srmd.SRMD(**kw)
+def test_srmd_rejects_what_the_reference_rejects():
+    with pytest.raises(NotImplementedError):  # ref architectures.py:404-405
+        sisr_amd.srmd.SRMD(upsample_mode="bilinear")
+    with pytest.raises(AssertionError):  # ref architectures.py:395
+        sisr_amd.srmd.SRMD(act_mode="B")

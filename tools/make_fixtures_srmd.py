@@ -50,7 +50,9 @@ def make_m1():
 VARIANTS = {"m4_srmd_BL_upconv": dict(act_mode="BL", upsample_mode="upconv", scale=4),
             "m4_srmd_L": dict(act_mode="L", upsample_mode="pixelshuffle", scale=2),
             "m4_srmd_BR": dict(act_mode="BR", upsample_mode="pixelshuffle", scale=3),
-            "m4_srmd_R_upconv": dict(act_mode="R", upsample_mode="upconv", scale=2)}
+            "m4_srmd_R_upconv": dict(act_mode="R", upsample_mode="upconv", scale=2),
+            "m4_srmd_IL_convtranspose": dict(act_mode="IL", upsample_mode="convtranspose", scale=2),
+            "m4_srmd_IR_convtranspose": dict(act_mode="IR", upsample_mode="convtranspose", scale=3)}
 
 
 def make_m4():
