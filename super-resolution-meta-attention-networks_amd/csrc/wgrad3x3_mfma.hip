@@ -912,17 +912,18 @@ struct ReduceParams {
   unsigned char unit_map[WG_MAX_UNITS];
 };
 
-// blockDim = (64, RG): x = element within a 64-run (coalesced across slabs), y = slab group (S split RG ways, up to
-// 8 loads in flight per thread; with RG = 16 the 128 slabs of a 64 -> 64 gradient are one round of loads); the
-// group sums are added in group order through LDS.  Latency-bound (5.5 us stand-alone for 18.9 MB of slabs), so the
-// point of RG is parallelism.
+// blockDim = (64, RG): x = a run of FOUR consecutive elements (one 16-byte load per slab; 256 elements per workgroup), y = slab
+// group (S split RG ways, up to 8 loads in flight per thread; with RG = 16 the 128 slabs of a 64 -> 64 gradient are one round
+// of loads); the group sums are added in group order through LDS -- per element the same order as summing slab by slab
+// within a group, then the groups.  Bound by the slabs' bytes and the memory latency (37.8 MB per 64 -> 64 gradient of the
+// one-workgroup-per-CU kernel; dword loads needed four times the instructions: 15.7 -> ~9 us for a batch of eight at 4 tiles).
 #define RG 16
 static __device__ __forceinline__ void wgrad_reduce_body(const ReduceParams& p) {
-  __shared__ float red[RG][64];
+  __shared__ __attribute__((aligned(16))) float red[RG][64][4];
   const long total = (long)p.units * SLAB;
-  const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+  const long gid = ((long)blockIdx.x * 64 + threadIdx.x) * 4;
   const int grp = threadIdx.y;
-  float s = 0.f;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
   const bool is_w = gid < total;
   const long j = gid - total;
   const bool is_b = !is_w && p.db && j < (long)p.cout_chunks * 64;
@@ -931,35 +932,40 @@ static __device__ __forceinline__ void wgrad_reduce_body(const ReduceParams& p) 
     const long stride = is_w ? (long)p.units * SLAB : (long)p.cout_chunks * 64;
     int k = grp;
     for (; k + 7 * RG < p.S; k += 8 * RG) {
-      float t[8];
+      f32x4 t[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = src[(long)(k + RG * u) * stride];
+      for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (long)(k + RG * u) * stride);
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += t[u];
     }
-    for (; k < p.S; k += RG) s += src[(long)k * stride];
+    for (; k < p.S; k += RG) s += *reinterpret_cast<const f32x4*>(src + (long)k * stride);
   }
-  red[grp][threadIdx.x] = s;
+  *reinterpret_cast<f32x4*>(red[grp][threadIdx.x]) = s;
   __syncthreads();
   if (grp != 0) return;
-  s = red[0][threadIdx.x];
+  s = *reinterpret_cast<const f32x4*>(red[0][threadIdx.x]);
 #pragma unroll
-  for (int g = 1; g < RG; ++g) s += red[g][threadIdx.x];
-  if (is_w) {
-    const int urow = (int)(gid / SLAB);
-    const int e = (int)(gid - (long)urow * SLAB);
-    const int unit = p.mapped ? p.unit_map[urow] : urow;
-    const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
-    const int quad = unit & 3, pair = unit >> 2;
-    const int cq = pair % p.cout_chunks, cc = pair / p.cout_chunks;
-    const int ci = (quad >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-    const int co = (quad & 1) * 32 + (l & 31);
-    const long o = (long)co * p.on + (long)cq * p.oq;
-    const long ii = (long)ci * p.in_ + (long)cc * p.iq;
-    p.dw[o * p.so + ii * p.si + (p.flip ? 8 - t : t)] = s * p.alpha;
-  } else if (is_b) {
-    const int cq = (int)(j >> 6), co = (int)(j & 63);
-    p.db[(long)co * p.bias_n + (long)cq * p.bias_q] = s * p.alpha;
+  for (int g = 1; g < RG; ++g) s += *reinterpret_cast<const f32x4*>(red[g][threadIdx.x]);
+#pragma unroll
+  for (int e4 = 0; e4 < 4; ++e4) {
+    if (is_w) {
+      const long ge = gid + e4;
+      const int urow = (int)(ge / SLAB);
+      const int e = (int)(ge - (long)urow * SLAB);
+      const int unit = p.mapped ? p.unit_map[urow] : urow;
+      const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
+      const int quad = unit & 3, pair = unit >> 2;
+      const int cq = pair % p.cout_chunks, cc = pair / p.cout_chunks;
+      const int ci = (quad >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      const int co = (quad & 1) * 32 + (l & 31);
+      const long o = (long)co * p.on + (long)cq * p.oq;
+      const long ii = (long)ci * p.in_ + (long)cc * p.iq;
+      p.dw[o * p.so + ii * p.si + (p.flip ? 8 - t : t)] = s[e4] * p.alpha;
+    } else if (is_b) {
+      const long je = j + e4;
+      const int cq = (int)(je >> 6), co = (int)(je & 63);
+      p.db[(long)co * p.bias_n + (long)cq * p.bias_q] = s[e4] * p.alpha;
+    }
   }
 }
 
@@ -1104,7 +1110,7 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   r.bias_n = bias_n;
   r.bias_q = bias_q;
   const long total = (long)units * SLAB + (dbias ? cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, RG), 0, (hipStream_t)stream, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(64, RG), 0, (hipStream_t)stream, r);
   return sisr_check_launch();
 }
 
@@ -1193,7 +1199,7 @@ extern "C" int sisr_wgrad3x3_c64_batch(const void* jobs_host, int njobs, const i
   int rc = sisr_check_launch();
   if (rc) return rc;
   const long total = 4L * SLAB + 64;  // bias rows past the weights; jobs without a bias skip them inside (db == null)
-  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((total + 63) / 64), njobs), dim3(64, RG), 0, (hipStream_t)stream, rb);
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((total + 255) / 256), njobs), dim3(64, RG), 0, (hipStream_t)stream, rb);
   return sisr_check_launch();
 }
 
@@ -1270,7 +1276,7 @@ extern "C" int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, cons
   r.bias_n = bias_n;
   r.bias_q = bias_q;
   const long total = (long)units * SLAB + (dbias ? cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, RG), 0, (hipStream_t)stream, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(64, RG), 0, (hipStream_t)stream, r);
   return sisr_check_launch();
 }
 
@@ -1347,6 +1353,6 @@ extern "C" int sisr_wgrad3x3_c64_x3(const float* x, const int64_t* xview, const 
   r.bias_n = bias_n;
   r.bias_q = bias_q;
   const long total = (long)units * SLAB + (dbias ? cout : 0);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, RG), 0, (hipStream_t)stream, r);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(64, RG), 0, (hipStream_t)stream, r);
   return sisr_check_launch();
 }
