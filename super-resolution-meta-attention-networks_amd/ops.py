@@ -1625,7 +1625,7 @@ class _BatchNormAct(Function):
 def batch_norm_act(x, bn, slope=1.0):
     """bn: an nn.BatchNorm2d (parameter / buffer holder); slope: LeakyReLU slope folded in (1 = none)."""
     training = bn.training or bn.running_mean is None
-    if bn.training and bn.num_batches_tracked is not None:
+    if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_sisr_counted_by_net", False):
         bn.num_batches_tracked += 1  # as nn.BatchNorm2d.forward does (momentum is a number here: the average is exponential)
     if bn.momentum is None:
         raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not built")

@@ -228,6 +228,18 @@ def _rgb_in(img):
     return ops.nchw_to_nhwc_pad(img)
 
 
+def _count_batches(net):
+    """nn.BatchNorm2d.forward adds one to num_batches_tracked per training forward: the network's ~190 counters in one
+    multi-tensor add instead of ~190 one-element kernels (the batch-norm op then leaves them alone)."""
+    if not net.training:
+        return
+    bns = [m for m in net.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+    for m in bns:
+        m._sisr_counted_by_net = True
+    if bns:
+        torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+
+
 class SPARNet(nn.Module):
     """ref: architectures.py:7-76"""
 
@@ -238,6 +250,7 @@ class SPARNet(nn.Module):
                bottleneck_size, None, False)
 
     def forward(self, input_img):
+        _count_batches(self)
         out = self.encoder(_rgb_in(input_img))
         out = self.res_layers(out)
         out = self.decoder(out)
@@ -255,6 +268,7 @@ class QSPARNet(nn.Module):
                bottleneck_size, metadata_count, metadata_encoder_only)
 
     def forward(self, input_img, metadata):
+        _count_batches(self)
         out, _ = self.encoder((_rgb_in(input_img), metadata))
         out, _ = self.res_layers((out, metadata))
         out, _ = self.decoder((out, metadata))
