@@ -213,6 +213,9 @@ class BaseModel(nn.Module):
                 kw = dict(kwargs)
                 if se is not None:
                     kw['extra_channels'] = se
+                # The warm-up pass below is a real forward: a network with batch norms (SPARNet) would advance its running
+                # statistics and step counters once more than the eager path does for this batch.  Buffers are put back after it.
+                saved_buffers = [(b, b.detach().clone()) for b in self.net.buffers()]
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):  # one eager pass off the default stream: allocator + lazy-init warm-up
@@ -222,6 +225,9 @@ class BaseModel(nn.Module):
                         self.criterion(self.run_model(sx, **kw), sy).backward()
                 torch.cuda.current_stream().wait_stream(side)
                 self.optimizer.zero_grad(set_to_none=True)
+                with torch.no_grad():
+                    for b, keep in saved_buffers:
+                        b.copy_(keep)
                 graph = torch.cuda.CUDAGraph()
                 dump = os.environ.get("SISR_GRAPH_DUMP")  # diagnostic: write the captured graph as a DOT file
                 if dump:
