@@ -32,6 +32,7 @@ Extra objects on the JSON line:
                 hipGraph -- with its own whole-step fraction and per-family launch times.
   han_bf16      N=1 default run only: BASELINE config 5 (HAN x4, bf16 matrix-core operands, 16 tiles), roofline bound "hbm"
                 against the bytes of the storage format in use (fp32 maps).
+  inference     N=1 default run only: RCAN x4 forward only through the handler's run_eval (32 tiles, output kept on the device).
 """
 import argparse
 import json
@@ -248,6 +249,34 @@ def measure(sisr, workload, B, steps, warmup, use_graph, rank, world, local, dev
     return res
 
 
+def measure_eval(sisr, workload, B, steps, warmup, local, dev):
+    """Forward-only throughput through the handler's run_eval (the reference's inference entry point, ref
+    SISR/models/__init__.py:491-533), output left on the device: weight packing + forward under no_grad per call."""
+    name, params, tflop_per_patch = WORKLOADS[workload]
+    params = dict(params)
+    params.pop("maps", None)
+    params.pop("hr_same", None)
+    torch.manual_seed(8)
+    h = sisr.available_models[name](device=local, model_save_dir="/tmp", eval_mode=True, scale=4, **params)
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(B, 3, 128, 128, generator=g).to(dev)
+    for _ in range(warmup):
+        h.run_eval(x, keep_on_device=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        h.run_eval(x, keep_on_device=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del h, x
+    torch.cuda.empty_cache()
+    v = B * steps / dt
+    return {"workload": f"{name.upper()} x4 full depth, forward only (run_eval, output kept on the device), {B} tiles of 128x128",
+            "value": v, "unit": "patches/s", "ms_per_batch": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+            "algorithmic_tflops": v * tflop_per_patch / 3.0,
+            "frac_of_fp32_mfma_peak": v * tflop_per_patch / 3.0 / FP32_MFMA_PEAK_TFLOPS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,6 +407,10 @@ def main():
                  "parity": "unpinned against the reference (it has no reduced-precision mode); pinned against the oracle's "
                            "bf16 restatement and, statistically, against fp32 (tests/test_bf16_gpu.py)"}
 
+    infer = None
+    if not explicit and not args.no_secondary and args.precision == "fp32" and world == 1:
+        infer = measure_eval(sisr, "rcan", 32, max(2, min(args.steps, 10)), min(args.warmup, 3), local, dev)
+
     x3 = None
     if not explicit and not args.no_secondary and args.precision == "fp32" and world == 1:
         # second line asked for by the round-1 review: the same step with the convs as bf16x3 splits
@@ -456,6 +489,8 @@ def main():
             line["han_bf16"] = han16
         if x3 is not None:
             line["bf16x3"] = x3
+        if infer is not None:
+            line["inference"] = infer
         if world == 1 and not args.no_cpu_baseline and args.precision == "fp32":
             line["cpu_baseline"] = cpu_baseline(workload)
         print(json.dumps(line), flush=True)
