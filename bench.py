@@ -336,13 +336,17 @@ def main():
     if not explicit and not args.no_secondary and args.precision == "fp32":
         # N = 1: the north_star family beside BASELINE's configs[1]; N > 1: the weak-scaling point beside config 4
         ssteps = max(2, min(args.steps, 5))
-        s = measure(sisr, "qrcan", 32, ssteps, min(args.warmup, 2), False, rank, world, local, dev)
-        secondary = ("meta_rcan" if world == 1 else "weak_scaling", {
-            "workload": "QRCAN (RCAN + meta-attention, style 'standard', q-layers on) x4 full depth, same train step",
-            "value": s["value"], "unit": "patches/s", "ms_per_step": s["ms_per_step"], "steps": ssteps,
-            "per_gpu_batch": 32, "global_batch": 32 * world, "n_gpus": world,
-            "algorithmic_tflops_per_gpu": s["value"] / world * s["tflop_per_patch"],
-            "frac_of_fp32_mfma_peak": s["value"] / world * s["tflop_per_patch"] / FP32_MFMA_PEAK_TFLOPS})
+        skey = "meta_rcan" if world == 1 else "weak_scaling"
+        try:
+            s = measure(sisr, "qrcan", 32, ssteps, min(args.warmup, 2), False, rank, world, local, dev)
+            secondary = (skey, {
+                "workload": "QRCAN (RCAN + meta-attention, style 'standard', q-layers on) x4 full depth, same train step",
+                "value": s["value"], "unit": "patches/s", "ms_per_step": s["ms_per_step"], "steps": ssteps,
+                "per_gpu_batch": 32, "global_batch": 32 * world, "n_gpus": world,
+                "algorithmic_tflops_per_gpu": s["value"] / world * s["tflop_per_patch"],
+                "frac_of_fp32_mfma_peak": s["value"] / world * s["tflop_per_patch"] / FP32_MFMA_PEAK_TFLOPS})
+        except Exception as e:  # the side measurement must not cost the run its headline line
+            secondary = (skey, {"error": repr(e)})
 
     c4 = han16 = None
     if not explicit and not args.no_secondary and args.precision == "fp32" and world == 1:
