@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: LR-patches/s (128x128x3 -> x4) for one training step on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its N ranks itself,
+                                                            as a child `python -m torch.distributed.run ...`, and relays the line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -33,6 +34,13 @@ Extra objects on the JSON line:
   han_bf16      N=1 default run only: BASELINE config 5 (HAN x4, bf16 matrix-core operands, 16 tiles), roofline bound "hbm"
                 against the bytes of the storage format in use (fp32 maps).
   inference     N=1 default run only: RCAN x4 forward only through the handler's run_eval (32 tiles, output kept on the device).
+  meta_edsr     N=1 default run only: BASELINE config 3 (QEDSR = EDSR-baseline + a meta-attention layer per block), 32 tiles.
+  b1_point      N=1 default run only: ONE tile per step (the per-GPU batch SURVEY 8 puts configs 2 and 3 at, and the batch
+                cpu_baseline is timed at): RCAN and QEDSR, forward+backward replayed from a hipGraph.
+  overlapped_grad_exchange   N > 1 default run only: the same workload with the replay's gradient exchange overlapped with its
+                backward (opt-in SISR_GRAPH_OVERLAP=1), measured last under a watchdog; config.grad_exchange names the mode
+                the headline ran.
+Every auxiliary object is measured inside its own try block: an error lands under that object's key as {"error": ...}.
 """
 import argparse
 import json
@@ -185,6 +193,42 @@ def cpu_baseline(workload, seconds_budget=30.0):
     return out
 
 
+def pmc_traffic(kind):
+    """tools/traffic_from_pmc.py derive(kind) -- HBM bytes per launch from the committed PMC summaries -- or None without them."""
+    import importlib.util
+    try:
+        spec = importlib.util.spec_from_file_location("traffic_from_pmc", os.path.join(ROOT, "tools", "traffic_from_pmc.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod.derive(kind)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a CHILD process (never exec: this parent has not touched the GPU and must not), one rank per GPU over RCCL,
+    pass rank 0's JSON line through on stdout, and return the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in child.stdout:  # ranks other than 0 print nothing on stdout; the launcher's own chatter goes to stderr
+        if ln.lstrip().startswith("{"):
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(ln)
+    return child.wait()
+
+
 def measure(sisr, workload, B, steps, warmup, use_graph, rank, world, local, dev, families=False, dp=False):
     """Build the handler, run warm-up + exactly `steps` timed steps (barrier + sync on both sides, max over ranks)."""
     name, params, tflop_per_patch = WORKLOADS[workload]
@@ -243,7 +287,12 @@ def measure(sisr, workload, B, steps, warmup, use_graph, rank, world, local, dev
             timer.remove()
         res["timer"] = timer
     if h.reducer is not None:
-        h.reducer.remove()
+        res["grad_exchange"] = (("hipGraph replay; buckets released by signal nodes of the replay, all-reduce on the reducer stream beside the "
+                                 "rest of the captured backward (SISR_GRAPH_OVERLAP=%s)" % os.environ.get("SISR_GRAPH_OVERLAP", "auto"))
+                                if use_graph and h.reducer.can_signal() else
+                                "hipGraph replay; all buckets all-reduced at the join after the replay" if use_graph else
+                                "eager; bucket all-reduce issued from gradient hooks on the reducer stream, overlapped with backward")
+        h.remove_multi_gpu()  # graphs first, then the reducer's hooks, progress words and sinks
     del h, x, y, kw
     torch.cuda.empty_cache()
     return res
@@ -299,13 +348,18 @@ def main():
                          "split exactly into three bf16 numbers, six products on the bf16 MFMA (fp32-class error)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare (`python bench.py --gpus N`, the way the reference turns multi-GPU on with a flag and no launcher,
+        # ref: Code/SISR/models/__init__.py:121-122, net_train.py:20): this process starts the N ranks itself
+        raise SystemExit(launch_ranks(args.gpus))
+
     import importlib
     sisr = importlib.import_module("sisr_amd")
     sisr.ops.set_precision(args.precision)
     rank, world, local = sisr.parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
+                         f"--nproc-per-node {args.gpus} (or start bench.py bare: it launches its own ranks)")
     if os.environ.get("SISR_BENCH_SHARE_GPU"):  # rehearsal on a 1-GPU box: every rank on cuda:0 (gloo backend)
         local = 0
     torch.cuda.set_device(local)
@@ -348,101 +402,133 @@ def main():
         except Exception as e:  # the side measurement must not cost the run its headline line
             secondary = (skey, {"error": repr(e)})
 
-    c4 = han16 = None
-    if not explicit and not args.no_secondary and args.precision == "fp32" and world == 1:
+    extras = {}
+
+    def guarded(key, fn):
+        """An auxiliary measurement must not cost the run its headline line: an error is recorded under the object's own key."""
         try:
-            # BASELINE config 4's per-GPU operating point (global batch 32 over 8 GPUs = 4 tiles each), on this one GPU: the
-            # reducer, its buckets and the all-reduce run through a one-rank RCCL world, forward + backward replay from a hipGraph
-            if not dist.is_initialized():
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29533")
-                dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
-            # (58 ms steps: 8 warm-up steps -- graph capture, clocks settling after the 400 ms steps before -- and 30 timed ones;
-            # with 3 / 10 the same code reads 1.5 - 2 patches/s lower)
-            c4_steps, c4_warm = max(2, min(3 * args.steps, 30)), max(min(args.warmup, 3), 8 if args.warmup else 0)
-            s4 = measure(sisr, "qrcan", 4, c4_steps, c4_warm, True, rank, world, local, dev,
-                         families=not args.no_kernel_timing, dp=True)
-            tf4 = s4["value"] * s4["tflop_per_patch"]
-            c4 = {"workload": "QRCAN (RCAN + meta-attention) x4 full depth, 4 tiles of 128x128 per GPU (BASELINE config 4: global "
-                              "batch 32 on 8 GPUs), one-rank RCCL world, forward+backward replayed from a hipGraph",
-                  "value": s4["value"], "unit": "patches/s", "ms_per_step": s4["ms_per_step"], "per_gpu_batch": 4,
-                  "steps": c4_steps, "warmup": c4_warm, "hip_graph": True, "parallelism": "dp1 (one-rank RCCL world: buckets, all_reduce, join)",
-                  "grad_exchange": "SISR_GRAPH_OVERLAP=" + os.environ.get("SISR_GRAPH_OVERLAP", "auto") + " (auto: buckets all-reduced at "
-                                   "the join in a one-rank world, behind signal nodes of the replay in a world of more ranks)",
-                  "roofline": {"bound": "mfma", "achieved": tf4, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf4 / FP32_MFMA_PEAK_TFLOPS,
-                               "families": s4["timer"].summary(FP32_MFMA_PEAK_TFLOPS) if "timer" in s4 else []}}
-            # the same point with the exchange overlapped with the replayed backward (what a world of more ranks runs by default)
-            prev = os.environ.get("SISR_GRAPH_OVERLAP")
-            os.environ["SISR_GRAPH_OVERLAP"] = "1"
-            try:
-                s4o = measure(sisr, "qrcan", 4, max(2, min(args.steps, 5)), 2, True, rank, world, local, dev, dp=True)
-            finally:
-                if prev is None:
-                    os.environ.pop("SISR_GRAPH_OVERLAP")
-                else:
-                    os.environ["SISR_GRAPH_OVERLAP"] = prev
-            c4["overlapped_grad_exchange"] = {
-                "what": "SISR_GRAPH_OVERLAP=1: every bucket's all-reduce is released by a signal node of the replay and runs on the "
-                        "reducer stream beside the rest of the captured backward (in a one-rank world there is nothing to hide: this "
-                        "is the cost of the mechanism)", "value": s4o["value"], "unit": "patches/s", "ms_per_step": s4o["ms_per_step"]}
-            # BASELINE config 5: HAN x4, bf16 matrix-core operands (opt-in mode), 16 tiles
-            sisr.ops.set_precision("bf16")
-            try:
-                # (80 ms steps: 4 warm-up and 10 timed ones; with 2 / 5 the reading swings between 185 and 210)
-                sh = measure(sisr, "han", 16, max(2, min(args.steps, 10)), max(min(args.warmup, 2), 4 if args.warmup else 0), False,
-                             rank, world, local, dev)
-            finally:
-                sisr.ops.set_precision("fp32")
-            gbs = sh["value"] * HBM_GB_PER_PATCH["han"]
-            tfam16 = None
-            tj16 = os.path.join(ROOT, "profiles", "traffic_conv3x3_c64_bf16.json")
-            if os.path.exists(tj16):
-                with open(tj16) as f:
-                    tfam16 = json.load(f).get("families_b32")  # measured / algorithmic HBM bytes per launch of the bf16 kernels
-            han16 = {"workload": "HAN x4 full depth, 16 tiles of 128x128, train step (BASELINE config 5)",
-                     "dtype": "bf16 MFMA operands (rounded while staged into LDS), f32 accumulate, f32 feature maps / gradients / "
-                              "optimiser state in HBM", "value": sh["value"], "unit": "patches/s", "ms_per_step": sh["ms_per_step"],
-                     "final_loss": sh["loss"],
-                     "roofline": {"bound": "hbm", "what": "whole step: algorithmic bytes per patch of the storage format in use "
-                                  "(fp32 maps, 17.0 GB per patch fwd+bwd) x patches/s", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic_families": tfam16,
-                                  "secondary": {"bound": "mfma", "achieved": sh["value"] * sh["tflop_per_patch"], "peak": 2500.0,
-                                                "unit": "TFLOP/s", "frac": sh["value"] * sh["tflop_per_patch"] / 2500.0}},
-                     "parity": "unpinned against the reference (it has no reduced-precision mode); pinned against the oracle's "
-                               "bf16 restatement and, statistically, against fp32 (tests/test_bf16_gpu.py)"}
-        except Exception as e:  # an auxiliary measurement must not cost the run its headline line
-            if c4 is None:
-                c4 = {"error": repr(e)}
-            else:
-                han16 = {"error": repr(e)}
+            extras[key] = fn()
+        except Exception as e:
+            extras[key] = {"error": repr(e)}
             sisr.ops.set_precision("fp32")
 
-    infer = None
-    if not explicit and not args.no_secondary and args.precision == "fp32" and world == 1:
-        try:
-            infer = measure_eval(sisr, "rcan", 32, max(2, min(args.steps, 10)), min(args.warmup, 3), local, dev)
-        except Exception as e:  # an auxiliary measurement must not cost the run its headline line
-            infer = {"error": repr(e)}
+    aux = not explicit and not args.no_secondary and args.precision == "fp32" and world == 1
 
-    x3 = None
-    if not explicit and not args.no_secondary and args.precision == "fp32" and world == 1:
+    def point(s, B, what, graph):
+        tf = s["value"] * s["tflop_per_patch"]
+        return {"workload": what, "value": s["value"], "unit": "patches/s", "ms_per_step": s["ms_per_step"], "per_gpu_batch": B,
+                "hip_graph": graph, "algorithmic_tflops": tf, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS}
+
+    def config4():
+        # BASELINE config 4's per-GPU operating point (global batch 32 over 8 GPUs = 4 tiles each), on this one GPU: the
+        # reducer, its buckets and the all-reduce run through a one-rank RCCL world, forward + backward replay from a hipGraph
+        # (58 ms steps: 8 warm-up steps -- graph capture, clocks settling after the 400 ms steps before -- and 30 timed ones;
+        # with 3 / 10 the same code reads 1.5 - 2 patches/s lower)
+        c4_steps, c4_warm = max(2, min(3 * args.steps, 30)), max(min(args.warmup, 3), 8 if args.warmup else 0)
+        s4 = measure(sisr, "qrcan", 4, c4_steps, c4_warm, True, rank, world, local, dev,
+                     families=not args.no_kernel_timing, dp=True)
+        tf4 = s4["value"] * s4["tflop_per_patch"]
+        return {"workload": "QRCAN (RCAN + meta-attention) x4 full depth, 4 tiles of 128x128 per GPU (BASELINE config 4: global "
+                            "batch 32 on 8 GPUs), one-rank RCCL world, forward+backward replayed from a hipGraph",
+                "value": s4["value"], "unit": "patches/s", "ms_per_step": s4["ms_per_step"], "per_gpu_batch": 4,
+                "steps": c4_steps, "warmup": c4_warm, "hip_graph": True, "parallelism": "dp1 (one-rank RCCL world: buckets, all_reduce, join)",
+                "grad_exchange": s4.get("grad_exchange"), "sample_lanes": sisr.ops.LANES,
+                "roofline": {"bound": "mfma", "achieved": tf4, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf4 / FP32_MFMA_PEAK_TFLOPS,
+                             "families": s4["timer"].summary(FP32_MFMA_PEAK_TFLOPS) if "timer" in s4 else []}}
+
+    def config4_overlapped():
+        # the same point with the exchange overlapped with the replayed backward (opt-in: SISR_GRAPH_OVERLAP=1)
+        prev = os.environ.get("SISR_GRAPH_OVERLAP")
+        os.environ["SISR_GRAPH_OVERLAP"] = "1"
         try:
+            s4o = measure(sisr, "qrcan", 4, max(2, min(args.steps, 5)), 2, True, rank, world, local, dev, dp=True)
+        finally:
+            if prev is None:
+                os.environ.pop("SISR_GRAPH_OVERLAP")
+            else:
+                os.environ["SISR_GRAPH_OVERLAP"] = prev
+        return {"what": "SISR_GRAPH_OVERLAP=1: every bucket's all-reduce is released by a signal node of the replay and runs on the "
+                        "reducer stream beside the rest of the captured backward (in a one-rank world there is nothing to hide: this "
+                        "is the cost of the mechanism)", "value": s4o["value"], "unit": "patches/s", "ms_per_step": s4o["ms_per_step"],
+                "grad_exchange": s4o.get("grad_exchange")}
+
+    def han_bf16():
+        # BASELINE config 5: HAN x4, bf16 matrix-core operands (opt-in mode, DESIGN.md section 7), 16 tiles
+        sisr.ops.set_precision("bf16")
+        try:
+            # (80 ms steps: 4 warm-up and 10 timed ones; with 2 / 5 the reading swings between 185 and 210)
+            sh = measure(sisr, "han", 16, max(2, min(args.steps, 10)), max(min(args.warmup, 2), 4 if args.warmup else 0), False,
+                         rank, world, local, dev)
+        finally:
+            sisr.ops.set_precision("fp32")
+        gb_per_patch = sisr.ops.hbm_gb_per_patch("han") if hasattr(sisr.ops, "hbm_gb_per_patch") else HBM_GB_PER_PATCH["han"]
+        gbs = sh["value"] * gb_per_patch
+        t16 = pmc_traffic("bf16")  # measured / algorithmic HBM bytes per launch of the bf16 kernels (from the PMC CSVs)
+        tfam16 = t16["families_b32"] if t16 is not None else None
+        return {"workload": "HAN x4 full depth, 16 tiles of 128x128, train step (BASELINE config 5)",
+                "dtype": "bf16 MFMA operands (rounded while staged into LDS), f32 accumulate, f32 feature maps / gradients / "
+                         "optimiser state in HBM", "value": sh["value"], "unit": "patches/s", "ms_per_step": sh["ms_per_step"],
+                "final_loss": sh["loss"],
+                "roofline": {"bound": "hbm", "what": "whole step: algorithmic bytes per patch of the storage format in use "
+                             "(%.1f GB per patch fwd+bwd) x patches/s" % gb_per_patch, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic_families": tfam16,
+                             "secondary": {"bound": "mfma", "achieved": sh["value"] * sh["tflop_per_patch"], "peak": 2500.0,
+                                           "unit": "TFLOP/s", "frac": sh["value"] * sh["tflop_per_patch"] / 2500.0}},
+                "parity": "unpinned against the reference (it has no reduced-precision mode); pinned against the oracle's "
+                          "bf16 restatement and, statistically, against fp32 (tests/test_bf16_gpu.py)"}
+
+    def meta_edsr():
+        # BASELINE config 3: Meta-EDSR (QEDSR: EDSR-baseline + a meta-attention layer per block, blur-kernel vector), 32 tiles
+        s = measure(sisr, "qedsr", 32, max(2, min(args.steps, 10)), min(args.warmup, 3), False, rank, world, local, dev)
+        return point(s, 32, "QEDSR (Meta-EDSR, BASELINE config 3) x4, 16 blocks x 64 features, 32 tiles of 128x128, train step", False)
+
+    def b1_point():
+        # the 1-tile-per-GPU operating point SURVEY 8 puts configs 2 and 3 at, and the batch cpu_baseline is timed at
+        out = {}
+        for wl, what in (("rcan", "RCAN x4 full depth"), ("qedsr", "QEDSR (Meta-EDSR) x4, 16 blocks x 64 features")):
+            s = measure(sisr, wl, 1, max(2, min(3 * args.steps, 40)), max(min(args.warmup, 3), 5 if args.warmup else 0), True,
+                        rank, world, local, dev)
+            out[wl] = point(s, 1, what + ", ONE 128x128 tile per step, forward+backward replayed from a hipGraph", True)
+        return out
+
+    if aux:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+            own_group = True
+        else:
+            own_group = False
+        guarded("config4_point", config4)
+        if "error" not in extras["config4_point"]:
+            guarded("_c4o", config4_overlapped)
+            extras["config4_point"]["overlapped_grad_exchange"] = extras.pop("_c4o")
+        if own_group:  # the one-rank world existed for config 4 only; later measurements run single-process
+            dist.destroy_process_group()
+        guarded("han_bf16", han_bf16)
+        guarded("meta_edsr", meta_edsr)
+        guarded("b1_point", b1_point)
+        guarded("inference", lambda: measure_eval(sisr, "rcan", 32, max(2, min(args.steps, 10)), min(args.warmup, 3), local, dev))
+
+        def bf16x3():
             # second line asked for by the round-1 review: the same step with the convs as bf16x3 splits (DESIGN.md)
             sisr.ops.set_precision("bf16x3")
             try:
                 s3 = measure(sisr, workload, B, max(2, min(args.steps, 5)), max(args.warmup, 3), False, rank, world, local, dev)
             finally:
                 sisr.ops.set_precision("fp32")
-            x3 = {"dtype": "f32 via bf16x3 split (six bf16 MFMA products per f32 product), f32 accumulate and storage",
-                  "what": "same workload and step as the headline line, opt-in arithmetic: NOT the headline (DESIGN.md section 7b)",
-                  "value": s3["value"], "unit": "patches/s", "ms_per_step": s3["ms_per_step"], "final_loss": s3["loss"],
-                  "speedup_vs_headline": s3["value"] / main_res["value"],
-                  "algorithmic_tflops": s3["value"] * s3["tflop_per_patch"]}
-        except Exception as e:  # an auxiliary measurement must not cost the run its headline line
-            x3 = {"error": repr(e)}
+            return {"dtype": "f32 via bf16x3 split (six bf16 MFMA products per f32 product), f32 accumulate and storage",
+                    "what": "same workload and step as the headline line, opt-in arithmetic: NOT the headline (DESIGN.md section 7b)",
+                    "value": s3["value"], "unit": "patches/s", "ms_per_step": s3["ms_per_step"], "final_loss": s3["loss"],
+                    "speedup_vs_headline": s3["value"] / main_res["value"],
+                    "algorithmic_tflops": s3["value"] * s3["tflop_per_patch"]}
+        guarded("bf16x3", bf16x3)
 
-    if rank == 0:
+    def emit():
+        """Rank 0 prints the ONE JSON line (everything measured so far)."""
+        if rank != 0:
+            return
         name, params, value = main_res["name"], main_res["params"], main_res["value"]
         tflop_per_patch = main_res["tflop_per_patch"]
         label = name.upper() + (f" ({params['num_features']} features, {params['num_blocks']} blocks)"
@@ -459,20 +545,21 @@ def main():
                                     f"{label} x4 full depth, 128x128 LR -> 512x512 tiles, train step = "
                                     f"fwd + L1 + bwd + Adam + scheduler"), "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"dp{world}" + (" (one-rank RCCL world)" if args.force_dp and world == 1 else ""),
-                       "hip_graph": bool(use_graph), "final_loss": main_res["loss"],
+                       "hip_graph": bool(use_graph), "grad_exchange": main_res.get("grad_exchange"),
+                       "sample_lanes": sisr.ops.LANES if use_graph else 1, "final_loss": main_res["loss"],
                        "algorithmic_tflops": value * tflop_per_patch},
         }
         step_tf = value / world * tflop_per_patch
         if args.precision == "fp32":
             fams = main_res["timer"].summary(FP32_MFMA_PEAK_TFLOPS) if "timer" in main_res else []
             traffic, tsrc, tfam = None, None, None
-            tj = os.path.join(ROOT, "profiles", "traffic_conv3x3_c64.json")
-            if os.path.exists(tj) and main_res["width"] == 64:
-                with open(tj) as f:
-                    tdoc = json.load(f)
-                traffic, tsrc = tdoc.get(str(B)), tdoc.get("source")
-                if B == 32:  # measured HBM bytes per launch of every family beside what it must move (PMC passes)
-                    tfam = tdoc.get("families_b32")
+            if main_res["width"] == 64 and B == 32:
+                # measured HBM bytes per launch of every family beside what it must move: recomputed here from the committed
+                # rocprofv3 --pmc summaries with the one unit rule tools/traffic_from_pmc.py states
+                tdoc = pmc_traffic("fp32")
+                if tdoc is not None:
+                    traffic, tfam = tdoc["32"], tdoc["families_b32"]
+                    tsrc = {"csv": tdoc["source"], "unit_rule": tdoc["unit_rule"], "derived_by": tdoc["derived_by"]}
             line["roofline"] = {
                 "bound": "mfma", "what": "whole training step: algorithmic TFLOP/s per GPU (patches/s x TFLOP per patch)",
                 "achieved": step_tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_tf / FP32_MFMA_PEAK_TFLOPS,
@@ -500,17 +587,44 @@ def main():
                                               "frac": step_tf / 2500.0}}
         if secondary is not None:
             line[secondary[0]] = secondary[1]
-        if c4 is not None:
-            line["config4_point"] = c4
-        if han16 is not None:
-            line["han_bf16"] = han16
-        if x3 is not None:
-            line["bf16x3"] = x3
-        if infer is not None:
-            line["inference"] = infer
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline and args.precision == "fp32":
             line["cpu_baseline"] = cpu_baseline(workload)
         print(json.dumps(line), flush=True)
+
+    if world > 1 and use_graph and not explicit and not args.no_secondary and args.precision == "fp32":
+        # The replayed step's exchange overlapped with its backward (signal nodes + wait kernels, SISR_GRAPH_OVERLAP=1) has never
+        # met a multi-rank RCCL world: measured LAST, under a watchdog that prints the headline line (with a note) and leaves if
+        # the attempt does not come back -- a hang here must not cost the scaling run its line.
+        import threading
+
+        def give_up():
+            extras["overlapped_grad_exchange"] = {"error": "no result within 180 s; the default (all buckets all-reduced at the join "
+                                                           "after the replay) is what the headline line ran"}
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+
+        dog = threading.Timer(180.0, give_up)
+        dog.daemon = True
+        dog.start()
+
+        def overlapped():
+            prev = os.environ.get("SISR_GRAPH_OVERLAP")
+            os.environ["SISR_GRAPH_OVERLAP"] = "1"
+            try:
+                so = measure(sisr, workload, B, max(2, min(args.steps, 10)), max(2, min(args.warmup, 4)), True, rank, world, local, dev)
+            finally:
+                if prev is None:
+                    os.environ.pop("SISR_GRAPH_OVERLAP")
+                else:
+                    os.environ["SISR_GRAPH_OVERLAP"] = prev
+            return {"what": "same workload with SISR_GRAPH_OVERLAP=1", "value": so["value"], "unit": "patches/s",
+                    "ms_per_step": so["ms_per_step"], "grad_exchange": so.get("grad_exchange")}
+        guarded("overlapped_grad_exchange", overlapped)
+        dog.cancel()
+
+    emit()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

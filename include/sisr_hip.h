@@ -69,7 +69,8 @@ int sisr_conv3x3_c64(const float* x, const int64_t* xview, const float* wpacked,
  * from gap_partial -- sisr_ca_gate_fwd's outputs) or into the gate's backward (backward = 1: from the `dot` partial sums
  * -- sisr_ca_gate_bwd's outputs; the last sample's finisher sums the parameter gradients over the batch).  Same
  * arithmetic and summation order as those two entry points.  counter: B + 1 zero-initialised device words, returned to
- * zero; workspace (backward): B * 80 floats.
+ * zero; workspace (backward): B rows of 80 floats (per sample: dz2 [64], then dz1 [hidden <= 16]), so the workspace of a
+ * launch over samples b0 .. b1 is rows b0 .. b1 of the whole batch's.
  * head != 0 turns the same record into a gate HEAD: the launch that CONSUMES a gate computes it first -- every workgroup for
  * its own sample, from the partial sums a previous launch wrote (head_part [B][head_parts][64]) -- instead of a gate launch of
  * its own between the two convs: backward = 0 on a gate_add / gate_out launch (in_scale must be g_out: it is filled here, with
@@ -156,7 +157,8 @@ int sisr_ca_gate_bwd(const float* dg_partial, int parts, int B, float inv_hw, co
                      int channels, int hidden, const float* s, const float* hid, const float* ca, const float* mul,
                      float* shift, float* dmul, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
                      unsigned* counter, void* stream);
-/* dw1 = db1 = dw2 = db2 = NULL (counter may be NULL too): only the per-sample part (shift, dmul, dz2 / dz1 into the
+/* workspace: B rows of 80 floats (sisr_ca_gate_bwd_workspace_bytes), per sample dz2 [64] then dz1 [hidden].
+ * dw1 = db1 = dw2 = db2 = NULL (counter may be NULL too): only the per-sample part (shift, dmul, dz2 / dz1 into the
  * workspace); the parameter gradients of up to sisr_ca_gate_bwd_params_batch_max() such calls are then taken in ONE launch.
  * jobs: HOST array of { that call's workspace, hid, s, dw1, db1, dw2, db2 } (sisr_ca_param_job_bytes() each). */
 int sisr_ca_gate_bwd_params_batch_max(void);

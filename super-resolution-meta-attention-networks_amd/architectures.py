@@ -54,25 +54,43 @@ def conv_weights(net):
     return out
 
 
+def _meta_sig(lay):
+    a, b = (lay.attribute_integrator[i] for i in lay.fc_index)
+    return (tuple(a.weight.shape), tuple(b.weight.shape), lay.nonlinearity, a.bias is not None, b.bias is not None)
+
+
+def meta_gates_batched(layers):
+    """True when meta_gates() runs these ParaCALayers as ONE launch (and their parameter gradients therefore all arrive from
+    one launch at the very end of a backward pass): more than one layer, all two-layer stacks of one shape with biases."""
+    if len(layers) < 2 or any(lay.num_layers != 2 for lay in layers):
+        return False
+    first = _meta_sig(layers[0])
+    return first[3] and first[4] and all(_meta_sig(lay) == first for lay in layers)
+
+
+def late_parameters(net):
+    """The parameters whose gradients a backward pass of `net` delivers last, in one launch: those of the meta-attention
+    layers the network hands to meta_gates() in one batch (a network says which through meta_gate_layers()).  Layers applied
+    block by block (QSPARNet's per-block metadata_attention, the metadata-mixing QCALayer styles' FC stacks) deliver their
+    gradients in the middle of backward and are NOT late."""
+    layers = net.meta_gate_layers() if hasattr(net, "meta_gate_layers") else []
+    if not meta_gates_batched(layers):
+        return []
+    return [p for lay in layers for p in lay.parameters()]
+
+
 def meta_gates(layers, attributes):
     """Gates of a list of ParaCALayers: one batched launch when they are uniform (the normal case: every q-layer of a
     network has the same metadata / hidden / channel sizes), else one launch per layer."""
     if not layers:
         return []
-    first = layers[0]
-    if any(lay.num_layers != 2 for lay in layers):
-        return [lay.gate(attributes) for lay in layers]
-    def sig(lay):
-        a, b = (lay.attribute_integrator[i] for i in lay.fc_index)
-        return (tuple(a.weight.shape), tuple(b.weight.shape), lay.nonlinearity, a.bias is not None, b.bias is not None)
-    if (len(layers) > 1 and not attributes.requires_grad and all(sig(lay) == sig(first) for lay in layers)
-            and sig(first)[3] and sig(first)[4]):
+    if meta_gates_batched(layers) and not attributes.requires_grad:
         params = []
         for lay in layers:
             a, b = (lay.attribute_integrator[i] for i in lay.fc_index)
             params.append((a.weight, a.bias, b.weight, b.bias))
         if all(t.is_contiguous() for lay in params for t in lay):
-            return list(ops.meta_gate_many(attributes, params, first.nonlinearity))
+            return list(ops.meta_gate_many(attributes, params, layers[0].nonlinearity))
     return [lay.gate(attributes) for lay in layers]
 
 
@@ -446,6 +464,10 @@ class QRCAN(nn.Module):
         res = _conv(self.final_body, res, residual=x)
         return _conv(self.tail[1], self.tail[0](res))
 
+    def meta_gate_layers(self):
+        """The layers forward() hands to meta_gates() in one batch (late_parameters)."""
+        return [b.q_node for g in self.body for b in g.body if b.q_layer]
+
 
 class ParamResBlock(nn.Module):
     """ref: attention_manipulators/architectures.py:332-356"""
@@ -488,3 +510,7 @@ class QEDSR(nn.Module):
             res, _ = blk((res, metadata), m)
         res = _conv(self.final_body, res, residual=x)
         return _conv(self.tail[1], self.tail[0](res))
+
+    def meta_gate_layers(self):
+        """The layers forward() hands to meta_gates() in one batch (late_parameters)."""
+        return [b.attention_layer for b in self.body]

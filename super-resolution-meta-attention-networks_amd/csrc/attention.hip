@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void ca_gate_fwd_kernel(const float* __restric
 // One launch (it sits on the serial backward chain of every block).  Per sample (one block each):
 //   dg = sum of the partials of sum_hw dOut*t;  dca = dg*mul; dz2 = dca*ca*(1-ca); dh = W2^T dz2;
 //   dz1 = dh*[hid>0]; ds = W1^T dz1  ->  shift[b][c] = ds*inv_hw (the GAP backward broadcast, consumed as the
-//   dgrad / wgrad prologue shift), dmul = dg*ca, and dz2 [B][64], dz1 [B][R] into the workspace.
+//   dgrad / wgrad prologue shift), dmul = dg*ca, and dz2 / dz1 into the workspace ([B][80] rows).
 // The block that finishes last (device-scope counter, reset for the next launch) then sums the parameter
 // gradients over the batch in batch order -- which block does it does not change the result.
 __global__ __launch_bounds__(256) void ca_gate_bwd_kernel(const float* __restrict__ dgpart, int parts, float inv_hw,
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void ca_gate_bwd_kernel(const float* __restric
 // Same ca_gate_bwd_params code, so the sums are those of the in-kernel form.
 #define CA_PB 32
 struct CaParamJob {
-  const float *dz, *hid, *s;  // dz: [B][80] workspace of that gate (dz2 [B][64], then dz1 [B][R])
+  const float *dz, *hid, *s;  // dz: [B][80] workspace of that gate (per sample: dz2 [64], then dz1 [R <= 16])
   float *dw1, *db1, *dw2, *db2;
 };
 struct CaParamBatch {
@@ -68,7 +68,7 @@ struct CaParamBatch {
 };
 __global__ __launch_bounds__(256) void ca_gate_bwd_params_batch_kernel(CaParamBatch bt, int B, int R) {
   const CaParamJob& j = bt.job[blockIdx.x];
-  ca_gate_bwd_params(j.dz, j.dz + (long)B * 64, j.hid, j.s, R, B, j.dw1, j.db1, j.dw2, j.db2);
+  ca_gate_bwd_params(j.dz, j.dz + 64, j.hid, j.s, R, B, j.dw1, j.db1, j.dw2, j.db2);
 }
 
 // ---------------------------------------------------------------- meta gate (ParaCALayer) forward / backward
@@ -647,8 +647,8 @@ extern "C" int sisr_ca_gate_bwd(const float* dg_partial, int parts, int B, float
   if (!defer && (!dw1 || !db1 || !dw2 || !db2 || !counter)) return SISR_ERR_ARG;
   if (mul && !dmul) return SISR_ERR_ARG;
   if (channels != 64 || hidden < 1 || hidden > 16) return SISR_ERR_UNSUPPORTED;
-  float* dz2 = workspace;
-  float* dz1 = workspace + (size_t)B * 64;
+  float* dz2 = workspace;  // [B][80] rows: dz2 | dz1 (ca_gate.h)
+  float* dz1 = workspace + 64;
   hipLaunchKernelGGL(ca_gate_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dg_partial, parts, inv_hw, w1, w2,
                      hidden, s, hid, ca, mul, shift, dmul, dz2, dz1, dw1, db1, dw2, db2, counter, B);
   return sisr_check_launch();

@@ -153,7 +153,10 @@ __device__ __forceinline__ void ca_gate_fwd_sample(const float* __restrict__ par
 
 // ---- backward, per sample (whole workgroup):  dg = sum of the partials of sum_hw dOut*t;  dca = dg*mul;
 //   dz2 = dca*ca*(1-ca); dh = W2^T dz2; dz1 = dh*[hid>0]; ds = W1^T dz1  ->  shift[b][c] = ds*inv_hw (the GAP backward
-//   broadcast, consumed as the dgrad / wgrad prologue shift), dmul = dg*ca, and dz2 [B][64], dz1 [B][R] into the workspace.
+//   broadcast, consumed as the dgrad / wgrad prologue shift), dmul = dg*ca, and dz2 / dz1 into the workspace: one row of
+//   CA_WS_ROW = 80 floats per sample, dz2 in its first 64, dz1 (R <= 16) behind them -- rows, so that a launch over a range of
+//   samples (a sample lane) writes a plain slice of the whole batch's workspace.  dz1_out = dz2_out + 64.
+#define CA_WS_ROW 80
 template <bool NT>
 __device__ __forceinline__ void ca_gate_bwd_sample(const float* __restrict__ dgpart, int parts, float inv_hw, int b,
                                                    const float* __restrict__ w1, const float* __restrict__ w2, int R,
@@ -185,7 +188,7 @@ __device__ __forceinline__ void ca_gate_bwd_sample(const float* __restrict__ dgp
       dca = dg * (pre ? mc : mul[b * 64 + c]);
     }
     const float dz2 = dca * ca * (1.f - ca);
-    dz2_out[b * 64 + c] = dz2;
+    dz2_out[b * CA_WS_ROW + c] = dz2;
     float ds = 0.f;
     if (pre) {
       float dh[4];
@@ -196,14 +199,14 @@ __device__ __forceinline__ void ca_gate_bwd_sample(const float* __restrict__ dgp
       for (int j = 0; j < 4; ++j)
         if (j < R) {
           const float dz1 = hr[j] > 0.f ? dh[j] : 0.f;
-          if (c == 0) dz1_out[b * R + j] = dz1;
+          if (c == 0) dz1_out[b * CA_WS_ROW + j] = dz1;
           ds += w1r[j] * dz1;
         }
     } else {
       for (int j = 0; j < R; ++j) {
         const float dh = wave_sum(w2[c * R + j] * dz2);
         const float dz1 = hid[b * R + j] > 0.f ? dh : 0.f;
-        if (c == 0) dz1_out[b * R + j] = dz1;
+        if (c == 0) dz1_out[b * CA_WS_ROW + j] = dz1;
         ds += w1[j * 64 + c] * dz1;
       }
     }
@@ -243,14 +246,14 @@ __device__ __forceinline__ void ca_gate_bwd_params(const float* dz2_out, const f
   for (int i = threadIdx.x; i < 2 * n + 64 + R; i += 256) {
     if (i < n) {  // dw2[c][j] = sum_b dz2[b][c] * hid[b][j]
       const int cc = i / R, j = i - cc * R;
-      dw2[i] = dot_b(dz2_out + cc, 64, hid + j, R);
+      dw2[i] = dot_b(dz2_out + cc, CA_WS_ROW, hid + j, R);
     } else if (i < 2 * n) {  // dw1[j][c] = sum_b dz1[b][j] * s[b][c]
       const int k = i - n, j = k >> 6, cc = k & 63;
-      dw1[k] = dot_b(dz1_out + j, R, s_in + cc, 64);
+      dw1[k] = dot_b(dz1_out + j, CA_WS_ROW, s_in + cc, 64);
     } else if (i < 2 * n + 64) {
-      db2[i - 2 * n] = dot_b(dz2_out + (i - 2 * n), 64, nullptr, 0);
+      db2[i - 2 * n] = dot_b(dz2_out + (i - 2 * n), CA_WS_ROW, nullptr, 0);
     } else {
-      db1[i - 2 * n - 64] = dot_b(dz1_out + (i - 2 * n - 64), R, nullptr, 0);
+      db1[i - 2 * n - 64] = dot_b(dz1_out + (i - 2 * n - 64), CA_WS_ROW, nullptr, 0);
     }
   }
 }

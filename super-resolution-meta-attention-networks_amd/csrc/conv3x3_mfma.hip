@@ -2301,7 +2301,7 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   } else if (tail) {
     p.bwd_tail.w1 = tail->w1; p.bwd_tail.w2 = tail->w2; p.bwd_tail.s = tail->s; p.bwd_tail.hid = tail->hid;
     p.bwd_tail.ca = tail->ca; p.bwd_tail.mul = tail->mul; p.bwd_tail.shift = tail->shift; p.bwd_tail.dmul = tail->dmul;
-    p.bwd_tail.dz2 = tail->workspace; p.bwd_tail.dz1 = tail->workspace + (size_t)B * 64;
+    p.bwd_tail.dz2 = tail->workspace; p.bwd_tail.dz1 = tail->workspace + 64;
     p.bwd_tail.dw1 = tail->dw1; p.bwd_tail.db1 = tail->db1; p.bwd_tail.dw2 = tail->dw2; p.bwd_tail.db2 = tail->db2;
     p.bwd_tail.counter = tail->counter; p.bwd_tail.inv_hw = tail->inv_hw; p.bwd_tail.R = tail->hidden;
   }
@@ -2315,7 +2315,7 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
     } else {
       p.bwd_tail.w1 = head->w1; p.bwd_tail.w2 = head->w2; p.bwd_tail.hid = head->hid; p.bwd_tail.ca = head->ca;
       p.bwd_tail.mul = head->mul; p.bwd_tail.shift = head->shift; p.bwd_tail.dmul = head->dmul;
-      p.bwd_tail.dz2 = head->workspace; p.bwd_tail.dz1 = head->workspace + (size_t)B * 64;
+      p.bwd_tail.dz2 = head->workspace; p.bwd_tail.dz1 = head->workspace + 64;
       p.bwd_tail.inv_hw = head->inv_hw; p.bwd_tail.R = head->hidden;
     }
   }

@@ -128,6 +128,10 @@ class QHAN(nn.Module):
         maps.append(res)
         return _han_tail(self, x, maps)
 
+    def meta_gate_layers(self):
+        """The layers forward() hands to meta_gates() in one batch (architectures.late_parameters)."""
+        return [b.q_node for g in list(self.body)[:-1] for b in g.body if b.q_layer]
+
 
 class HANHandler(BaseModel):
     def __init__(self, device, model_save_dir, eval_mode=False, lr=1e-4, scale=4, perceptual=None, scheduler=None,

@@ -67,9 +67,9 @@ class BaseModel(nn.Module):
         betas = (optimizer_params['beta_1'], optimizer_params['beta_2']) if optimizer_params is not None else (0.9, 0.999)
         if params and all(p.is_cuda for p in params) and os.environ.get("SISR_FLAT_ADAM", "1") != "0":
             from .optim import FlatAdam  # one-launch Adam over a flat arena, torch.optim.Adam's schema (optim.py)
-            # the meta-attention layers' gradients come out of ONE launch at the very end of backward (architectures.meta_gates)
-            late = [p for m in self.net.modules() if type(m).__name__ == 'ParaCALayer' for p in m.parameters()]
-            self.optimizer = FlatAdam(params, lr=lr, betas=betas, late=late)
+            # the meta-attention layers a network runs as ONE launch deliver their gradients at the very end of backward
+            # (architectures.meta_gates); layers applied block by block (QSPARNet, the metadata-mixing styles) do not
+            self.optimizer = FlatAdam(params, lr=lr, betas=betas, late=A.late_parameters(self.net))
         else:  # CPU handlers exist for construction / checkpoint plumbing only and are never stepped
             self.optimizer = optim.Adam(params, lr=lr, betas=betas)
 
@@ -111,10 +111,26 @@ class BaseModel(nn.Module):
         """One process per GPU: gradients are averaged over the torch.distributed (RCCL) world.  bucket_mb: size of the
         all-reduce buckets (default 8, or SISR_DP_BUCKET_MB)."""
         from .parallel import GradReducer
+        self.remove_multi_gpu()  # graphs captured with another reducer signal ITS progress words and write into its buckets
+        self._graphs = {}
         self.reducer = GradReducer(self.net, bucket_mb=bucket_mb, arena=getattr(self.optimizer, 'grad_views', None),
                                    arena_flat=getattr(self.optimizer, 'flat_g', None),
                                    arena_offsets=getattr(self.optimizer, 'offsets', None),
                                    arena_order=getattr(self.optimizer, 'arena_order', None))
+
+    def remove_multi_gpu(self):
+        """Back to a single-process handler: the captured graphs go first (their signal nodes hold raw pointers to the reducer's
+        pinned progress words), then the reducer's hooks, words and gradient sinks."""
+        if self.reducer is None:
+            return
+        if self._graphs:
+            torch.cuda.synchronize()
+            self._graphs = {}
+        red, self.reducer = self.reducer, None
+        red.remove()
+        if getattr(self.optimizer, 'grad_views', None) is not None:  # the optimiser's arena stays the gradients' home
+            for p, view in self.optimizer.grad_views.items():
+                ops.GRAD_SINK[p.data_ptr()] = view
 
     # -- checkpoints (ref :349-464)
     def save_model(self, model_save_name, model_idx, extract_state_only=False):
@@ -182,10 +198,16 @@ class BaseModel(nn.Module):
             ops.pack_all(self.net, A.conv_weights)  # every conv weight repacked by one launch
             out = self.run_model(x, image_names=tag, **kwargs)
             loss = self.criterion(out, y)
-            self.standard_update(loss if loss_scale == 1.0 else loss * loss_scale)
+            scale = loss_scale * self._dp_scale()
+            self.standard_update(loss if scale == 1.0 else loss * scale)
         finally:
             ops.invalidate_packs()  # the optimiser moved the weights
         return loss.detach(), out.detach()
+
+    def _dp_scale(self):
+        """1 / world with a reducer: backward then produces this rank's share of the AVERAGE gradient, the all-reduce sums the
+        shares, and nothing is left to scale between the exchange and the optimiser (GradReducer.reduce(prescaled=True))."""
+        return 1.0 / self.reducer.world if self.reducer is not None else 1.0
 
     def _graphed_step(self, x, y, kwargs):
         """Forward + loss + backward captured once per batch shape into a hipGraph and replayed; the reducer,
@@ -222,7 +244,7 @@ class BaseModel(nn.Module):
                     self.optimizer.zero_grad(set_to_none=True)
                     ops.pack_all(self.net, A.conv_weights)
                     with ops.deferred_wgrads():
-                        self.criterion(self.run_model(sx, **kw), sy).backward()
+                        (self.criterion(self.run_model(sx, **kw), sy) * self._dp_scale()).backward()
                 torch.cuda.current_stream().wait_stream(side)
                 self.optimizer.zero_grad(set_to_none=True)
                 with torch.no_grad():
@@ -243,7 +265,7 @@ class BaseModel(nn.Module):
                         # with signal nodes a gradient must be launched before its parameter's hook runs: nothing is deferred
                         # past the autograd node that produces it (the group nodes flush their own batches before they return)
                         with ops.deferred_wgrads(enabled=not signal):
-                            loss.backward()
+                            (loss if red is None or red.world == 1 else loss * self._dp_scale()).backward()
                     finally:
                         if signal:
                             order = red.end_capture()
@@ -267,7 +289,7 @@ class BaseModel(nn.Module):
             if red is not None:
                 red.hooks_enabled = True
         if red is not None:
-            red.reduce()
+            red.reduce(prescaled=True)
         if self.grad_clip is not None:
             nn.utils.clip_grad_norm_(self.net.parameters(), self.grad_clip)
         self.optimizer.step()
@@ -289,7 +311,7 @@ class BaseModel(nn.Module):
 
     def _finish_update(self):
         if self.reducer is not None:
-            self.reducer.reduce()
+            self.reducer.reduce(prescaled=True)
         if self.grad_clip is not None:
             nn.utils.clip_grad_norm_(self.net.parameters(), self.grad_clip)
         self.optimizer.step()

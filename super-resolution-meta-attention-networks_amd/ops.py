@@ -1045,6 +1045,76 @@ class _ResBlock(Function):
             IN_BACKWARD = False
 
 
+# Sample lanes.  The tiles of a minibatch never meet inside a residual group (no batch statistics on the path), so the chain of
+# B-tile launches of a group can run as LANES chains of B / LANES tiles on LANES streams -- parallel branches of the captured
+# step.  At 4 tiles per GPU a single chain fills the chip with ONE round of workgroups that stage, multiply and store in
+# lock-step (43 - 51 us per launch in the step against 31 us of MFMA time); two chains drift out of phase and one's K loops
+# cover the other's staging and stores (tools/lane_probe.py: 38.7 -> 36.7 us per 4-tile link, mask form 40.5 -> 37.6).
+# Used where launches are small AND the step is replayed from a hipGraph (eager launches at these sizes are host-bound and
+# lanes double their number); the weight gradients stay whole-batch launches: the lanes meet before every batch of eight.
+LANES = int(os.environ.get("SISR_LANES", 2))
+LANES_EAGER = os.environ.get("SISR_LANES_EAGER", "0") != "0"  # tests / probes: lanes outside a capture too
+LANES_MAX_PIXELS = int(os.environ.get("SISR_LANES_MAX_PIXELS", 8 * 128 * 128))
+LANES_INTERLEAVE = os.environ.get("SISR_LANES_INTERLEAVE", "1") != "0"  # issue the lanes' launches block by block, alternating
+_lane_streams = {}
+
+
+def _lane_cuts(B, H, W):
+    """[(b0, b1)] sample ranges of the lanes of a group launch chain ([(0, B)]: one chain on the calling stream)."""
+    if (LANES < 2 or B % LANES or PRECISION != "fp32" or not WgradQueue.wanted(B, H, W) or B * H * W > LANES_MAX_PIXELS
+            or _use_ca_tail(B, H, W) or not (LANES_EAGER or torch.cuda.is_current_stream_capturing())):
+        return [(0, B)]
+    return [(B * k // LANES, B * (k + 1) // LANES) for k in range(LANES)]
+
+
+class _Lanes:
+    """Lane 0 is the calling stream; lanes 1.. are side streams forked from it (fork()) and joined back into it (join()).
+    Every buffer a lane touches is allocated on the calling stream BEFORE the fork and released after the join, so the caching
+    allocator's stream-ordered reuse stays sound."""
+
+    def __init__(self, device, cuts):
+        self.cuts, self.main = cuts, torch.cuda.current_stream(device)
+        pool = _lane_streams.setdefault(device.index, [])
+        while len(pool) < len(cuts) - 1:
+            pool.append(torch.cuda.Stream(device=device))
+        self.side = pool[:len(cuts) - 1]
+
+    def fork(self):
+        for s in self.side:
+            s.wait_stream(self.main)
+
+    def join(self):
+        for s in self.side:
+            self.main.wait_stream(s)
+
+    def run(self, fn):
+        """fn(b0, b1) once per lane, each on its stream.  A generator function is advanced round-robin -- lane 0 up to its
+        first yield, lane 1 up to its first yield, ... -- so that the lanes' launches are issued (and captured) interleaved,
+        block by block, instead of one whole chain after the other."""
+        gens = []
+        for k, (b0, b1) in enumerate(self.cuts):
+            if k == 0:
+                g = fn(b0, b1)
+            else:
+                with torch.cuda.stream(self.side[k - 1]):
+                    g = fn(b0, b1)
+            if hasattr(g, "__next__"):
+                gens.append((k, g))
+        while gens:
+            alive = []
+            for k, g in gens:
+                try:
+                    if k == 0:
+                        next(g)
+                    else:
+                        with torch.cuda.stream(self.side[k - 1]):
+                            next(g)
+                    alive.append((k, g))
+                except StopIteration:
+                    pass
+            gens = alive
+
+
 class _GatedGroup(Function):
     """A whole residual group of channel-attention blocks as ONE autograd node:
 
@@ -1055,7 +1125,12 @@ class _GatedGroup(Function):
     Same kernels and arithmetic as the per-block node, but the two passes a block cannot fuse on its own move into
     its neighbours: the gated skip  u_k = t2_k * g_k + u_{k-1}  is built (and written once) by the NEXT conv's
     halo staging, and the gate gradient  sum(dU_k * t2_k)  is taken by the PREVIOUS backward conv's epilogue while
-    it produces dU_k.  Per block that removes two HBM-bound launches (3 + 2 map passes with the MFMA units idle)."""
+    it produces dU_k.  Per block that removes two HBM-bound launches (3 + 2 map passes with the MFMA units idle).
+
+    Both passes are written as a chain over a sample range [b0, b1) of buffers allocated for the whole batch: one chain over
+    all samples on the calling stream, or (small launches inside a hipGraph capture, _lane_cuts) one chain per sample lane on
+    parallel streams -- every launch of a lane is the same kernel on a contiguous slice of the batch, so results do not depend
+    on the number of lanes (bit-identical)."""
 
     PER = 9  # w1, b1, w2, b2, caw1, cab1, caw2, cab2, m
 
@@ -1073,60 +1148,84 @@ class _GatedGroup(Function):
         tails = _use_ca_tail(B, H, W)
         heads = GATE_HEADS and not tails and WgradQueue.wanted(B, H, W) and B * H * W <= GATE_HEADS_MAX_PIXELS
         PER = _GatedGroup.PER
-        cur, pend = x, None
-        tensors, packs, meta, small = [], [], [], []
+        lanes = _Lanes(dev, _lane_cuts(B, H, W))
 
         def pack(w):
             return pack_pair(w) if need else (pack_weight(w, "fwd"), None)
 
+        # every buffer of the group, on the calling stream
+        blks, tensors, packs, meta, small = [], [], [], [], []
         for k in range(n):
             w1, b1, w2, b2, caw1, cab1, caw2, cab2, m = args[k * PER:(k + 1) * PER]
             w1, w2 = w1.contiguous(), w2.contiguous()
             p1, pd1 = pack(w1)
             p2, pd2 = pack(w2)
-            t1 = _empty_cl(B, 64, H, W, dev)
-            if pend is None:
-                conv_c64(cur, v, p1, b1, (1, 64), t1, v, B, H, W, 64, 64, relu=True)
-            else:
-                u = _empty_cl(B, 64, H, W, dev)
-                conv_c64(pend[0], v, p1, b1, (1, 64), t1, v, B, H, W, 64, 64, relu=True, in_scale=pend[1], gate_add=cur,
-                         gate_out=u, ca_tail=pend[2])
-                cur = u
-            t2 = _empty_cl(B, 64, H, W, dev)
-            gap = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
             R = caw1.shape[0]
-            caw1c, caw2c = caw1.reshape(R, 64).contiguous(), caw2.reshape(64, R).contiguous()
-            sv, hid, ca, g = _vec(B, 64, dev), _vec(B, R, dev), _vec(B, 64, dev), _vec(B, 64, dev)
-            mm = m.contiguous() if m is not None else None
-            if tails:  # the gate is computed by conv2's last-arriving workgroup per sample
-                conv_c64(t1, v, p2, b2, (1, 64), t2, v, B, H, W, 64, 64, gap=gap,
-                         ca_tail=_tail_fwd(B, H, W, R, caw1c, cab1, caw2c, cab2, mm, sv, hid, ca, g, dev))
-            elif heads:  # the gate is computed by the conv that consumes it (the next block's conv1, or the group's tail conv)
-                conv_c64(t1, v, p2, b2, (1, 64), t2, v, B, H, W, 64, 64, gap=gap)
-                hd = hip.CaTail()
-                hd.backward, hd.hidden, hd.inv_hw, hd.head, hd.head_parts = 0, R, 1.0 / (H * W), 1, parts
-                cb1, cb2 = cab1.contiguous(), cab2.contiguous()
-                hd.w1, hd.b1, hd.w2, hd.b2, hd.mul = hip.ptr(caw1c), hip.ptr(cb1), hip.ptr(caw2c), hip.ptr(cb2), hip.ptr(mm)
-                hd.s_out, hd.hid_out, hd.ca_out, hd.g_out = hip.ptr(sv), hip.ptr(hid), hip.ptr(ca), hip.ptr(g)
-                hd.head_part = hip.ptr(gap)
-                head_keep = (hd, gap, cb1, cb2, mm)
-            else:
-                conv_c64(t1, v, p2, b2, (1, 64), t2, v, B, H, W, 64, 64, gap=gap)
-                hip.check(L.sisr_ca_gate_fwd(hip.ptr(gap), parts, B, 1.0 / (H * W), hip.ptr(caw1c), hip.ptr_c(cab1),
-                                             hip.ptr(caw2c), hip.ptr_c(cab2), 64, R, hip.ptr(mm), hip.ptr(sv),
-                                             hip.ptr(hid), hip.ptr(ca), hip.ptr(g), hip.stream()), "sisr_ca_gate_fwd")
-            pend = (t2, g, head_keep[0] if heads else None, head_keep if heads else None)
+            d = dict(p1=p1, p2=p2, b1=b1, b2=b2, R=R, t1=_empty_cl(B, 64, H, W, dev), t2=_empty_cl(B, 64, H, W, dev),
+                     u=_empty_cl(B, 64, H, W, dev) if k > 0 else x,
+                     gap=torch.empty((B, parts, 64), device=dev, dtype=torch.float32),
+                     caw1c=caw1.reshape(R, 64).contiguous(), caw2c=caw2.reshape(64, R).contiguous(),
+                     cb1=cab1.contiguous(), cb2=cab2.contiguous(), mm=m.contiguous() if m is not None else None,
+                     sv=_vec(B, 64, dev), hid=_vec(B, R, dev), ca=_vec(B, 64, dev), g=_vec(B, 64, dev))
+            blks.append(d)
             small.append((b1, b2, caw1, cab1, caw2, cab2))
-            blk = [cur, w1, w2, t1, t2, caw1c, caw2c, sv, hid, ca, g] + ([mm] if mm is not None else [])
-            meta.append((len(blk), mm is not None, tuple(caw1.shape), tuple(caw2.shape)))
+            blk = [d["u"], w1, w2, d["t1"], d["t2"], d["caw1c"], d["caw2c"], d["sv"], d["hid"], d["ca"], d["g"]]
+            if d["mm"] is not None:
+                blk.append(d["mm"])
+            meta.append((len(blk), d["mm"] is not None, tuple(caw1.shape), tuple(caw2.shape)))
             tensors += blk
             packs.append((pd1, pd2))
         wt, bt = args[n * PER:n * PER + 2]
         wt = wt.contiguous()
         pt, pdt = pack(wt)
         un, out = _empty_cl(B, 64, H, W, dev), _empty_cl(B, 64, H, W, dev)
-        conv_c64(pend[0], v, pt, bt, (1, 64), out, v, B, H, W, 64, 64, in_scale=pend[1], gate_add=cur, gate_out=un, res=x,
-                 ca_tail=pend[2])
+        keep = []  # argument records the launches of a lane point into
+        interleave = len(lanes.cuts) > 1 and LANES_INTERLEAVE
+
+        def chain(b0, b1):
+            """The group's forward launches on samples [b0, b1) (a generator: with several lanes it yields after every block)."""
+            sl, Bl = slice(b0, b1), b1 - b0
+            pend = None  # (t2, g, gate head) of the block whose gated skip the next conv builds
+            for k in range(n):
+                d = blks[k]
+                t1, t2, gap = d["t1"][sl], d["t2"][sl], d["gap"][sl]
+                sv, hid, ca, g = d["sv"][sl], d["hid"][sl], d["ca"][sl], d["g"][sl]
+                mm = d["mm"][sl] if d["mm"] is not None else None
+                if pend is None:
+                    conv_c64(x[sl], v, d["p1"], d["b1"], (1, 64), t1, v, Bl, H, W, 64, 64, relu=True)
+                else:
+                    conv_c64(pend[0], v, d["p1"], d["b1"], (1, 64), t1, v, Bl, H, W, 64, 64, relu=True, in_scale=pend[1],
+                             gate_add=blks[k - 1]["u"][sl], gate_out=d["u"][sl], ca_tail=pend[2])
+                hd = None
+                if tails:  # the gate is computed by conv2's last-arriving workgroup per sample
+                    conv_c64(t1, v, d["p2"], d["b2"], (1, 64), t2, v, Bl, H, W, 64, 64, gap=gap,
+                             ca_tail=_tail_fwd(Bl, H, W, d["R"], d["caw1c"], d["cb1"], d["caw2c"], d["cb2"], mm, sv, hid, ca, g, dev))
+                elif heads:  # the gate is computed by the conv that consumes it (the next block's conv1, or the group's tail conv)
+                    conv_c64(t1, v, d["p2"], d["b2"], (1, 64), t2, v, Bl, H, W, 64, 64, gap=gap)
+                    hd = hip.CaTail()
+                    hd.backward, hd.hidden, hd.inv_hw, hd.head, hd.head_parts = 0, d["R"], 1.0 / (H * W), 1, parts
+                    hd.w1, hd.b1, hd.w2, hd.b2, hd.mul = (hip.ptr(d["caw1c"]), hip.ptr(d["cb1"]), hip.ptr(d["caw2c"]),
+                                                          hip.ptr(d["cb2"]), hip.ptr(mm))
+                    hd.s_out, hd.hid_out, hd.ca_out, hd.g_out = hip.ptr(sv), hip.ptr(hid), hip.ptr(ca), hip.ptr(g)
+                    hd.head_part = hip.ptr(gap)
+                    keep.append(hd)
+                else:
+                    conv_c64(t1, v, d["p2"], d["b2"], (1, 64), t2, v, Bl, H, W, 64, 64, gap=gap)
+                    hip.check(L.sisr_ca_gate_fwd(hip.ptr(gap), parts, Bl, 1.0 / (H * W), hip.ptr(d["caw1c"]), hip.ptr(d["cb1"]),
+                                                 hip.ptr(d["caw2c"]), hip.ptr(d["cb2"]), 64, d["R"], hip.ptr(mm), hip.ptr(sv),
+                                                 hip.ptr(hid), hip.ptr(ca), hip.ptr(g), hip.stream()), "sisr_ca_gate_fwd")
+                pend = (t2, g, hd)
+                if interleave:
+                    yield
+            conv_c64(pend[0], v, pt, bt, (1, 64), out[sl], v, Bl, H, W, 64, 64, in_scale=pend[1], gate_add=blks[n - 1]["u"][sl],
+                     gate_out=un[sl], res=x[sl], ca_tail=pend[2])
+
+        lanes.fork()
+        if interleave:
+            lanes.run(chain)
+        else:
+            lanes.run(lambda b0, b1: [None for _ in chain(b0, b1)] and None)
+        lanes.join()
         ctx.save_for_backward(*tensors, un, wt)
         ctx.cfg = (n, (B, H, W), meta, parts)
         ctx.packs, ctx.pdt = packs, pdt
@@ -1161,22 +1260,26 @@ class _GatedGroup(Function):
             side = _side_ok(wt, *(t for blk in blocks for t in blk[0][1:3]))
             # small launches: the group's 2n + 1 weight gradients go out eight to a launch (WgradQueue) instead of one by one
             queue = WgradQueue(B, H, W, dev) if WgradQueue.wanted(B, H, W) else None
-            gate_jobs = []
+            tails = _use_ca_tail(B, H, W)
+            bheads = not tails and queue is not None and GATE_HEADS and B * H * W <= GATE_HEADS_MAX_PIXELS
+            lanes = _Lanes(dev, _lane_cuts(B, H, W) if queue is not None else [(0, B)])
+            nl = len(lanes.cuts)
+            gate_jobs, keep = [], []
             # tail conv: weight gradient from (u_n, dout); dU_n = convT(dout), with sum(dU_n * t2_n) on the side
             dwt, dbt = _grad_buf(wt), _grad_buf_or(ctx.bt, 64, dev)
             if queue is not None:
                 queue.add(un, dout, dwt, dbt)
             else:
                 run(lambda: wgrad_c64(un, v, dout, v, dwt, dbt, B, H, W, 64, 64), (un, dout, dwt, dbt))
-            tails = _use_ca_tail(B, H, W)
 
             def gate_bwd_out(k):
-                """Outputs of block k's gate backward (allocated before the conv launch whose tail fills them)."""
+                """Outputs of block k's gate backward (allocated before the conv launch whose tail / head fills them)."""
                 tens, has_m, s_caw1, s_caw2 = blocks[k]
-                R = tens[5].shape[0]
                 _, _, caw1, cab1, caw2, cab2 = ctx.small[k]
                 return dict(shift=_vec(B, 64, dev), dmv=_vec(B, 64, dev) if has_m else None,
-                            dcaw1=_grad_buf(caw1), dcab1=_grad_buf(cab1), dcaw2=_grad_buf(caw2), dcab2=_grad_buf(cab2))
+                            dcaw1=_grad_buf(caw1), dcab1=_grad_buf(cab1), dcaw2=_grad_buf(caw2), dcab2=_grad_buf(cab2),
+                            dgp=torch.empty((B, parts, 64), device=dev, dtype=torch.float32),
+                            dzw=torch.empty((B, 80), device=dev) if queue is not None and not tails else None)
 
             def tail_for(k, o):
                 if not tails:
@@ -1186,69 +1289,144 @@ class _GatedGroup(Function):
                 return _tail_bwd(B, H, W, caw1c.shape[0], caw1c, caw2c, s, hid, ca, tens[11] if has_m else None, o["shift"],
                                  o["dmv"], o["dcaw1"], o["dcab1"], o["dcaw2"], o["dcab2"], dev)
 
-            dy = _empty_cl(B, 64, H, W, dev)
-            dgp = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
-            go = gate_bwd_out(n - 1)
-            conv_c64(dout, v, ctx.pdt, None, (1, 64), dy, v, B, H, W, 64, 64, gap=dgp, dot=blocks[-1][0][4],
-                     ca_tail=tail_for(n - 1, go))
-            grads = [None] * (n * _GatedGroup.PER)
-            for k in range(n - 1, -1, -1):
+            def block_bufs(k):
+                """Maps block k's backward writes: dt1 (gradient at ReLU(conv1)) and dprev (gradient at the block's input), plus
+                the gate-backward outputs of block k - 1, which block k's last conv feeds."""
+                return dict(dt1=_empty_cl(B, 64, H, W, dev), dprev=_empty_cl(B, 64, H, W, dev), go=gate_bwd_out(k - 1) if k > 0 else None)
+
+            def first_conv(b0, b1, dy, go):
+                """dU_n = convT_tail(dout), with the partial sums of sum(dU_n * t2_n) for block n - 1's gate backward."""
+                sl = slice(b0, b1)
+                conv_c64(dout[sl], v, ctx.pdt, None, (1, 64), dy[sl], v, b1 - b0, H, W, 64, 64, gap=go["dgp"][sl],
+                         dot=blocks[-1][0][4][sl], ca_tail=tail_for(n - 1, go))
+
+            def block_chain(k, b0, b1, dy, go, bufs, mid1=None, mid2=None):
+                """Block k's part of the input-gradient chain on samples [b0, b1): gate backward (as a launch, a head of the next
+                conv, or the previous conv's tail), dgrad through conv2 (ReLU mask, gated gradient rebuilt while staging), dgrad
+                through conv1 (+ the skip's gradient; partial sums for block k - 1's gate backward).  mid1 / mid2: called after
+                the gate backward / after the first conv (where a single chain issues the block's weight gradients)."""
+                sl, Bl = slice(b0, b1), b1 - b0
                 tens, has_m, s_caw1, s_caw2 = blocks[k]
                 xk, w1, w2, t1, t2, caw1c, caw2c, s, hid, ca, g = tens[:11]
-                mm = tens[11] if has_m else None
+                mm = tens[11][sl] if has_m else None
                 pd1, pd2 = ctx.packs[k]
                 R = caw1c.shape[0]
-                shift, dmv, dcaw1, dcab1, dcaw2, dcab2 = (go[key] for key in ("shift", "dmv", "dcaw1", "dcab1", "dcaw2", "dcab2"))
+                shift, dmv = go["shift"][sl], go["dmv"][sl] if has_m else None
                 bhead = None
-                if not tails and queue is not None and GATE_HEADS and B * H * W <= GATE_HEADS_MAX_PIXELS:
-                    # ... and the per-sample part is computed by the conv that consumes `shift` (gate head)
-                    dzw = torch.empty((B, 80), device=dev)
+                if bheads:  # the per-sample part of the gate backward is computed by the conv that consumes `shift` (gate head)
                     bhead = hip.CaTail()
                     bhead.backward, bhead.hidden, bhead.inv_hw, bhead.head, bhead.head_parts = 1, R, 1.0 / hw, 1, parts
-                    bhead.w1, bhead.w2, bhead.hid, bhead.ca, bhead.mul = (hip.ptr(caw1c), hip.ptr(caw2c), hip.ptr(hid), hip.ptr(ca),
-                                                                          hip.ptr(mm))
-                    bhead.shift, bhead.dmul, bhead.workspace, bhead.head_part = hip.ptr(shift), hip.ptr(dmv), hip.ptr(dzw), hip.ptr(dgp)
-                    gate_jobs.append((dzw, hid, s, dcaw1, dcab1, dcaw2, dcab2, R))
+                    bhead.w1, bhead.w2, bhead.hid, bhead.ca, bhead.mul = (hip.ptr(caw1c), hip.ptr(caw2c), hip.ptr(hid[sl]),
+                                                                          hip.ptr(ca[sl]), hip.ptr(mm))
+                    bhead.shift, bhead.dmul, bhead.workspace, bhead.head_part = (hip.ptr(shift), hip.ptr(dmv), hip.ptr(go["dzw"][sl]),
+                                                                                  hip.ptr(go["dgp"][sl]))
+                    keep.append(bhead)
                 elif not tails and queue is not None:
                     # small launches: the chain kernel only produces what the next conv waits for; the gates' parameter
                     # gradients of the whole group are one launch at the end (their dz2 / dz1 wait in per-gate workspaces)
-                    dzw = torch.empty((B, 80), device=dev)
-                    hip.check(L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
-                                                 hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
-                                                 hip.ptr(dmv), None, None, None, None, hip.ptr(dzw), None, hip.stream()),
+                    hip.check(L.sisr_ca_gate_bwd(hip.ptr(go["dgp"][sl]), parts, Bl, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
+                                                 hip.ptr(s[sl]), hip.ptr(hid[sl]), hip.ptr(ca[sl]), hip.ptr(mm), hip.ptr(shift),
+                                                 hip.ptr(dmv), None, None, None, None, hip.ptr(go["dzw"][sl]), None, hip.stream()),
                               "sisr_ca_gate_bwd")
-                    gate_jobs.append((dzw, hid, s, dcaw1, dcab1, dcaw2, dcab2, R))
-                elif not tails:
-                    hip.check(L.sisr_ca_gate_bwd(hip.ptr(dgp), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
+                elif not tails:  # (one chain over the whole batch: queue is None implies a single lane)
+                    hip.check(L.sisr_ca_gate_bwd(hip.ptr(go["dgp"]), parts, B, 1.0 / hw, hip.ptr(caw1c), hip.ptr(caw2c), 64, R,
                                                  hip.ptr(s), hip.ptr(hid), hip.ptr(ca), hip.ptr(mm), hip.ptr(shift),
-                                                 hip.ptr(dmv), hip.ptr(dcaw1), hip.ptr(dcab1), hip.ptr(dcaw2), hip.ptr(dcab2),
-                                                 hip.ptr(_gate_ws(B, dev)), hip.gate_counter(dev), hip.stream()),
+                                                 hip.ptr(dmv), hip.ptr(go["dcaw1"]), hip.ptr(go["dcab1"]), hip.ptr(go["dcaw2"]),
+                                                 hip.ptr(go["dcab2"]), hip.ptr(_gate_ws(B, dev)), hip.gate_counter(dev), hip.stream()),
                               "sisr_ca_gate_bwd")
+                if mid1 is not None:
+                    mid1()
+                dt1, dprev = bufs["dt1"], bufs["dprev"]
+                conv_c64(dy[sl], v, pd2, None, (1, 64), dt1[sl], v, Bl, H, W, 64, 64, mask=t1[sl], in_scale=g[sl], in_shift=shift,
+                         ca_tail=bhead)
+                if mid2 is not None:
+                    mid2()
+                if k > 0:
+                    gn = bufs["go"]
+                    conv_c64(dt1[sl], v, pd1, None, (1, 64), dprev[sl], v, Bl, H, W, 64, 64, res=dy[sl], gap=gn["dgp"][sl],
+                             dot=blocks[k - 1][0][4][sl], ca_tail=tail_for(k - 1, gn))
+                else:
+                    conv_c64(dt1[sl], v, pd1, None, (1, 64), dprev[sl], v, Bl, H, W, 64, 64, res=dy[sl])
+
+            grads = [None] * (n * _GatedGroup.PER)
+
+            def wgrad2(k, dy, go):
+                """Weight gradient of block k's second conv, from (t1, the gated gradient dy * g + shift rebuilt while staging)."""
+                tens = blocks[k][0]
+                w2, t1, g = tens[2], tens[3], tens[10]
                 dw2, db2 = _grad_buf(w2), _grad_buf_or(ctx.small[k][1], 64, dev)
-                dw1, db1 = _grad_buf(w1), _grad_buf_or(ctx.small[k][0], 64, dev)
-                if queue is None:
-                    run(lambda t1=t1, dy=dy, dw2=dw2, db2=db2, g=g, shift=shift:
-                        wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, dy_scale=g, dy_shift=shift),
-                        (t1, dy, g, shift, dw2, db2))
-                dt1 = _empty_cl(B, 64, H, W, dev)
-                conv_c64(dy, v, pd2, None, (1, 64), dt1, v, B, H, W, 64, 64, mask=t1, in_scale=g, in_shift=shift, ca_tail=bhead)
-                if queue is not None:  # after the conv above: with a gate head it is that launch which fills `shift`
+                shift = go["shift"]
+                if queue is not None:
                     queue.add(t1, dy, dw2, db2, dy_scale=g, dy_shift=shift)
+                else:
+                    run(lambda: wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, dy_scale=g, dy_shift=shift),
+                        (t1, dy, g, shift, dw2, db2))
+                grads[k * _GatedGroup.PER + 2:k * _GatedGroup.PER + 4] = [dw2, db2]
+
+            def wgrad1(k, go, bufs):
+                """Weight gradient of block k's first conv, from (the block's input, dt1); the block's small gradients."""
+                tens, has_m = blocks[k][0], blocks[k][1]
+                xk, w1, caw1c, s, hid = tens[0], tens[1], tens[5], tens[7], tens[8]
+                dw1, db1 = _grad_buf(w1), _grad_buf_or(ctx.small[k][0], 64, dev)
+                dt1 = bufs["dt1"]
+                if queue is not None:
+                    if not tails:
+                        gate_jobs.append((go["dzw"], hid, s, go["dcaw1"], go["dcab1"], go["dcaw2"], go["dcab2"], caw1c.shape[0]))
                     queue.add(xk, dt1, dw1, db1)
                 else:
-                    run(lambda xk=xk, dt1=dt1, dw1=dw1, db1=db1: wgrad_c64(xk, v, dt1, v, dw1, db1, B, H, W, 64, 64),
-                        (xk, dt1, dw1, db1))
-                dprev = _empty_cl(B, 64, H, W, dev)
-                if k > 0:
-                    dgp = torch.empty((B, parts, 64), device=dev, dtype=torch.float32)
-                    go = gate_bwd_out(k - 1)
-                    conv_c64(dt1, v, pd1, None, (1, 64), dprev, v, B, H, W, 64, 64, res=dy, gap=dgp, dot=blocks[k - 1][0][4],
-                             ca_tail=tail_for(k - 1, go))
-                else:
-                    conv_c64(dt1, v, pd1, None, (1, 64), dprev, v, B, H, W, 64, 64, res=dy)
-                dy = dprev
-                grads[k * _GatedGroup.PER:(k + 1) * _GatedGroup.PER] = [dw1, db1, dw2, db2, dcaw1, dcab1, dcaw2, dcab2,
-                                                                       dmv if has_m else None]
+                    run(lambda: wgrad_c64(xk, v, dt1, v, dw1, db1, B, H, W, 64, 64), (xk, dt1, dw1, db1))
+                P = _GatedGroup.PER
+                grads[k * P:k * P + 2] = [dw1, db1]
+                grads[k * P + 4:k * P + 9] = [go["dcaw1"], go["dcab1"], go["dcaw2"], go["dcab2"], go["dmv"] if has_m else None]
+
+            dy = _empty_cl(B, 64, H, W, dev)
+            go = gate_bwd_out(n - 1)
+            if nl == 1:
+                # one chain on the calling stream: buffers come and go block by block, weight gradients follow their operands
+                first_conv(0, B, dy, go)
+                for k in range(n - 1, -1, -1):
+                    bufs = block_bufs(k)
+                    if queue is None:  # side stream: wgrad2 beside the conv2 input gradient, wgrad1 beside conv1's
+                        block_chain(k, 0, B, dy, go, bufs, mid1=lambda: wgrad2(k, dy, go), mid2=lambda: wgrad1(k, go, bufs))
+                    else:  # queued: after the first conv (with a gate head it is that launch which fills `shift`)
+                        block_chain(k, 0, B, dy, go, bufs, mid2=lambda: (wgrad2(k, dy, go), wgrad1(k, go, bufs)))
+                    dy, go = bufs["dprev"], bufs["go"]
+            else:
+                # sample lanes: the chains of a SEGMENT of blocks run side by side; then the lanes meet, the segment's weight
+                # gradients (whole-batch launches, eight to a launch) run, and the lanes part again for the next segment
+                seg = max(1, int(os.environ.get("SISR_LANES_SEGMENT", 4)))
+                state = {"dy": dy, "go": go}
+                k_hi = n - 1
+                first = True
+                while k_hi >= 0:
+                    ks = list(range(k_hi, max(-1, k_hi - seg), -1))
+                    allb = {k: block_bufs(k) for k in ks}  # before the fork, on the calling stream
+
+                    def segment(b0, b1, first=first, ks=ks, allb=allb, dy0=state["dy"], go0=state["go"]):
+                        dyl, gol = dy0, go0
+                        if first:
+                            first_conv(b0, b1, dyl, gol)
+                        for k in ks:
+                            block_chain(k, b0, b1, dyl, gol, allb[k])
+                            dyl, gol = allb[k]["dprev"], allb[k]["go"]
+                            if LANES_INTERLEAVE:
+                                yield
+
+                    lanes.fork()
+                    if LANES_INTERLEAVE:
+                        lanes.run(segment)
+                    else:
+                        lanes.run(lambda b0, b1: [None for _ in segment(b0, b1)] and None)
+                    lanes.join()
+                    dyl, gol = state["dy"], state["go"]
+                    for k in ks:
+                        wgrad2(k, dyl, gol)
+                        wgrad1(k, gol, allb[k])
+                        dyl, gol = allb[k]["dprev"], allb[k]["go"]
+                    state["dy"], state["go"] = dyl, gol
+                    first = False
+                    k_hi -= seg
+                dy = state["dy"]
             dx = _affine(dy, None, None, dout, B, H, W, 64) if ctx.needs_input_grad[0] else None
             if queue is not None:
                 queue.flush()  # before the gradients leave the node (reducer hooks may read them right after)

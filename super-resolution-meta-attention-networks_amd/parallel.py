@@ -11,8 +11,10 @@ GAP/LAM/CSAM reduce within a sample), so the only exchange is one gradient avera
     collective overlaps the rest of backward (62 MB fp32 for RCAN ≈ 0.1-0.7 ms on 7 xGMI links versus
     tens of ms of backward);
   * ``reduce()`` (called by ``standard_update`` between backward and the optimiser step) joins the side
-    stream, scales each bucket by 1 / world_size in place and hands the parameters views of it as their
-    ``.grad`` (no copy back).  L1 'mean' over equal shards makes mean-of-means exact.
+    stream and hands the parameters views of the buckets as their ``.grad`` (no copy back).  The 1 / world_size
+    factor is applied to the LOSS by the handlers (``reduce(prescaled=True)``; exact for power-of-two worlds), so the
+    sum IS the average; a stand-alone caller gets one in-place scaling launch per bucket instead.  L1 'mean' over
+    equal shards makes mean-of-means exact.
 
 Works unchanged on CPU tensors with the gloo backend (used by the world_size-2 tests).
 """
@@ -178,16 +180,21 @@ class GradReducer:
     # -- hipGraph replays (BaseModel._graphed_step)
     @staticmethod
     def graph_overlap_mode():
-        """SISR_GRAPH_OVERLAP: auto (default: 'spin' in a world of more than one rank, '0' in a one-rank world, where there is
-        nothing to hide and the extra nodes cost ~2 %) | 0 (all buckets at the join) | 1 = spin | poll | wait."""
+        """SISR_GRAPH_OVERLAP: auto (default) = 0: all buckets are all-reduced at the join after the replay -- the exchange is
+        <= 1 ms of a 53 ms step at 4 tiles per GPU, the signal nodes + wait kernels cost 1.3 ms where there is nothing to hide,
+        and the signalled path has never met a multi-rank RCCL world (no node was available to this build), so the robust
+        path is the default until it has been measured there | 1 = spin | poll | wait."""
         mode = os.environ.get("SISR_GRAPH_OVERLAP", "auto")
         return "spin" if mode == "1" else mode
 
     def can_signal(self):
         mode = self.graph_overlap_mode()
         if mode == "auto":
-            mode = "spin" if self.world > 1 else "0"
-        return self.flags is not None and self.overlap and mode != "0"
+            mode = "0"
+        from . import ops
+        # SISR_GRAPH_FORK=1 captures the weight gradients as parallel branches: a signal node on the capture stream would not
+        # be ordered behind them, so that combination joins all buckets after the replay
+        return self.flags is not None and self.overlap and mode != "0" and not ops.GRAPH_FORK
 
     def begin_capture(self):
         """Call on the capturing stream, right before the backward pass that is being captured."""
@@ -269,8 +276,10 @@ class GradReducer:
             self.works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.launched[bi] = True
 
-    def reduce(self):
-        """Join: every bucket reduced (launching those whose hooks did not fire), grads <- sum / world."""
+    def reduce(self, prescaled=False):
+        """Join: every bucket reduced (launching those whose hooks did not fire), grads <- sum / world.
+        prescaled: the caller has already divided by the world size (the handlers scale the LOSS by 1 / world before backward,
+        so the summed gradients are the average and the per-bucket scaling launches disappear from the step's tail)."""
         for bi in range(len(self.buckets)):
             if not self.launched[bi]:
                 self._launch(bi)
@@ -284,8 +293,8 @@ class GradReducer:
             self.works[bi].wait()
             if self.cuda:
                 torch.cuda.current_stream().wait_stream(self.stream)
-            flat = self.flat[bi]
-            flat.mul_(inv)  # one kernel per bucket; the averaged gradients are handed out as views of it
+            if not prescaled:
+                self.flat[bi].mul_(inv)  # one kernel per bucket; the averaged gradients are handed out as views of it
             for p in bucket:
                 if p.grad is not self.views[p]:
                     p.grad = self.views[p]
@@ -294,6 +303,8 @@ class GradReducer:
             self.works[bi] = None
 
     def remove(self):
+        """Detach from the network.  Captured hipGraphs whose signal nodes write this reducer's progress words must be destroyed
+        FIRST (BaseModel.remove_multi_gpu does both in that order): the words are freed here."""
         for h in self.handles:
             h.remove()
         self.handles = []

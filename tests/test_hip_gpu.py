@@ -237,6 +237,46 @@ def test_gate_heads_are_bit_identical_to_the_gate_launches(meta, shape):
         assert torch.equal(res[True][1][k], res[False][1][k]), k
 
 
+@pytest.mark.parametrize("meta", [False, True])
+@pytest.mark.parametrize("shape,lanes,heads", [((4, 37, 70), 2, True), ((4, 128, 128), 2, True), ((4, 40, 48), 4, True),
+                                               ((6, 32, 40), 2, False), ((6, 32, 40), 3, True)])
+def test_sample_lanes_are_bit_identical_to_one_chain(meta, shape, lanes, heads):
+    """Small launches of a residual group run as LANES chains of B / LANES samples on parallel streams (ops._lane_cuts; inside
+    a hipGraph capture by default, forced here in eager mode): every launch of a lane is the same kernel on a contiguous
+    slice of the batch and the weight gradients stay whole-batch launches, so outputs and every gradient equal the single
+    chain's to the bit -- with gate heads and with stand-alone gate launches, five blocks (two weight-gradient segments)."""
+    torch.manual_seed(8)
+    if meta:
+        net = A.QRCAN(n_resblocks=5, n_resgroups=2, n_feats=64, scale=2, style="standard", num_metadata=10,
+                      include_q_layer=True).to(DEV)
+    else:
+        net = A.RCAN(n_resblocks=5, n_resgroups=2, n_feats=64, scale=2).to(DEV)
+    B, H, W = shape
+    x = rnd(B, 3, H, W, seed=83, scale=0.5).to(DEV)
+    md = rnd(B, 10, 1, 1, seed=84, scale=0.3).to(DEV)
+    cot, res = None, {}
+    prev = (ops.LANES, ops.LANES_EAGER, ops.GATE_HEADS)
+    if ops.PRECISION != "fp32":
+        pytest.skip("sample lanes are an fp32-path feature")
+    try:
+        ops.GATE_HEADS = heads
+        for mode in (lanes, 1):
+            ops.LANES, ops.LANES_EAGER = mode, True
+            assert len(ops._lane_cuts(B, H, W)) == mode
+            net.zero_grad(set_to_none=True)
+            out = net(x, md) if meta else net(x)
+            if cot is None:
+                cot = rnd(*out.shape, seed=85).to(DEV)
+            out.backward(cot)
+            torch.cuda.synchronize()
+            res[mode] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    finally:
+        ops.LANES, ops.LANES_EAGER, ops.GATE_HEADS = prev
+    assert torch.equal(res[lanes][0], res[1][0])
+    for k in res[lanes][1]:
+        assert torch.equal(res[lanes][1][k], res[1][1][k]), k
+
+
 def test_conv_residual_alpha_and_multichunk():
     # 128 -> 192 channels, y = conv*alpha + res  (multi-chunk K loop and multiple output chunks)
     B, H, W = 1, 9, 35
@@ -721,7 +761,7 @@ def test_native_library_is_loaded():
         assert "libsisr_hip.so" in f.read()
 
 
-def _run_dp_worker(tmp_path, model, mode, steps, ranks, alt=0, port=29731, bucket_mb=None):
+def _run_dp_worker(tmp_path, model, mode, steps, ranks, alt=0, port=29731, bucket_mb=None, overlap="auto"):
     import os
     import subprocess
     import sys
@@ -733,7 +773,7 @@ def _run_dp_worker(tmp_path, model, mode, steps, ranks, alt=0, port=29731, bucke
         env.pop(k, None)
     if bucket_mb is not None:
         env["SISR_DP_BUCKET_MB"] = str(bucket_mb)
-    env.setdefault("SISR_GRAPH_OVERLAP", "auto")
+    env["SISR_GRAPH_OVERLAP"] = overlap  # auto = all buckets at the join after a replay; "1" = released by signal nodes
     args = [worker, out, model, mode, str(steps), str(alt)]
     if ranks == 1:
         cmd = [sys.executable] + args
@@ -779,7 +819,7 @@ def test_two_ranks_many_buckets_equal_one_process_gradients(tmp_path, mode):
     bucket k + 1 of the same arena; in graph mode the replay's signal nodes release the buckets one by one
     (GradReducer.launch_signalled) while the rest of the captured backward runs.  Same 2e-6 bound, four different batches."""
     one = _run_dp_worker(tmp_path, "qrcan", "eager", 4, 1, 0)
-    two = _run_dp_worker(tmp_path, "qrcan", mode, 4, 2, 0, 29777 + (mode == "graph"), bucket_mb=0.25)
+    two = _run_dp_worker(tmp_path, "qrcan", mode, 4, 2, 0, 29777 + (mode == "graph"), bucket_mb=0.25, overlap="1")
     assert two["buckets"] >= 4, two["buckets"]
     if mode == "graph":
         assert two["signalled"] and min(two["signalled"]) >= 4, two["signalled"]  # the overlapped path, not the join

@@ -83,8 +83,13 @@ PY
       local tag=$1; shift
       ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d "$O/prof_$tag" -o p -- python "$R/$1" "${@:2}" > "$O/prof_$tag.log" 2>&1 )
       python tools/rocpd_step.py "$O/prof_$tag/p_results.db" > "$O/anatomy_$tag.txt"
+      python tools/rocpd_gaps.py "$O/prof_$tag/p_results.db" 15 >> "$O/anatomy_$tag.txt"
+      python tools/rocpd_window.py "$O/prof_$tag/p_results.db" 300 50 > "$O/window_$tag.txt"; python tools/rocpd_window.py "$O/prof_$tag/p_results.db" 1200 50 >> "$O/window_$tag.txt"
       python tools/rocpd_stats.py "$O/prof_$tag/p_results.db" > "$O/kernel_stats_$tag.csv"
       rm -rf "$O/prof_$tag"; cat "$O/anatomy_$tag.txt" | cut -c1-160 ;;
+    lanes)      # lanes [BATCHES] [extra lane_probe args]: half-batch conv chains on parallel graph branches
+      local bs=${1:-4 8}; shift || true
+      for b in $bs; do timeout -k 10 300 python tools/lane_probe.py --batch $b "$@" > "$O/lanes_b$b.jsonl" 2> "$O/lanes_b$b.err" || tail -5 "$O/lanes_b$b.err"; cat "$O/lanes_b$b.jsonl"; done ;;
     pmc)        # pmc TAG COUNTER kbench-args...: one rocprofv3 --pmc pass over tools/kbench.py -> per-kernel mean of the counter
       local tag=$1 ctr=$2; shift 2
       ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$O/pmc_${tag}_$ctr" -o p -- python "$R/tools/kbench.py" "$@" > "$O/pmc_${tag}_$ctr.log" 2>&1 )
