@@ -5,5 +5,5 @@ Import with ``importlib.import_module("super-resolution-meta-attention-networks_
 architectures (drop-in nn.Modules), handlers (model-handler API), parallel (RCCL data parallelism),
 metrics (PSNR).
 """
-from . import hip, ops, architectures, metrics, handlers, parallel, han, san, srmd, sftmd, sparnet, degrade, data, cli  # noqa: F401
+from . import hip, ops, optim, architectures, metrics, handlers, parallel, han, san, srmd, sftmd, sparnet, degrade, data, cli  # noqa: F401
 from .handlers import ModelInterface, available_models  # noqa: F401

@@ -194,12 +194,88 @@ class ResidualGroup(nn.Module):
         return _conv(mods[-1], res, residual=x)
 
 
+# ----------------------------------------------------------------------------- feature counts that are not multiples of 64
+class ChannelPadded:
+    """Mixin of the residual-conv networks (RCAN / QRCAN / EDSR / QEDSR / HAN / QHAN) for a feature count n that is not a
+    multiple of 64 (the reference takes any width: ref attention_manipulators/handlers.py:24-29, advanced/architectures.py:126-161).
+
+    The kernels work on 64-channel chunks, so such a network RUNS as its twin of width P = the next multiple of 64 with
+    every parameter zero-padded -- exactly the same function: padded conv outputs are 0 (zero weights and bias), padded
+    inputs meet zero weights, a padded hidden unit of a gate is ReLU(0) = 0, and a padded gate value (sigmoid(0)) only ever
+    multiplies a zero map.  Parameters, state_dict() keys and shapes, the optimiser and checkpoints stay the reference's: the
+    padding is a differentiable op per parameter (ops.pad_param, one launch each way) applied every forward, the twin is
+    a parameter-less skeleton on the meta device called through torch.func.functional_call, and autograd hands the gradients
+    back cropped.  Costs one small launch per parameter and pass -- these widths appear in no published configuration.
+
+    Layout rules of the padded axes (a dimension of size k * n is padded per n-run, never as a suffix of the whole):
+      * [n][k]  the Upsampler convs' output channels and biases (PixelShuffle reads channel c * r^2 + i * r + j);
+      * [k][n]  channel concatenations on the input side (HAN's 11 n and 2 n convs);
+      * anything else that differs from the twin (gate hidden sizes such as n // 16, n // 2) is padded as a suffix."""
+
+    _twin = None
+
+    def _init_padding(self, n_feats, build_twin, nk=None):
+        """Call at the end of __init__: build_twin(P) -> the same architecture at width P.  nk(key, dim) -> True where a
+        k * n axis is laid out [n][k] (default: dimension 0 of the Upsampler's parameters, 'tail.0.*')."""
+        if n_feats % 64 == 0:
+            return
+        if nk is None:
+            nk = lambda k, d: d == 0 and ".tail.0." in "." + k  # noqa: E731
+        P = (n_feats + 63) // 64 * 64
+        with torch.device("meta"):
+            twin = build_twin(P)
+        want = {k: tuple(v.shape) for k, v in twin.named_parameters()}
+        have = {k: tuple(v.shape) for k, v in self.named_parameters()}
+        if list(want) != list(have):
+            raise RuntimeError("channel padding: the twin network's parameter names differ")
+        plans = {}
+        for k, real in have.items():
+            cur, steps = list(real), []
+            for d in range(len(real)):
+                r, t = real[d], want[k][d]
+                if r == t:
+                    continue
+                before = 1
+                for q in cur[:d]:
+                    before *= q
+                after = 1
+                for q in cur[d + 1:]:
+                    after *= q
+                if r % n_feats == 0 and t == r // n_feats * P:
+                    kk = r // n_feats
+                    if kk > 1 and nk(k, d):                           # Upsampler: [n][r^2]
+                        steps.append((before, n_feats, kk * after, P))
+                    else:                                             # plain axis, or a [k][n] concatenation
+                        steps.append((before * kk, n_feats, after, P))
+                elif t > r:
+                    steps.append((before, r, after, t))
+                else:
+                    raise RuntimeError(f"channel padding: {k} {real} -> {want[k]}")
+                cur[d] = t
+            plans[k] = (steps, want[k])
+        object.__setattr__(self, "_twin", twin)  # not a registered sub-module: no parameters, no state-dict entries
+        self._pad_plans, self._pad_width = plans, (n_feats, P)
+
+    def padded(self):
+        return self._twin is not None
+
+    def _run_padded(self, *args):
+        shadow = {k: ops.pad_param(p, *self._pad_plans[k]) for k, p in self.named_parameters()}
+        return torch.func.functional_call(self._twin, shadow, args)
+
+
+def _pad_channels(t, n, P):
+    """(B, n, 1, 1) per-channel metadata (QRCAN 'modulate': one value per feature channel) -> (B, P, 1, 1), zeros behind."""
+    B = t.shape[0]
+    return ops.pad_param(t.reshape(B, n), [(B, n, 1, P)], (B, P, 1, 1))
+
+
 def _check_rgb(x, what):
     if not x.is_cuda:
         raise RuntimeError(f"{what}: this network only runs on a HIP device (no CPU fallback); got a CPU tensor")
 
 
-class RCAN(nn.Module):
+class RCAN(ChannelPadded, nn.Module):
     """ref: advanced/architectures.py:126-161"""
 
     def __init__(self, n_resblocks=20, n_resgroups=10, n_feats=64, in_feats=3, out_feats=3, scale=4, reduction=16,
@@ -214,9 +290,12 @@ class RCAN(nn.Module):
         self.head = nn.Sequential(*head)
         self.body = nn.Sequential(*body)
         self.tail = nn.Sequential(*tail)
+        self._init_padding(n_feats, lambda P: RCAN(n_resblocks, n_resgroups, P, in_feats, out_feats, scale, reduction, res_scale))
 
     def forward(self, x):
         _check_rgb(x, "RCAN")
+        if self.padded():
+            return self._run_padded(x)
         x = _conv(self.head[0], x)
         res = x
         mods = list(self.body)
@@ -226,7 +305,7 @@ class RCAN(nn.Module):
         return _conv(self.tail[1], self.tail[0](res))
 
 
-class EDSR(nn.Module):
+class EDSR(ChannelPadded, nn.Module):
     """ref: advanced/architectures.py:183-225"""
 
     def __init__(self, in_features=3, out_features=3, net_features=64, num_blocks=16, scale=4, res_scale=0.1):
@@ -239,9 +318,12 @@ class EDSR(nn.Module):
         self.head = nn.Sequential(*head)
         self.body = nn.Sequential(*body)
         self.tail = nn.Sequential(*tail)
+        self._init_padding(net_features, lambda P: EDSR(in_features, out_features, P, num_blocks, scale, res_scale))
 
     def forward(self, x):
         _check_rgb(x, "EDSR")
+        if self.padded():
+            return self._run_padded(x)
         x = _conv(self.head[0], x)
         res = x
         mods = list(self.body)
@@ -431,7 +513,7 @@ class QResidualGroup(nn.Module):
         return _conv(self.final_body, res, residual=feat), md
 
 
-class QRCAN(nn.Module):
+class QRCAN(ChannelPadded, nn.Module):
     """ref: attention_manipulators/architectures.py:246-316"""
 
     def __init__(self, n_resblocks=20, n_resgroups=10, n_feats=64, in_feats=3, out_feats=3, scale=4, reduction=16,
@@ -452,9 +534,20 @@ class QRCAN(nn.Module):
         self.head = nn.Sequential(*head)
         self.body = nn.Sequential(*body)
         self.tail = nn.Sequential(*tail)
+        if n_feats % 64 and style not in ('standard', 'modulate'):
+            raise NotImplementedError(f"QRCAN style '{style}' concatenates metadata inside its FC stack; with n_feats not a multiple "
+                                      f"of 64 only 'standard' and 'modulate' are built (channel padding, ChannelPadded)")
+        self._init_padding(n_feats, lambda P: QRCAN(
+            n_resblocks, n_resgroups, P, in_feats, out_feats, scale, reduction, res_scale, style, num_metadata,
+            include_pixel_attention, selective_meta_blocks, num_q_layers_inner_residual, include_q_layer))
 
     def forward(self, x, metadata):
         _check_rgb(x, "QRCAN")
+        if self.padded():
+            n, P = self._pad_width
+            if self.style == 'modulate':  # one metadata value per feature channel (handlers.QRCANHandler.scale_qpi)
+                metadata = _pad_channels(metadata, n, P)
+            return self._run_padded(x, metadata)
         x = _conv(self.head[0], x)
         res = x
         qblocks = [b for g in self.body for b in g.body if b.q_layer]
@@ -488,7 +581,7 @@ class ParamResBlock(nn.Module):
         return y, md
 
 
-class QEDSR(nn.Module):
+class QEDSR(ChannelPadded, nn.Module):
     """ref: attention_manipulators/architectures.py:359-399"""
 
     def __init__(self, in_features=3, out_features=3, num_features=64, input_para=1, num_blocks=16, scale=4,
@@ -501,9 +594,13 @@ class QEDSR(nn.Module):
         tail = [Upsampler(default_conv, scale, num_features), default_conv(num_features, out_features, 3)]
         self.body = nn.Sequential(*body)
         self.tail = nn.Sequential(*tail)
+        self._init_padding(num_features, lambda P: QEDSR(in_features, out_features, P, input_para, num_blocks, scale, res_scale,
+                                                         q_layer_nonlinearity))
 
     def forward(self, x, metadata):
         _check_rgb(x, "QEDSR")
+        if self.padded():
+            return self._run_padded(x, metadata)
         x = _conv(self.head, x)
         res = x
         for blk, m in zip(self.body, meta_gates([b.attention_layer for b in self.body], metadata)):

@@ -60,7 +60,7 @@ def _han_tail(net, x_head, maps):
     return A._conv(net.tail[1], net.tail[0](res))
 
 
-class HAN(nn.Module):
+class HAN(A.ChannelPadded, nn.Module):
     """ref: advanced/architectures.py:314-377"""
 
     def __init__(self, n_resgroups=10, n_resblocks=20, n_feats=64, reduction=16, scale=4, n_colors=3, res_scale=1.0,
@@ -79,9 +79,12 @@ class HAN(nn.Module):
         self.last_conv = nn.Conv2d(n_feats * 11, n_feats, 3, 1, 1)
         self.last = nn.Conv2d(n_feats * 2, n_feats, 3, 1, 1)
         self.tail = nn.Sequential(*tail)
+        self._init_padding(n_feats, lambda P: HAN(n_resgroups, n_resblocks, P, reduction, scale, n_colors, res_scale, conv))
 
     def forward(self, x):
         A._check_rgb(x, "HAN")
+        if self.padded():
+            return self._run_padded(x)
         x = A._conv(self.head[0], x)
         res, maps = x, []
         mods = list(self.body)
@@ -93,7 +96,7 @@ class HAN(nn.Module):
         return _han_tail(self, x, maps)
 
 
-class QHAN(nn.Module):
+class QHAN(A.ChannelPadded, nn.Module):
     """ref: attention_manipulators/architectures.py:470-540"""
 
     def __init__(self, n_resgroups=10, n_resblocks=20, n_feats=64, reduction=16, num_metadata=0, scale=4, n_colors=3,
@@ -113,9 +116,13 @@ class QHAN(nn.Module):
         self.last_conv = nn.Conv2d(n_feats * 11, n_feats, 3, 1, 1)
         self.last = nn.Conv2d(n_feats * 2, n_feats, 3, 1, 1)
         self.tail = nn.Sequential(*tail)
+        self._init_padding(n_feats, lambda P: QHAN(n_resgroups, n_resblocks, P, reduction, num_metadata, scale, n_colors,
+                                                   res_scale, conv, num_q_layers_inner_residual))
 
     def forward(self, x, metadata):
         A._check_rgb(x, "QHAN")
+        if self.padded():
+            return self._run_padded(x, metadata)
         x = A._conv(self.head[0], x)
         res, maps = x, []
         mods = list(self.body)

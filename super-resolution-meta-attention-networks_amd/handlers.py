@@ -469,10 +469,6 @@ class QRCANHandler(QModel):
                  scheduler_params=None, style='modulate', perceptual=None, clamp=False, min_mu=-0.2, max_mu=0.8,
                  n_feats=64, **kwargs):
         super().__init__(device=device, model_save_dir=model_save_dir, eval_mode=eval_mode, **kwargs)
-        if n_feats % 64:  # fail at construction, not at the first forward (ref: attention_manipulators/handlers.py:24-29)
-            raise NotImplementedError("QRCAN on the gfx950 kernels: n_feats must be a multiple of 64 (64, the reference's "
-                                      "default and every sample config, runs the fused group node; wider nets the modular "
-                                      "gated blocks)")
         self.net = A.QRCAN(scale=scale, in_feats=in_features, num_metadata=self.num_metadata, n_feats=n_feats,
                            style=style, **kwargs)
         self.colorspace = 'augmented_rgb'

@@ -1052,7 +1052,7 @@ class _ResBlock(Function):
 # cover the other's staging and stores (tools/lane_probe.py: 38.7 -> 36.7 us per 4-tile link, mask form 40.5 -> 37.6).
 # Used where launches are small AND the step is replayed from a hipGraph (eager launches at these sizes are host-bound and
 # lanes double their number); the weight gradients stay whole-batch launches: the lanes meet before every batch of eight.
-LANES = int(os.environ.get("SISR_LANES", 2))
+LANES = int(os.environ.get("SISR_LANES", 1))  # measured: no gain inside the replayed step, so one chain by default
 LANES_EAGER = os.environ.get("SISR_LANES_EAGER", "0") != "0"  # tests / probes: lanes outside a capture too
 LANES_MAX_PIXELS = int(os.environ.get("SISR_LANES_MAX_PIXELS", 8 * 128 * 128))
 LANES_INTERLEAVE = os.environ.get("SISR_LANES_INTERLEAVE", "1") != "0"  # issue the lanes' launches block by block, alternating
@@ -1558,6 +1558,36 @@ def _crop_oihw(wp, shape):
     hip.check(hip.lib().sisr_pad_oihw(hip.ptr(wp), hip.ptr(out), co, ci, wp.shape[0], wp.shape[1] if wp.dim() > 1 else 1,
                                       taps, 1, hip.stream()), "sisr_pad_oihw(crop)")
     return out
+
+
+class _PadAxis(Function):
+    """Zero-pad ONE axis of a contiguous tensor seen as [outer][n][inner] to [outer][P][inner] (one sisr_pad_oihw launch);
+    backward crops.  The building block of pad_param."""
+
+    @staticmethod
+    def forward(ctx, t, outer, n, inner, P):
+        t = t.contiguous()
+        ctx.geo = (outer, n, inner, P)
+        out = torch.empty(outer * P * inner, device=t.device, dtype=torch.float32)
+        hip.check(hip.lib().sisr_pad_oihw(hip.ptr(t), hip.ptr(out), outer, n, outer, P, inner, 0, hip.stream()), "sisr_pad_oihw")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outer, n, inner, P = ctx.geo
+        g = g.contiguous()
+        out = torch.empty(outer * n * inner, device=g.device, dtype=torch.float32)
+        hip.check(hip.lib().sisr_pad_oihw(hip.ptr(g), hip.ptr(out), outer, n, outer, P, inner, 1, hip.stream()),
+                  "sisr_pad_oihw(crop)")
+        return out, None, None, None, None
+
+
+def pad_param(t, steps, shape):
+    """Differentiable zero-padding of a parameter for a network whose feature count is not a multiple of 64 (architectures.
+    ChannelPadded): steps = [(outer, n, inner, P)] applied in order, the result viewed as `shape`.  Gradients come back cropped."""
+    for outer, n, inner, P in steps:
+        t = _PadAxis.apply(t, outer, n, inner, P)
+    return t.reshape(shape)
 
 
 class _ConvChain(Function):

@@ -228,16 +228,27 @@ def _rgb_in(img):
     return ops.nchw_to_nhwc_pad(img)
 
 
-def _count_batches(net):
+class _count_batches:
     """nn.BatchNorm2d.forward adds one to num_batches_tracked per training forward: the network's ~190 counters in one
-    multi-tensor add instead of ~190 one-element kernels (the batch-norm op then leaves them alone)."""
-    if not net.training:
-        return
-    bns = [m for m in net.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
-    for m in bns:
-        m._sisr_counted_by_net = True
-    if bns:
-        torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+    multi-tensor add instead of ~190 one-element kernels.  While the network's forward runs, every batch norm that was counted
+    here carries a mark that tells ops.batch_norm_act to leave its counter alone; the marks come off when the forward returns,
+    so a sub-module called on its own later counts for itself again.  A batch norm counts iff ITS OWN .training is set (a
+    frozen batch norm inside a training network does not)."""
+
+    def __init__(self, net):
+        self.bns = [m for m in net.modules() if isinstance(m, nn.BatchNorm2d) and m.training and m.num_batches_tracked is not None]
+
+    def __enter__(self):
+        for m in self.bns:
+            m._sisr_counted_by_net = True
+        if self.bns:
+            torch._foreach_add_([m.num_batches_tracked for m in self.bns], 1)
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.bns:
+            m._sisr_counted_by_net = False
+        return False
 
 
 class SPARNet(nn.Module):
@@ -250,11 +261,11 @@ class SPARNet(nn.Module):
                bottleneck_size, None, False)
 
     def forward(self, input_img):
-        _count_batches(self)
-        out = self.encoder(_rgb_in(input_img))
-        out = self.res_layers(out)
-        out = self.decoder(out)
-        return ops.shuffle_rgb(self.out_conv(out), 3, 1)
+        with _count_batches(self):
+            out = self.encoder(_rgb_in(input_img))
+            out = self.res_layers(out)
+            out = self.decoder(out)
+            return ops.shuffle_rgb(self.out_conv(out), 3, 1)
 
 
 class QSPARNet(nn.Module):
@@ -268,11 +279,11 @@ class QSPARNet(nn.Module):
                bottleneck_size, metadata_count, metadata_encoder_only)
 
     def forward(self, input_img, metadata):
-        _count_batches(self)
-        out, _ = self.encoder((_rgb_in(input_img), metadata))
-        out, _ = self.res_layers((out, metadata))
-        out, _ = self.decoder((out, metadata))
-        return ops.shuffle_rgb(self.out_conv(out), 3, 1)
+        with _count_batches(self):
+            out, _ = self.encoder((_rgb_in(input_img), metadata))
+            out, _ = self.res_layers((out, metadata))
+            out, _ = self.decoder((out, metadata))
+            return ops.shuffle_rgb(self.out_conv(out), 3, 1)
 
 
 class SPARNetHandler(BaseModel):
