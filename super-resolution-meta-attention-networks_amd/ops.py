@@ -1566,6 +1566,7 @@ class _PadAxis(Function):
 
     @staticmethod
     def forward(ctx, t, outer, n, inner, P):
+        ctx.in_shape = tuple(t.shape)
         t = t.contiguous()
         ctx.geo = (outer, n, inner, P)
         out = torch.empty(outer * P * inner, device=t.device, dtype=torch.float32)
@@ -1579,7 +1580,7 @@ class _PadAxis(Function):
         out = torch.empty(outer * n * inner, device=g.device, dtype=torch.float32)
         hip.check(hip.lib().sisr_pad_oihw(hip.ptr(g), hip.ptr(out), outer, n, outer, P, inner, 1, hip.stream()),
                   "sisr_pad_oihw(crop)")
-        return out, None, None, None, None
+        return out.reshape(ctx.in_shape), None, None, None, None
 
 
 def pad_param(t, steps, shape):
