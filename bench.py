@@ -59,6 +59,11 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: fp32 ma
 HBM_PEAK_GBS = 8000.0          # same guide: HBM3E ~8 TB/s
 # algorithmic HBM bytes per LR patch, fwd + bwd, fp32 maps, layer at a time with the legal fusions
 HBM_GB_PER_PATCH = {"rcan": 16.5, "qrcan": 16.5, "edsr": 1.4, "qedsr": 1.4, "han": 17.0, "qhan": 17.0}
+# ... with the residual groups' kept activations stored as bf16 (ops.set_storage("act")): per RCAB forward 3 fp32-map units
+# instead of 6 (conv1 with the GATE prologue reads t2 and the skip and writes the new skip and t1, conv2 reads t1 and writes
+# t2: six half-size maps), backward 9 instead of 11 (the ReLU mask, the DOT operand and both weight gradients' x operand are
+# half size; gradient maps stay fp32): 200 blocks x 5 x 4 MiB = 4.2 GB less per patch
+HBM_GB_PER_PATCH_ACT16 = {k: v - 4.2 for k, v in HBM_GB_PER_PATCH.items() if k in ("rcan", "qrcan", "han", "qhan")}
 # algorithmic HBM bytes of ONE 64 -> 64 launch per 128 x 128 sample (fp32 maps of 4 MiB): what each kernel family must move
 FAMILY_MAPS = {"conv fwd, plain": 2, "conv fwd, GATE": 4, "dgrad, ReLU mask": 3, "dgrad + residual, DOT": 4,
                "dgrad, plain / residual": 3, "wgrad": 2}
@@ -346,6 +351,8 @@ def main():
                     help="arithmetic of the 64-channel convs: fp32 MFMA (reference arithmetic, the headline); bf16 MFMA "
                          "operands with fp32 accumulate / storage (BASELINE config 'HAN x4 bf16'); bf16x3 = fp32 operands "
                          "split exactly into three bf16 numbers, six products on the bf16 MFMA (fp32-class error)")
+    ap.add_argument("--storage", default="0", choices=["0", "act"],
+                    help="with --precision bf16: storage of the maps a residual group keeps: 0 = fp32, act = bf16 activations")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -356,6 +363,10 @@ def main():
     import importlib
     sisr = importlib.import_module("sisr_amd")
     sisr.ops.set_precision(args.precision)
+    if args.storage != "0":
+        if args.precision != "bf16":
+            raise SystemExit("--storage act needs --precision bf16")
+        sisr.ops.set_storage(args.storage)
     rank, world, local = sisr.parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
@@ -454,22 +465,29 @@ def main():
                 "grad_exchange": s4o.get("grad_exchange")}
 
     def han_bf16():
-        # BASELINE config 5: HAN x4, bf16 matrix-core operands (opt-in mode), 16 tiles
+        # BASELINE config 5: HAN x4, bf16 matrix-core operands (opt-in mode), 16 tiles, the residual
+        # groups' kept activations stored as bf16; the same step with fp32 maps beside it
         sisr.ops.set_precision("bf16")
         try:
             # (80 ms steps: 4 warm-up and 10 timed ones; with 2 / 5 the reading swings between 185 and 210)
-            sh = measure(sisr, "han", 16, max(2, min(args.steps, 10)), max(min(args.warmup, 2), 4 if args.warmup else 0), False,
-                         rank, world, local, dev)
+            n_t, n_w = max(2, min(args.steps, 10)), max(min(args.warmup, 2), 4 if args.warmup else 0)
+            s32 = measure(sisr, "han", 16, n_t, n_w, False, rank, world, local, dev)
+            sisr.ops.set_storage("act")
+            sh = measure(sisr, "han", 16, n_t, n_w, False, rank, world, local, dev)
         finally:
+            sisr.ops.set_storage("0")
             sisr.ops.set_precision("fp32")
-        gb_per_patch = sisr.ops.hbm_gb_per_patch("han") if hasattr(sisr.ops, "hbm_gb_per_patch") else HBM_GB_PER_PATCH["han"]
+        gb_per_patch = HBM_GB_PER_PATCH_ACT16["han"]
         gbs = sh["value"] * gb_per_patch
         t16 = pmc_traffic("bf16")  # measured / algorithmic HBM bytes per launch of the bf16 kernels (from the PMC CSVs)
         tfam16 = t16["families_b32"] if t16 is not None else None
         return {"workload": "HAN x4 full depth, 16 tiles of 128x128, train step (BASELINE config 5)",
-                "dtype": "bf16 MFMA operands (rounded while staged into LDS), f32 accumulate, f32 feature maps / gradients / "
-                         "optimiser state in HBM", "value": sh["value"], "unit": "patches/s", "ms_per_step": sh["ms_per_step"],
-                "final_loss": sh["loss"],
+                "dtype": "bf16 MFMA operands, f32 accumulate; the residual groups' kept activations (t1, t2, gated skips) stored "
+                         "as bf16 in HBM, gradient maps / group inputs and outputs / optimiser state f32",
+                "value": sh["value"], "unit": "patches/s", "ms_per_step": sh["ms_per_step"], "final_loss": sh["loss"],
+                "fp32_map_storage": {"value": s32["value"], "unit": "patches/s", "ms_per_step": s32["ms_per_step"],
+                                     "hbm_gb_per_patch": HBM_GB_PER_PATCH["han"],
+                                     "frac_of_hbm_peak": s32["value"] * HBM_GB_PER_PATCH["han"] / HBM_PEAK_GBS},
                 "roofline": {"bound": "hbm", "what": "whole step: algorithmic bytes per patch of the storage format in use "
                              "(%.1f GB per patch fwd+bwd) x patches/s" % gb_per_patch, "achieved": gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic_families": tfam16,
@@ -578,9 +596,10 @@ def main():
                                 "frac": step_tf / peak, "traffic": None,
                                 "vs_fp32_mfma_peak": step_tf / FP32_MFMA_PEAK_TFLOPS}
         else:
-            # bf16 mode: every conv moves two fp32 maps per launch and ~15 us of MFMA: HBM-bound
-            gbs = value / world * HBM_GB_PER_PATCH.get(workload, 16.5)
-            line["roofline"] = {"bound": "hbm", "what": "whole step, algorithmic fp32-map bytes per patch x patches/s per GPU",
+            # bf16 mode: every conv moves two maps per launch and ~15 us of MFMA: HBM-bound
+            table = HBM_GB_PER_PATCH_ACT16 if args.storage == "act" else HBM_GB_PER_PATCH
+            gbs = value / world * table.get(workload, 16.5)
+            line["roofline"] = {"bound": "hbm", "what": "whole step, algorithmic bytes per patch of the storage format in use x patches/s per GPU",
                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                 "traffic": None,
                                 "secondary": {"bound": "mfma", "achieved": step_tf, "peak": 2500.0, "unit": "TFLOP/s",

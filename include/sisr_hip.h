@@ -274,6 +274,25 @@ int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, const float* dy
                            int bias_n, int bias_q, float* workspace, size_t workspace_bytes, int B, int H, int W,
                            int cin, int cout, void* stream);
 
+/* ---- bf16 STORAGE of the maps a residual group keeps (opt-in on top of the bf16 operand mode; BASELINE config 5) -------
+ * ref: the maps are the reference's fp32 activations of advanced/architectures.py:48-71, :94-110 (RCAB / ResidualGroup);
+ * the reference has no reduced-precision mode -- parity is pinned to the oracle's restatement of exactly this rounding.
+ * A bf16 map has the View of its fp32 twin (strides in ELEMENTS) and 2-byte elements; it is passed as float* (16-byte
+ * aligned).  storage bits of the conv: 1 = x / gate_add / gate_out, 2 = y, 4 = mask / dot, 8 = res are bf16 maps.  64 -> 64
+ * only, always the persistent tile loop; only the combinations the fused group node launches exist (others: unsupported).
+ * Weight gradient: storage 1 = x is a bf16 map, 3 = x and dY are.  sisr_f32_to_bf16 rounds a map to nearest even. */
+int sisr_conv3x3_c64_bf16s(const float* x, const int64_t* xview, const void* wpacked_bf16, const float* bias, int bias_n,
+                           int bias_q, float* y, const int64_t* yview, const float* res, const float* mask,
+                           const float* in_scale, const float* in_shift, float alpha, int relu, float* gap_partial,
+                           const float* gate_add, float* gate_out, const float* dot, int B, int H, int W, int storage,
+                           void* stream);
+int sisr_wgrad3x3_c64_bf16s(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
+                            const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so, int64_t si,
+                            int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n, int in_perm_q, float* dbias,
+                            int bias_n, int bias_q, float* workspace, size_t workspace_bytes, int B, int H, int W,
+                            int cin, int cout, int storage, void* stream);
+int sisr_f32_to_bf16(const float* src, void* dst, long n, void* stream); /* n a multiple of 8 */
+
 /* ---- SAN attention modules ---------------------------------------------------------------------
  * Second-order channel attention, ref: advanced/SAN_blocks.py:244-302 SOCA + advanced/mpncov.py:12-112.
  *   covpool_fwd : cov[b] = (1/M) sum_p (x_p - mean[b]) x_p^T      x [B][M][64] channels-last, mean [B][64]

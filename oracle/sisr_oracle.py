@@ -32,10 +32,32 @@ import torch.nn.functional as F
 # storage; bias gradient from the unrounded output gradient.  The reference has no such mode: vectors for it are
 # "parity unpinned" against the reference and pinned only against this restatement.
 CONV_PRECISION = "fp32"
+# Storage of the maps a residual group keeps, in the product's bf16 mode ("bf16 storage"): "fp32", or
+# "bf16" = the group's input copy, t1 = ReLU(conv1), t2 = conv2 and the gated skips u_k are rounded to bf16 (nearest even)
+# where they are written -- what sits in HBM and what every later launch reads -- while the channel-attention pooling takes
+# the unrounded conv2 output (the kernel sums its fp32 accumulators), gradient maps stay fp32 and pass the rounding unchanged.
+# Restated for the blocks the product runs as ONE group node (RCAB stacks, QRCAB 'standard' without pixel attention).
+MAP_STORAGE = "fp32"
 
 
 def _r16(t):
     return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _StoreBf16(torch.autograd.Function):
+    """A map written to HBM as bf16: the value is rounded, the gradient passes (the backward kernels rebuild gradients in fp32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _r16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _st(x):
+    return _StoreBf16.apply(x) if (MAP_STORAGE == "bf16" and CONV_PRECISION == "bf16") else x
 
 
 class _Bf16Conv(torch.autograd.Function):
@@ -183,8 +205,22 @@ def rcab(sd, key, x):
     return ca_layer(sd, key + ".body.3", r) + x
 
 
+def _stored_group(x, n_resblocks, block_key, tail_key, sd, gate_fn):
+    """A group of channel-attention blocks with its kept maps in bf16 (MAP_STORAGE): gate_fn(k, t2_unrounded) -> (B,C,1,1)."""
+    u = _st(x)
+    for i in range(n_resblocks):
+        key = block_key(i)
+        t1 = _st(F.relu(conv(sd, key + ".body.0", u)))
+        t2 = conv(sd, key + ".body.2", t1)
+        u = _st(_st(t2) * gate_fn(i, t2) + u)
+    return conv(sd, tail_key, u) + x
+
+
 def residual_group(sd, key, x, n_resblocks):
     """ref: advanced/architectures.py:107-110."""
+    if MAP_STORAGE == "bf16" and CONV_PRECISION == "bf16" and x.shape[1] == 64:
+        return _stored_group(x, n_resblocks, lambda i: f"{key}.body.{i}", f"{key}.body.{n_resblocks}", sd,
+                             lambda i, t2: ca_gate(sd, f"{key}.body.{i}.body.3", t2))
     r = x
     for i in range(n_resblocks):
         r = rcab(sd, f"{key}.body.{i}", r)
@@ -204,6 +240,12 @@ def qrcab(sd, key, x, md, style, pa, q_layer):
 
 def q_residual_group(sd, key, x, md, n_resblocks, style, pa, q_layer, num_q_layers):
     """ref: attention_manipulators/architectures.py:215-233."""
+    if MAP_STORAGE == "bf16" and CONV_PRECISION == "bf16" and style == "standard" and not pa and x.shape[1] == 64:
+        def gate(i, t2):
+            q_in = q_layer if (num_q_layers is None or i < num_q_layers) else False
+            g = ca_gate(sd, f"{key}.body.{i}.final_body", t2)
+            return g * para_ca_gate(sd, f"{key}.body.{i}.q_node", md, nonlinearity=True) if q_in else g
+        return _stored_group(x, n_resblocks, lambda i: f"{key}.body.{i}", key + ".final_body", sd, gate)
     r = x
     for i in range(n_resblocks):
         q_in = q_layer if (num_q_layers is None or i < num_q_layers) else False

@@ -1636,7 +1636,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3_kernel(ConvParams p, lo
 // Arithmetic, fragment order and results are those of conv3x3_c64_bf16_kernel.
 #define PB_BUF (TH * TW * BE_LD * 4)
 
-template <bool AFFINE, bool MASK, bool RES, bool GATE, bool DOT>
+// bf16 STORAGE of maps (sisr_conv3x3_c64_bf16s): a map kept in HBM as bf16 has the same View (strides in elements) and is
+// addressed through a `const float*` field of ConvParams reinterpreted as 2-byte elements.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sisr_unpack_bf16x8(u32x4 w, f32x4& a, f32x4& b) {  // exact: a bf16 is the top half of a float
+  a[0] = __uint_as_float(w[0] << 16); a[1] = __uint_as_float(w[0] & 0xffff0000u);
+  a[2] = __uint_as_float(w[1] << 16); a[3] = __uint_as_float(w[1] & 0xffff0000u);
+  b[0] = __uint_as_float(w[2] << 16); b[1] = __uint_as_float(w[2] & 0xffff0000u);
+  b[2] = __uint_as_float(w[3] << 16); b[3] = __uint_as_float(w[3] & 0xffff0000u);
+}
+__device__ __forceinline__ f32x4 sisr_load_bf16x4(const float* base, long elem) {  // four consecutive bf16 elements -> fp32
+  const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+  f32x4 r;
+  r[0] = __uint_as_float(w[0] << 16); r[1] = __uint_as_float(w[0] & 0xffff0000u);
+  r[2] = __uint_as_float(w[1] << 16); r[3] = __uint_as_float(w[1] & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ void sisr_store_bf16x4(float* base, long elem, f32x4 v) {  // RNE
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  bf16x4_t r;
+  r[0] = (__bf16)v[0]; r[1] = (__bf16)v[1]; r[2] = (__bf16)v[2]; r[3] = (__bf16)v[3];
+  *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + elem) = __builtin_bit_cast(u32x2, r);
+}
+
+// IN16: x, gate_add and gate_out are bf16 maps (the halo goes to LDS without conversion unless a prologue touches it);
+// OUT16: y is a bf16 map (rounded once, in the epilogue's store); AUX16: mask and dot are bf16 maps; RES16: res is.
+template <bool AFFINE, bool MASK, bool RES, bool GATE, bool DOT, bool IN16 = false, bool OUT16 = false, bool AUX16 = false,
+          bool RES16 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvParams p, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1667,9 +1693,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
   // 8 c8 .. +7 of halo column pcol + 1 in all six rows; the two edge columns (0 and 33: 6 rows x 2 x 8 chunks = 96
   // items) go one per thread to tid % 96 (threads 96.. load a duplicate and do not write), so every load is
   // unconditional and a thread holds 14 float4 pairs per tile.
-  struct Halo {
-    f32x4 in[HALO_H][2];
-    f32x4 ed[2];
+  struct Halo {  // IN16: one 16-B piece (eight bf16) per item, held in in[r][0] / ed[0] as raw bits
+    f32x4 in[HALO_H][IN16 ? 1 : 2];
+    f32x4 ed[IN16 ? 1 : 2];
   };
   Halo v;
   const int eidx = tid % 96, er = eidx >> 4, eside = (eidx >> 3) & 1, ec8 = eidx & 7;
@@ -1683,18 +1709,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
   auto issue = [&](const float* src, int tile, Halo& dst) {
     int b, h0, w0;
     decode(tile, b, h0, w0);
-    const float* xb = src + (long)b * p.xv.sB;
     const int gwi = min(w0 + pcol, W - 1);
-#pragma unroll
-    for (int r = 0; r < HALO_H; ++r) {
-      const float* a = xb + (long)min(max(h0 - 1 + r, 0), H - 1) * p.xv.sH + gwi * (int)p.xv.sW + c8 * 8;
-      dst.in[r][0] = *reinterpret_cast<const f32x4*>(a);
-      dst.in[r][1] = *reinterpret_cast<const f32x4*>(a + 4);
-    }
     const int gwe = min(max(eside ? w0 + TW : w0 - 1, 0), W - 1);
-    const float* e = xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8;
-    dst.ed[0] = *reinterpret_cast<const f32x4*>(e);
-    dst.ed[1] = *reinterpret_cast<const f32x4*>(e + 4);
+    if (IN16) {
+      const unsigned short* xb = reinterpret_cast<const unsigned short*>(src) + (long)b * p.xv.sB;
+#pragma unroll
+      for (int r = 0; r < HALO_H; ++r)
+        dst.in[r][0] = *reinterpret_cast<const f32x4*>(xb + (long)min(max(h0 - 1 + r, 0), H - 1) * p.xv.sH + gwi * (int)p.xv.sW + c8 * 8);
+      dst.ed[0] = *reinterpret_cast<const f32x4*>(xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8);
+    } else {
+      const float* xb = src + (long)b * p.xv.sB;
+#pragma unroll
+      for (int r = 0; r < HALO_H; ++r) {
+        const float* a = xb + (long)min(max(h0 - 1 + r, 0), H - 1) * p.xv.sH + gwi * (int)p.xv.sW + c8 * 8;
+        dst.in[r][0] = *reinterpret_cast<const f32x4*>(a);
+        dst.in[r][IN16 ? 0 : 1] = *reinterpret_cast<const f32x4*>(a + 4);
+      }
+      const float* e = xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8;
+      dst.ed[0] = *reinterpret_cast<const f32x4*>(e);
+      dst.ed[IN16 ? 0 : 1] = *reinterpret_cast<const f32x4*>(e + 4);
+    }
   };
   auto commit = [&](unsigned char* buf, int tile) {
     int b, h0, w0;
@@ -1724,37 +1758,60 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
     for (int r = 0; r < HALO_H; ++r) {
       const int gh = h0 - 1 + r;
       const bool rok = gh >= 0 && gh < H;
-      f32x4 ta = v.in[r][0], tb = v.in[r][1];
-      if (AFFINE) {
-        ta = ta * s4a + t4a;
-        tb = tb * s4b + t4b;
-      }
-      if (GATE) {
-        ta = sisr_mul_add4(ta, s4a, u.in[r][0]);
-        tb = sisr_mul_add4(tb, s4b, u.in[r][1]);
-        if (r >= 1 && r <= TH && gh < H && cok) {  // interior columns are exactly the pixels this tile owns
-          float* o = p.gate_out + (long)b * p.xv.sB + (long)gh * p.xv.sH + (long)gw * p.xv.sW + c8 * 8;
-          *reinterpret_cast<f32x4*>(o) = ta;
-          *reinterpret_cast<f32x4*>(o + 4) = tb;
+      u32x4 pk;
+      if (IN16 && !AFFINE && !GATE) {
+        pk = __builtin_bit_cast(u32x4, v.in[r][0]);  // stored bf16 -> LDS as it is
+      } else {
+        f32x4 ta, tb;
+        if (IN16) sisr_unpack_bf16x8(__builtin_bit_cast(u32x4, v.in[r][0]), ta, tb);
+        else { ta = v.in[r][0]; tb = v.in[r][IN16 ? 0 : 1]; }
+        if (AFFINE) {
+          ta = ta * s4a + t4a;
+          tb = tb * s4b + t4b;
         }
+        if (GATE) {
+          f32x4 ua, ub;
+          if (IN16) sisr_unpack_bf16x8(__builtin_bit_cast(u32x4, u.in[r][0]), ua, ub);
+          else { ua = u.in[r][0]; ub = u.in[r][IN16 ? 0 : 1]; }
+          ta = sisr_mul_add4(ta, s4a, ua);
+          tb = sisr_mul_add4(tb, s4b, ub);
+          if (!IN16 && r >= 1 && r <= TH && gh < H && cok) {  // interior columns are exactly the pixels this tile owns
+            float* o = p.gate_out + (long)b * p.xv.sB + (long)gh * p.xv.sH + (long)gw * p.xv.sW + c8 * 8;
+            *reinterpret_cast<f32x4*>(o) = ta;
+            *reinterpret_cast<f32x4*>(o + 4) = tb;
+          }
+        }
+        pk = sisr_pack_bf16x8(ta, tb);
+        if (IN16 && GATE && r >= 1 && r <= TH && gh < H && cok)  // the gated skip is stored as the bf16 the MFMA reads
+          *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.gate_out) + (long)b * p.xv.sB + (long)gh * p.xv.sH +
+                                    (long)gw * p.xv.sW + c8 * 8) = pk;
       }
-      u32x4 pk = sisr_pack_bf16x8(ta, tb);
       const unsigned m = (rok && cok) ? 0xffffffffu : 0u;
       pk &= (u32x4){m, m, m, m};
       *reinterpret_cast<u32x4*>(buf + r * (HALO_W * BH_PIX) + lo_in) = pk;
     }
     {
       const int ecol = eside ? HALO_W - 1 : 0, gwe = eside ? w0 + TW : w0 - 1, ghe = h0 - 1 + er;
-      f32x4 ta = v.ed[0], tb = v.ed[1];
-      if (AFFINE) {
-        ta = ta * e4a + f4a;
-        tb = tb * e4b + f4b;
+      u32x4 pk;
+      if (IN16 && !AFFINE && !GATE) {
+        pk = __builtin_bit_cast(u32x4, v.ed[0]);
+      } else {
+        f32x4 ta, tb;
+        if (IN16) sisr_unpack_bf16x8(__builtin_bit_cast(u32x4, v.ed[0]), ta, tb);
+        else { ta = v.ed[0]; tb = v.ed[IN16 ? 0 : 1]; }
+        if (AFFINE) {
+          ta = ta * e4a + f4a;
+          tb = tb * e4b + f4b;
+        }
+        if (GATE) {
+          f32x4 ua, ub;
+          if (IN16) sisr_unpack_bf16x8(__builtin_bit_cast(u32x4, u.ed[0]), ua, ub);
+          else { ua = u.ed[0]; ub = u.ed[IN16 ? 0 : 1]; }
+          ta = sisr_mul_add4(ta, e4a, ua);
+          tb = sisr_mul_add4(tb, e4b, ub);
+        }
+        pk = sisr_pack_bf16x8(ta, tb);
       }
-      if (GATE) {
-        ta = sisr_mul_add4(ta, e4a, u.ed[0]);
-        tb = sisr_mul_add4(tb, e4b, u.ed[1]);
-      }
-      u32x4 pk = sisr_pack_bf16x8(ta, tb);
       const unsigned m = (ghe >= 0 && ghe < H && gwe >= 0 && gwe < W) ? 0xffffffffu : 0u;
       pk &= (u32x4){m, m, m, m};
       if (tid < 96)
@@ -1836,9 +1893,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
       const int row = h0 + (i >> 1), col = pr + 16 * (i & 1);
       ok[i] = row < H && w0 + col < W;
       off[i] = tile_base + (long)min(row, H - 1) * p.yv.sH + (long)min(col, W - 1 - w0) * p.yv.sW;
-      if (RES) rv[i] = *reinterpret_cast<const f32x4*>(p.res + off[i]);
-      if (MASK) mv[i] = *reinterpret_cast<const f32x4*>(p.mask + off[i]);
-      if (DOT) dv[i] = *reinterpret_cast<const f32x4*>(p.dot + off[i]);
+      if (RES) rv[i] = RES16 ? sisr_load_bf16x4(p.res, off[i]) : *reinterpret_cast<const f32x4*>(p.res + off[i]);
+      if (MASK) mv[i] = AUX16 ? sisr_load_bf16x4(p.mask, off[i]) : *reinterpret_cast<const f32x4*>(p.mask + off[i]);
+      if (DOT) dv[i] = AUX16 ? sisr_load_bf16x4(p.dot, off[i]) : *reinterpret_cast<const f32x4*>(p.dot + off[i]);
     }
     __syncthreads();
     f32x4 dsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -1853,7 +1910,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
       }
       if (RES) val += rv[i];
       if (ok[i]) {
-        *reinterpret_cast<f32x4*>(p.y + off[i]) = val;
+        if (OUT16) sisr_store_bf16x4(p.y, off[i], val);
+        else *reinterpret_cast<f32x4*>(p.y + off[i]) = val;
         if (DOT) dsum[i >> 2] += val * dv[i];
       }
     }
@@ -2589,6 +2647,89 @@ extern "C" int sisr_conv3x3_c64_bf16(const float* x, const int64_t* xview, const
 #undef BF_CASE
   }
   return sisr_check_launch();
+}
+
+// bf16 operands AND bf16 storage of selected maps (64 -> 64 only; always the persistent tile loop).  storage bits:
+//   1  x, gate_add and gate_out are bf16 maps      2  y is a bf16 map (rounded to nearest even in the epilogue's store)
+//   4  mask and dot are bf16 maps                   8  res is a bf16 map
+// A bf16 map has the View of its fp32 twin (strides in ELEMENTS) and 2-byte elements; pointers are passed as float* and
+// must be 16-byte aligned.  Everything else (bias, scales, partial sums, arithmetic: bf16 operands, fp32 accumulate) is
+// sisr_conv3x3_c64_bf16's.  Only the combinations the fused residual-group node launches are built; others return
+// SISR_ERR_UNSUPPORTED.
+extern "C" int sisr_conv3x3_c64_bf16s(const float* x, const int64_t* xview, const void* wpacked_bf16, const float* bias,
+                                      int bias_n, int bias_q, float* y, const int64_t* yview, const float* res,
+                                      const float* mask, const float* in_scale, const float* in_shift, float alpha, int relu,
+                                      float* gap_partial, const float* gate_add, float* gate_out, const float* dot, int B,
+                                      int H, int W, int storage, void* stream) {
+  if (!x || !wpacked_bf16 || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0 || storage < 0 || storage > 15) return SISR_ERR_ARG;
+  const bool gate = gate_add != nullptr;
+  if (gate != (gate_out != nullptr) || (gate && !in_scale) || (gate && dot) || (dot && !gap_partial) ||
+      (gate && (in_shift || mask)) || memcmp(xview, yview, 6 * sizeof(int64_t)) != 0)
+    return SISR_ERR_UNSUPPORTED;
+  if (in_shift && !in_scale) return SISR_ERR_UNSUPPORTED;
+  if (gap_partial && !dot && (mask || res)) return SISR_ERR_UNSUPPORTED;
+  if (relu != 0 && relu != 1) return SISR_ERR_UNSUPPORTED;
+  if (!sisr_aligned16(x) || !sisr_aligned16(y) || !sisr_aligned16(wpacked_bf16) || !sisr_aligned16(in_scale) ||
+      !sisr_aligned16(in_shift) || !sisr_aligned16(gate_add) || !sisr_aligned16(gate_out) || !sisr_aligned16(res) ||
+      !sisr_aligned16(mask) || !sisr_aligned16(dot))
+    return SISR_ERR_ALIGN;
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.xv = view_from(xview);
+  p.y = y;
+  p.yv = view_from(yview);
+  if ((p.xv.sB | p.xv.sH | p.xv.sW | p.xv.chi | p.xv.clo) & 7) return SISR_ERR_ALIGN;  // 16-B pieces of 2-byte elements
+  p.res = res;
+  p.mask = mask;
+  p.w = reinterpret_cast<const float*>(wpacked_bf16);
+  p.bias = bias;
+  p.in_scale = in_scale;
+  p.in_shift = in_shift;
+  p.gap = gap_partial;
+  p.gate_add = gate_add;
+  p.gate_out = gate_out;
+  p.dot = dot;
+  p.alpha = alpha;
+  p.bias_n = bias_n;
+  p.bias_q = bias_q;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.cin_chunks = p.cout_chunks = 1;
+  p.relu = relu;
+  p.tiles_w = (W + TW - 1) / TW;
+  p.tiles_h = (H + TH - 1) / TH;
+  const long nblk = (long)p.tiles_w * p.tiles_h * B;
+  if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
+  const int G = (int)(nblk < 512 ? nblk : 512);  // two workgroups per CU; fewer tiles than that: one tile each
+  const size_t plb = 2 * (size_t)PB_BUF;
+  const dim3 pg(G);
+  const int total = (int)nblk;
+  hipStream_t st = (hipStream_t)stream;
+#define PSX(AF, MK, RS, GT, DT, I16, O16, A16, R16)                                                                     \
+  do {                                                                                                                  \
+    SISR_ALLOW_LDS((conv3x3_c64_bf16_persist_kernel<AF, MK, RS, GT, DT, I16, O16, A16, R16>), plb);                     \
+    hipLaunchKernelGGL((conv3x3_c64_bf16_persist_kernel<AF, MK, RS, GT, DT, I16, O16, A16, R16>), pg, dim3(256), plb, st, \
+                       p, total);                                                                                       \
+    return sisr_check_launch();                                                                                         \
+  } while (0)
+  const int form = (in_scale && !gate ? 16 : 0) | (mask ? 8 : 0) | (res ? 4 : 0) | (gate ? 2 : 0) | (dot ? 1 : 0);
+  // forward of the group node: bf16 activations in and out
+  if (storage == 3 && form == 0) PSX(false, false, false, false, false, true, true, false, false);   // conv (+ ReLU / GAP sums)
+  if (storage == 3 && form == 2) PSX(false, false, false, true, false, true, true, false, false);    // GATE prologue
+  if (storage == 1 && form == 6) PSX(false, false, true, true, false, true, false, false, false);    // group tail: + fp32 residual, fp32 out
+  // backward with fp32 gradient maps: only the saved activations (mask, dot) are bf16
+  if (storage == 4 && form == 1) PSX(false, false, false, false, true, false, false, true, false);   // first conv, DOT
+  if (storage == 4 && form == 5) PSX(false, false, true, false, true, false, false, true, false);    // dgrad + residual, DOT
+  if (storage == 4 && form == 24) PSX(true, true, false, false, false, false, false, true, false);   // dgrad, ReLU mask + affine
+  // backward with bf16 gradient maps as well
+  if (storage == 6 && form == 1) PSX(false, false, false, false, true, false, true, true, false);    // fp32 dOut -> bf16 dU, DOT
+  if (storage == 15 && form == 5) PSX(false, false, true, false, true, true, true, true, true);
+  if (storage == 7 && form == 24) PSX(true, true, false, false, false, true, true, true, false);
+  if (storage == 11 && form == 4) PSX(false, false, true, false, false, true, true, false, true);    // block 0: dgrad + residual
+#undef PSX
+  return SISR_ERR_UNSUPPORTED;
 }
 
 // bf16x3: fp32 through the bf16 matrix cores (three-way operand split, six products); same contract as

@@ -294,6 +294,27 @@ extern "C" int sisr_pad_oihw(const float* src, float* dst, int cout, int cin, in
   return sisr_check_launch();
 }
 
+// fp32 map -> bf16 map (RNE), eight elements per thread (include/sisr_hip.h: bf16 storage)
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n8) {
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i], b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+    bf16x8_t r;
+    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+    r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+    reinterpret_cast<u32x4_t*>(dst)[i] = __builtin_bit_cast(u32x4_t, r);
+  }
+}
+
+extern "C" int sisr_f32_to_bf16(const float* src, void* dst, long n, void* stream) {
+  if (!src || !dst || n <= 0 || (n & 7)) return SISR_ERR_ARG;
+  if (!sisr_aligned16(src) || !sisr_aligned16(dst)) return SISR_ERR_ALIGN;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(misc_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, src,
+                     static_cast<unsigned short*>(dst), n / 8);
+  return sisr_check_launch();
+}
+
 extern "C" int sisr_shuffle_rgb(const float* src, float* dst, int B, int C, int r, int H, int W, int Cp, int adjoint,
                                 void* stream) {
   if (!src || !dst || B <= 0 || C <= 0 || r <= 0 || H <= 0 || W <= 0 || Cp < C * r * r) return SISR_ERR_ARG;

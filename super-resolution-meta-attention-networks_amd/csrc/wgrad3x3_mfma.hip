@@ -479,7 +479,10 @@ __device__ __forceinline__ bf16x8 wg_tr_frag(const unsigned char* base, unsigned
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_kernel(WgradParams p) {
+// X16 / Y16: x / dY is a bf16 map in HBM (same View, 2-byte elements; sisr_wgrad3x3_c64_bf16s): its 16-B pieces go to LDS
+// as they are (x) or after the fp32 affine rebuild and re-rounding (dY with dy_scale / dy_shift).
+template <bool X16, bool Y16>
+static __device__ __forceinline__ void wgrad3x3_c64_bf16_body(const WgradParams& p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* ldx = ldsb;
   unsigned char* ldy = ldsb + BW_X_BYTES;
@@ -529,14 +532,21 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_kernel(WgradParams p
   // the loads of tile i+1 (38 float4 per thread) are in flight while tile i is in its K loop.  Thread (c8, pcol)
   // owns channels 8 c8 .. +7 of x halo column pcol + 1 (ten rows) and of dY column pcol (eight rows); the two edge
   // columns of the halo (10 x 2 x 8 = 160 items) go one per thread to tid < 160 -- every load is unconditional.
-  struct Stage {
-    f32x4 x[WH_H][2];
-    f32x4 xe[2];
-    f32x4 y[WT_H][2];
+  struct Stage {  // a bf16 map's item is one 16-B piece (eight channels), held in [..][0] as raw bits
+    f32x4 x[WH_H][X16 ? 1 : 2];
+    f32x4 xe[X16 ? 1 : 2];
+    f32x4 y[WT_H][Y16 ? 1 : 2];
   };
   Stage st;
   const int c8 = tid & 7, pcol = tid >> 3;
   const int eidx = tid % 160, er = eidx >> 4, eside = (eidx >> 3) & 1, ec8 = eidx & 7;
+  auto unpack8 = [](f32x4 raw, f32x4& a, f32x4& b) {
+    const u32x4 w = __builtin_bit_cast(u32x4, raw);
+    a[0] = __uint_as_float(w[0] << 16); a[1] = __uint_as_float(w[0] & 0xffff0000u);
+    a[2] = __uint_as_float(w[1] << 16); a[3] = __uint_as_float(w[1] & 0xffff0000u);
+    b[0] = __uint_as_float(w[2] << 16); b[1] = __uint_as_float(w[2] & 0xffff0000u);
+    b[2] = __uint_as_float(w[3] << 16); b[3] = __uint_as_float(w[3] & 0xffff0000u);
+  };
   auto decode = [&](int tile, int& b, int& h0, int& w0) {
     b = tile / tiles_per_img;
     const int tr = tile - b * tiles_per_img;
@@ -547,27 +557,39 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_kernel(WgradParams p
   auto issue = [&](int tile) {
     int b, h0, w0;
     decode(tile, b, h0, w0);
-    const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(cc);
     const int gxi = min(w0 + pcol, W - 1) * (int)p.xv.sW + c8 * 8;
+    const int gwe = min(max(eside ? w0 + WT_W : w0 - 1, 0), W - 1);
+    if (X16) {
+      const unsigned short* xb = reinterpret_cast<const unsigned short*>(p.x) + (long)b * p.xv.sB + p.xv.chunk(cc);
 #pragma unroll
-    for (int r = 0; r < WH_H; ++r) {
-      const float* a = xb + (long)min(max(h0 - 1 + r, 0), H - 1) * p.xv.sH + gxi;
-      st.x[r][0] = *reinterpret_cast<const f32x4*>(a);
-      st.x[r][1] = *reinterpret_cast<const f32x4*>(a + 4);
-    }
-    {
-      const int gwe = min(max(eside ? w0 + WT_W : w0 - 1, 0), W - 1);
+      for (int r = 0; r < WH_H; ++r)
+        st.x[r][0] = *reinterpret_cast<const f32x4*>(xb + (long)min(max(h0 - 1 + r, 0), H - 1) * p.xv.sH + gxi);
+      st.xe[0] = *reinterpret_cast<const f32x4*>(xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8);
+    } else {
+      const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(cc);
+#pragma unroll
+      for (int r = 0; r < WH_H; ++r) {
+        const float* a = xb + (long)min(max(h0 - 1 + r, 0), H - 1) * p.xv.sH + gxi;
+        st.x[r][0] = *reinterpret_cast<const f32x4*>(a);
+        st.x[r][X16 ? 0 : 1] = *reinterpret_cast<const f32x4*>(a + 4);
+      }
       const float* e = xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8;
       st.xe[0] = *reinterpret_cast<const f32x4*>(e);
-      st.xe[1] = *reinterpret_cast<const f32x4*>(e + 4);
+      st.xe[X16 ? 0 : 1] = *reinterpret_cast<const f32x4*>(e + 4);
     }
-    const float* yb = p.dy + (long)b * p.yv.sB + p.yv.chunk(cq);
     const int gyi = min(w0 + pcol, W - 1) * (int)p.yv.sW + c8 * 8;
+    if (Y16) {
+      const unsigned short* yb = reinterpret_cast<const unsigned short*>(p.dy) + (long)b * p.yv.sB + p.yv.chunk(cq);
 #pragma unroll
-    for (int r = 0; r < WT_H; ++r) {
-      const float* a = yb + (long)min(h0 + r, H - 1) * p.yv.sH + gyi;
-      st.y[r][0] = *reinterpret_cast<const f32x4*>(a);
-      st.y[r][1] = *reinterpret_cast<const f32x4*>(a + 4);
+      for (int r = 0; r < WT_H; ++r) st.y[r][0] = *reinterpret_cast<const f32x4*>(yb + (long)min(h0 + r, H - 1) * p.yv.sH + gyi);
+    } else {
+      const float* yb = p.dy + (long)b * p.yv.sB + p.yv.chunk(cq);
+#pragma unroll
+      for (int r = 0; r < WT_H; ++r) {
+        const float* a = yb + (long)min(h0 + r, H - 1) * p.yv.sH + gyi;
+        st.y[r][0] = *reinterpret_cast<const f32x4*>(a);
+        st.y[r][Y16 ? 0 : 1] = *reinterpret_cast<const f32x4*>(a + 4);
+      }
     }
   };
   auto commit = [&](int tile) {
@@ -579,14 +601,14 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_kernel(WgradParams p
 #pragma unroll
     for (int r = 0; r < WH_H; ++r) {
       const int gh = h0 - 1 + r;
-      u32x4 pk = wg_pack_bf16x8(st.x[r][0], st.x[r][1]);
+      u32x4 pk = X16 ? __builtin_bit_cast(u32x4, st.x[r][0]) : wg_pack_bf16x8(st.x[r][0], st.x[r][X16 ? 0 : 1]);
       const unsigned m = (gh >= 0 && gh < H && cokx) ? 0xffffffffu : 0u;
       pk &= (u32x4){m, m, m, m};
       *reinterpret_cast<u32x4*>(ldx + r * (WH_W * BW_PIX) + lx) = pk;
     }
     {
       const int ecol = eside ? WH_W - 1 : 0, gwe = eside ? w0 + WT_W : w0 - 1, ghe = h0 - 1 + er;
-      u32x4 pk = wg_pack_bf16x8(st.xe[0], st.xe[1]);
+      u32x4 pk = X16 ? __builtin_bit_cast(u32x4, st.xe[0]) : wg_pack_bf16x8(st.xe[0], st.xe[X16 ? 0 : 1]);
       const unsigned m = (ghe >= 0 && ghe < H && gwe >= 0 && gwe < W) ? 0xffffffffu : 0u;
       pk &= (u32x4){m, m, m, m};
       if (tid < 160)
@@ -608,7 +630,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_kernel(WgradParams p
 #pragma unroll
     for (int r = 0; r < WT_H; ++r) {
       const bool ok = coky && (h0 + r < H);
-      const f32x4 ta = sisr_keep_if(st.y[r][0] * s4a + t4a, ok), tb = sisr_keep_if(st.y[r][1] * s4b + t4b, ok);
+      f32x4 ya, yb2;
+      if (Y16) unpack8(st.y[r][0], ya, yb2);
+      else { ya = st.y[r][0]; yb2 = st.y[r][Y16 ? 0 : 1]; }
+      const f32x4 ta = sisr_keep_if(ya * s4a + t4a, ok), tb = sisr_keep_if(yb2 * s4b + t4b, ok);
       bsa += ta;
       bsb += tb;
       *reinterpret_cast<u32x4*>(ldy + r * (WT_W * BW_PIX) + ly) = wg_pack_bf16x8(ta, tb);
@@ -669,6 +694,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_kernel(WgradParams p
     }
   }
 }
+__global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_kernel(WgradParams p) { wgrad3x3_c64_bf16_body<false, false>(p); }
+__global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_x16_kernel(WgradParams p) { wgrad3x3_c64_bf16_body<true, false>(p); }
+__global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_xy16_kernel(WgradParams p) { wgrad3x3_c64_bf16_body<true, true>(p); }
 
 // ------------------------------------------------------------------ bf16x3 weight gradient
 // The bf16 kernel above with every fp32 operand split exactly into three bf16 numbers (conv3x3_mfma.hip, "bf16x3") and six
@@ -1218,12 +1246,13 @@ extern "C" size_t sisr_wgrad3x3_c64_bf16_workspace_bytes(int B, int H, int W, in
   return ((size_t)S * pairs * 4 * SLAB + (size_t)S * cout) * sizeof(float);
 }
 
-extern "C" int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
-                                      const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so,
-                                      int64_t si, int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n,
-                                      int in_perm_q, float* dbias, int bias_n, int bias_q, float* workspace,
-                                      size_t workspace_bytes, int B, int H, int W, int cin, int cout, void* stream) {
+static int wgrad3x3_c64_bf16_launch(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
+                                    const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so,
+                                    int64_t si, int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n,
+                                    int in_perm_q, float* dbias, int bias_n, int bias_q, float* workspace,
+                                    size_t workspace_bytes, int B, int H, int W, int cin, int cout, int storage, void* stream) {
   if (!x || !dy || !dw || !xview || !dyview || !workspace || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if (storage != 0 && storage != 1 && storage != 3) return SISR_ERR_UNSUPPORTED;
   if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
   if (workspace_bytes < sisr_wgrad3x3_c64_bf16_workspace_bytes(B, H, W, cin, cout)) return SISR_ERR_ARG;
   if (!sisr_aligned16(x) || !sisr_aligned16(dy) || !sisr_aligned16(workspace) || !sisr_aligned16(dy_scale) ||
@@ -1234,8 +1263,8 @@ extern "C" int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, cons
   p.xv = view_from(xview);
   p.dy = dy;
   p.yv = view_from(dyview);
-  if ((p.xv.sB | p.xv.sH | p.xv.sW | p.xv.chi | p.xv.clo | p.yv.sB | p.yv.sH | p.yv.sW | p.yv.chi | p.yv.clo) & 3)
-    return SISR_ERR_ALIGN;
+  if ((p.xv.sB | p.xv.sH | p.xv.sW | p.xv.chi | p.xv.clo | p.yv.sB | p.yv.sH | p.yv.sW | p.yv.chi | p.yv.clo) & (storage ? 7 : 3))
+    return SISR_ERR_ALIGN;  // 16-B pieces: four fp32 or eight bf16 elements
   p.dy_scale = dy_scale;
   p.dy_shift = dy_shift;
   p.B = B;
@@ -1251,8 +1280,16 @@ extern "C" int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, cons
   p.slabs = workspace;
   p.bias_slabs = dbias ? workspace + (size_t)p.S * units * SLAB : nullptr;
   const size_t lds_bytes = BW_X_BYTES + BW_Y_BYTES;
-  SISR_ALLOW_LDS(wgrad3x3_c64_bf16_kernel, lds_bytes);
-  hipLaunchKernelGGL(wgrad3x3_c64_bf16_kernel, dim3(p.S, pairs), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  if (storage == 0) {
+    SISR_ALLOW_LDS(wgrad3x3_c64_bf16_kernel, lds_bytes);
+    hipLaunchKernelGGL(wgrad3x3_c64_bf16_kernel, dim3(p.S, pairs), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  } else if (storage == 1) {
+    SISR_ALLOW_LDS(wgrad3x3_c64_bf16_x16_kernel, lds_bytes);
+    hipLaunchKernelGGL(wgrad3x3_c64_bf16_x16_kernel, dim3(p.S, pairs), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  } else {
+    SISR_ALLOW_LDS(wgrad3x3_c64_bf16_xy16_kernel, lds_bytes);
+    hipLaunchKernelGGL(wgrad3x3_c64_bf16_xy16_kernel, dim3(p.S, pairs), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  }
   int rc = sisr_check_launch();
   if (rc) return rc;
   ReduceParams r;
@@ -1278,6 +1315,30 @@ extern "C" int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, cons
   const long total = (long)units * SLAB + (dbias ? cout : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(64, RG), 0, (hipStream_t)stream, r);
   return sisr_check_launch();
+}
+
+extern "C" int sisr_wgrad3x3_c64_bf16(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
+                                      const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so,
+                                      int64_t si, int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n,
+                                      int in_perm_q, float* dbias, int bias_n, int bias_q, float* workspace,
+                                      size_t workspace_bytes, int B, int H, int W, int cin, int cout, void* stream) {
+  return wgrad3x3_c64_bf16_launch(x, xview, dy, dyview, dy_scale, dy_shift, alpha, dw, so, si, flip_taps, out_perm_n,
+                                  out_perm_q, in_perm_n, in_perm_q, dbias, bias_n, bias_q, workspace, workspace_bytes, B, H,
+                                  W, cin, cout, 0, stream);
+}
+
+// The same with bf16 STORAGE of its inputs: storage 1 = x is a bf16 map (a saved activation), 3 = x and dY are (same Views,
+// 2-byte elements, pointers passed as float*; workspace from sisr_wgrad3x3_c64_bf16_workspace_bytes).
+extern "C" int sisr_wgrad3x3_c64_bf16s(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
+                                       const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so,
+                                       int64_t si, int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n,
+                                       int in_perm_q, float* dbias, int bias_n, int bias_q, float* workspace,
+                                       size_t workspace_bytes, int B, int H, int W, int cin, int cout, int storage,
+                                       void* stream) {
+  if (storage != 1 && storage != 3) return SISR_ERR_ARG;
+  return wgrad3x3_c64_bf16_launch(x, xview, dy, dyview, dy_scale, dy_shift, alpha, dw, so, si, flip_taps, out_perm_n,
+                                  out_perm_q, in_perm_n, in_perm_q, dbias, bias_n, bias_q, workspace, workspace_bytes, B, H,
+                                  W, cin, cout, storage, stream);
 }
 
 static int wgrad_x3_split(int B, int H, int W, int pairs) {

@@ -83,6 +83,13 @@ _SIGS.update({  # bf16 matrix-core variants (csrc/conv3x3_mfma.hip, csrc/wgrad3x
     "sisr_wgrad3x3_c64_bf16": (c_int, [P, P, P, P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
                                   c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
 })
+_SIGS.update({  # bf16 storage of the maps a residual group keeps (csrc/conv3x3_mfma.hip, wgrad3x3_mfma.hip, misc.hip)
+    "sisr_conv3x3_c64_bf16s": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, c_float, c_int, P, P, P, P, c_int, c_int, c_int,
+                                      c_int, P]),
+    "sisr_wgrad3x3_c64_bf16s": (c_int, [P, P, P, P, P, P, c_float, P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, P,
+                                       c_int, c_int, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sisr_f32_to_bf16": (c_int, [P, P, c_long, P]),
+})
 _SIGS.update({  # step-level launches (round 2): all conv weights / all meta gates of a network at once
     "sisr_pack_job_bytes": (c_size_t, []),
     "sisr_pack_conv3x3_many": (c_int, [P, c_int, c_int, c_int, P]),
@@ -263,6 +270,15 @@ def gate_counter(device):
         c = torch.zeros(4, device=device, dtype=torch.int32)
         _counters[device.index] = c
     return c.data_ptr()
+
+
+def ptr_any(t):
+    """Device pointer of an fp32 OR bf16 map (None -> NULL): the bf16-storage entry points take both through float*."""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"expected an fp32 or bf16 tensor on a HIP device; got {t.dtype} on {t.device}")
+    return t.data_ptr()
 
 
 def ptr_bf16(t):

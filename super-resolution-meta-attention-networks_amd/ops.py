@@ -372,6 +372,46 @@ def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=
     hip.check(rc, name)
 
 
+# bf16 STORAGE (on top of PRECISION == "bf16", BASELINE config 5): the maps a residual group keeps for itself and for its
+# backward pass -- t1 = ReLU(conv1), t2 = conv2, the gated skips u_k -- live in HBM as bf16 (rounded once, where they are
+# written; read back without conversion as MFMA operands), which halves what the group's HBM-bound kernels move for them.
+# Group inputs / outputs, gradient maps, gates, partial sums, weights' master copies and the optimiser stay fp32.
+#   "0"    fp32 maps (the default)      "act"  the group's activations as above
+BF16_STORAGE = os.environ.get("SISR_BF16_STORAGE", "0")
+
+
+def set_storage(name):
+    """Storage format of the maps a residual group keeps, in the bf16 operand mode: "0" (fp32) or "act" (bf16 activations)."""
+    global BF16_STORAGE
+    if name not in ("0", "act"):
+        raise ValueError(f"storage must be '0' or 'act', got {name!r}")
+    BF16_STORAGE = name
+
+
+def _empty_cl16(B, C, H, W, device):
+    return torch.empty((B, C, H, W), device=device, dtype=torch.bfloat16, memory_format=CL)
+
+
+def to_bf16_map(x):
+    """fp32 channels-last map -> bf16 channels-last map (round to nearest even), one launch."""
+    y = _empty_cl16(*x.shape, x.device)
+    hip.check(hip.lib().sisr_f32_to_bf16(hip.ptr(x), hip.ptr_any(y), x.numel(), hip.stream()), "sisr_f32_to_bf16")
+    return y
+
+
+def conv_c64s(x, packed, bias, y, B, H, W, storage, res=None, mask=None, in_scale=None, in_shift=None, alpha=1.0, relu=False,
+              gap=None, gate_add=None, gate_out=None, dot=None):
+    """64 -> 64 conv of the bf16 operand mode with bf16-stored maps (include/sisr_hip.h: sisr_conv3x3_c64_bf16s storage bits)."""
+    if packed.dtype != torch.bfloat16 or packed.numel() != 64 * 64 * 9:
+        raise RuntimeError("bf16 storage needs a weight packed in the bf16 operand mode (64 -> 64)")
+    v = hip.view_plain(H, W, 64)
+    rc = hip.lib().sisr_conv3x3_c64_bf16s(hip.ptr_any(x), v, _wptr(packed), hip.ptr(bias), 1, 64, hip.ptr_any(y), v,
+                                          hip.ptr_any(res), hip.ptr_any(mask), hip.ptr(in_scale), hip.ptr(in_shift), float(alpha),
+                                          int(relu), hip.ptr(gap), hip.ptr_any(gate_add), hip.ptr_any(gate_out), hip.ptr_any(dot),
+                                          B, H, W, int(storage), hip.stream())
+    hip.check(rc, "sisr_conv3x3_c64_bf16s")
+
+
 _DEFERRED = None  # {(B, H, W, device index): WgradQueue} while a deferred_wgrads() block is open
 _DEFERRED_STREAM = None  # the stream the block was opened on: launches issued from another stream are not queued
 
@@ -424,7 +464,7 @@ def _flush_deferred():
 
 
 def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_scale=None, dy_shift=None, shuffle=1,
-              active_units=0, owner=None):
+              active_units=0, owner=None, storage=0):
     """active_units (fp32 kernel): bit mask of the 32 x 32-channel blocks of the gradient to compute (0 = all).
     owner: the weight Parameter -- with it, inside a deferred_wgrads() block, an eligible launch is queued instead."""
     if (_DEFERRED is not None and hip.stream() == _DEFERRED_STREAM and owner is not None and owner.requires_grad and
@@ -453,6 +493,14 @@ def wgrad_c64(x, xview, dy, dyview, dw, db, B, H, W, cin, cout, alpha=1.0, dy_sc
     ws = hip.workspace(x.device, nbytes)
     rr = shuffle * shuffle
     on, oq = (rr, 1) if shuffle > 1 else (1, 64)
+    if storage:  # bf16-stored x (1) or x and dY (3): the bf16 operand mode's kernel reading 2-byte elements
+        if PRECISION != "bf16":
+            raise RuntimeError("bf16-stored maps exist in the bf16 operand mode only")
+        fn, name = L.sisr_wgrad3x3_c64_bf16s, "sisr_wgrad3x3_c64_bf16s"
+        args = (hip.ptr_any(x), xview, hip.ptr_any(dy), dyview, hip.ptr(dy_scale), hip.ptr(dy_shift), float(alpha), hip.ptr(dw),
+                cin * 9, 9, 0, on, oq, 1, 64, hip.ptr(db), on, oq, hip.ptr(ws), nbytes, B, H, W, cin, cout)
+        hip.check(fn(*args, int(storage), hip.stream()), name)
+        return
     args = (hip.ptr(x), xview, hip.ptr(dy), dyview, hip.ptr(dy_scale), hip.ptr(dy_shift), float(alpha), hip.ptr(dw),
             cin * 9, 9, 0, on, oq, 1, 64, hip.ptr(db), on, oq, hip.ptr(ws), nbytes, B, H, W, cin, cout)
     rc = fn(*args, int(active_units), hip.stream()) if fp32 else fn(*args, hip.stream())
@@ -1149,6 +1197,16 @@ class _GatedGroup(Function):
         heads = GATE_HEADS and not tails and WgradQueue.wanted(B, H, W) and B * H * W <= GATE_HEADS_MAX_PIXELS
         PER = _GatedGroup.PER
         lanes = _Lanes(dev, _lane_cuts(B, H, W))
+        # bf16 operand mode with bf16 storage: the maps this group keeps (t1, t2, the gated skips) are bf16 in HBM
+        st16 = PRECISION == "bf16" and BF16_STORAGE == "act" and not tails and not heads
+        new_map = _empty_cl16 if st16 else _empty_cl
+        x_in = to_bf16_map(x) if st16 else x  # block 0's input and first skip, in the group's storage format
+
+        def conv(xx, pk, bias, yy, Bl, storage, **kw):
+            if st16:
+                conv_c64s(xx, pk, bias, yy, Bl, H, W, storage, **kw)
+            else:
+                conv_c64(xx, v, pk, bias, (1, 64), yy, v, Bl, H, W, 64, 64, **kw)
 
         def pack(w):
             return pack_pair(w) if need else (pack_weight(w, "fwd"), None)
@@ -1161,8 +1219,8 @@ class _GatedGroup(Function):
             p1, pd1 = pack(w1)
             p2, pd2 = pack(w2)
             R = caw1.shape[0]
-            d = dict(p1=p1, p2=p2, b1=b1, b2=b2, R=R, t1=_empty_cl(B, 64, H, W, dev), t2=_empty_cl(B, 64, H, W, dev),
-                     u=_empty_cl(B, 64, H, W, dev) if k > 0 else x,
+            d = dict(p1=p1, p2=p2, b1=b1, b2=b2, R=R, t1=new_map(B, 64, H, W, dev), t2=new_map(B, 64, H, W, dev),
+                     u=new_map(B, 64, H, W, dev) if k > 0 else x_in,
                      gap=torch.empty((B, parts, 64), device=dev, dtype=torch.float32),
                      caw1c=caw1.reshape(R, 64).contiguous(), caw2c=caw2.reshape(64, R).contiguous(),
                      cb1=cab1.contiguous(), cb2=cab2.contiguous(), mm=m.contiguous() if m is not None else None,
@@ -1178,7 +1236,7 @@ class _GatedGroup(Function):
         wt, bt = args[n * PER:n * PER + 2]
         wt = wt.contiguous()
         pt, pdt = pack(wt)
-        un, out = _empty_cl(B, 64, H, W, dev), _empty_cl(B, 64, H, W, dev)
+        un, out = new_map(B, 64, H, W, dev), _empty_cl(B, 64, H, W, dev)
         keep = []  # argument records the launches of a lane point into
         interleave = len(lanes.cuts) > 1 and LANES_INTERLEAVE
 
@@ -1192,7 +1250,10 @@ class _GatedGroup(Function):
                 sv, hid, ca, g = d["sv"][sl], d["hid"][sl], d["ca"][sl], d["g"][sl]
                 mm = d["mm"][sl] if d["mm"] is not None else None
                 if pend is None:
-                    conv_c64(x[sl], v, d["p1"], d["b1"], (1, 64), t1, v, Bl, H, W, 64, 64, relu=True)
+                    conv(x_in[sl], d["p1"], d["b1"], t1, Bl, 3, relu=True)
+                elif st16:
+                    conv(pend[0], d["p1"], d["b1"], t1, Bl, 3, relu=True, in_scale=pend[1], gate_add=blks[k - 1]["u"][sl],
+                         gate_out=d["u"][sl])
                 else:
                     conv_c64(pend[0], v, d["p1"], d["b1"], (1, 64), t1, v, Bl, H, W, 64, 64, relu=True, in_scale=pend[1],
                              gate_add=blks[k - 1]["u"][sl], gate_out=d["u"][sl], ca_tail=pend[2])
@@ -1210,15 +1271,18 @@ class _GatedGroup(Function):
                     hd.head_part = hip.ptr(gap)
                     keep.append(hd)
                 else:
-                    conv_c64(t1, v, d["p2"], d["b2"], (1, 64), t2, v, Bl, H, W, 64, 64, gap=gap)
+                    conv(t1, d["p2"], d["b2"], t2, Bl, 3, gap=gap)
                     hip.check(L.sisr_ca_gate_fwd(hip.ptr(gap), parts, Bl, 1.0 / (H * W), hip.ptr(d["caw1c"]), hip.ptr(d["cb1"]),
                                                  hip.ptr(d["caw2c"]), hip.ptr(d["cb2"]), 64, d["R"], hip.ptr(mm), hip.ptr(sv),
                                                  hip.ptr(hid), hip.ptr(ca), hip.ptr(g), hip.stream()), "sisr_ca_gate_fwd")
                 pend = (t2, g, hd)
                 if interleave:
                     yield
-            conv_c64(pend[0], v, pt, bt, (1, 64), out[sl], v, Bl, H, W, 64, 64, in_scale=pend[1], gate_add=blks[n - 1]["u"][sl],
-                     gate_out=un[sl], res=x[sl], ca_tail=pend[2])
+            if st16:  # bf16 t2 and skips in, the group's output (+ its fp32 input as the residual) in fp32
+                conv(pend[0], pt, bt, out[sl], Bl, 1, in_scale=pend[1], gate_add=blks[n - 1]["u"][sl], gate_out=un[sl], res=x[sl])
+            else:
+                conv_c64(pend[0], v, pt, bt, (1, 64), out[sl], v, Bl, H, W, 64, 64, in_scale=pend[1],
+                         gate_add=blks[n - 1]["u"][sl], gate_out=un[sl], res=x[sl], ca_tail=pend[2])
 
         lanes.fork()
         if interleave:
@@ -1230,6 +1294,7 @@ class _GatedGroup(Function):
         ctx.cfg = (n, (B, H, W), meta, parts)
         ctx.packs, ctx.pdt = packs, pdt
         ctx.small, ctx.bt = small, bt  # the small parameters: their gradients go straight into the optimiser's arena too
+        ctx.st16 = st16
         return out
 
     @staticmethod
@@ -1257,6 +1322,16 @@ class _GatedGroup(Function):
             for cnt, has_m, s1, s2 in meta:
                 blocks.append((sv_all[pos:pos + cnt], has_m, s1, s2))
                 pos += cnt
+            st16 = ctx.st16  # the saved activations (un, every block's input, t1, t2) are bf16 maps; gradient maps are fp32
+            wst = 1 if st16 else 0
+
+            def conv(xx, pk, yy, Bl, **kw):
+                """a backward conv of the group: fp32 gradient maps in and out, bf16 mask / dot operands under st16"""
+                if st16 and (kw.get("mask") is not None or kw.get("dot") is not None):
+                    conv_c64s(xx, pk, None, yy, Bl, H, W, 4, **kw)
+                else:
+                    conv_c64(xx, v, pk, None, (1, 64), yy, v, Bl, H, W, 64, 64, **kw)
+
             side = _side_ok(wt, *(t for blk in blocks for t in blk[0][1:3]))
             # small launches: the group's 2n + 1 weight gradients go out eight to a launch (WgradQueue) instead of one by one
             queue = WgradQueue(B, H, W, dev) if WgradQueue.wanted(B, H, W) else None
@@ -1270,7 +1345,7 @@ class _GatedGroup(Function):
             if queue is not None:
                 queue.add(un, dout, dwt, dbt)
             else:
-                run(lambda: wgrad_c64(un, v, dout, v, dwt, dbt, B, H, W, 64, 64), (un, dout, dwt, dbt))
+                run(lambda: wgrad_c64(un, v, dout, v, dwt, dbt, B, H, W, 64, 64, storage=wst), (un, dout, dwt, dbt))
 
             def gate_bwd_out(k):
                 """Outputs of block k's gate backward (allocated before the conv launch whose tail / head fills them)."""
@@ -1297,8 +1372,11 @@ class _GatedGroup(Function):
             def first_conv(b0, b1, dy, go):
                 """dU_n = convT_tail(dout), with the partial sums of sum(dU_n * t2_n) for block n - 1's gate backward."""
                 sl = slice(b0, b1)
-                conv_c64(dout[sl], v, ctx.pdt, None, (1, 64), dy[sl], v, b1 - b0, H, W, 64, 64, gap=go["dgp"][sl],
-                         dot=blocks[-1][0][4][sl], ca_tail=tail_for(n - 1, go))
+                if st16:
+                    conv(dout[sl], ctx.pdt, dy[sl], b1 - b0, gap=go["dgp"][sl], dot=blocks[-1][0][4][sl])
+                else:
+                    conv_c64(dout[sl], v, ctx.pdt, None, (1, 64), dy[sl], v, b1 - b0, H, W, 64, 64, gap=go["dgp"][sl],
+                             dot=blocks[-1][0][4][sl], ca_tail=tail_for(n - 1, go))
 
             def block_chain(k, b0, b1, dy, go, bufs, mid1=None, mid2=None):
                 """Block k's part of the input-gradient chain on samples [b0, b1): gate backward (as a launch, a head of the next
@@ -1337,11 +1415,17 @@ class _GatedGroup(Function):
                 if mid1 is not None:
                     mid1()
                 dt1, dprev = bufs["dt1"], bufs["dprev"]
-                conv_c64(dy[sl], v, pd2, None, (1, 64), dt1[sl], v, Bl, H, W, 64, 64, mask=t1[sl], in_scale=g[sl], in_shift=shift,
-                         ca_tail=bhead)
+                if st16:
+                    conv(dy[sl], pd2, dt1[sl], Bl, mask=t1[sl], in_scale=g[sl], in_shift=shift)
+                else:
+                    conv_c64(dy[sl], v, pd2, None, (1, 64), dt1[sl], v, Bl, H, W, 64, 64, mask=t1[sl], in_scale=g[sl],
+                             in_shift=shift, ca_tail=bhead)
                 if mid2 is not None:
                     mid2()
-                if k > 0:
+                if k > 0 and st16:
+                    gn = bufs["go"]
+                    conv(dt1[sl], pd1, dprev[sl], Bl, res=dy[sl], gap=gn["dgp"][sl], dot=blocks[k - 1][0][4][sl])
+                elif k > 0:
                     gn = bufs["go"]
                     conv_c64(dt1[sl], v, pd1, None, (1, 64), dprev[sl], v, Bl, H, W, 64, 64, res=dy[sl], gap=gn["dgp"][sl],
                              dot=blocks[k - 1][0][4][sl], ca_tail=tail_for(k - 1, gn))
@@ -1359,7 +1443,7 @@ class _GatedGroup(Function):
                 if queue is not None:
                     queue.add(t1, dy, dw2, db2, dy_scale=g, dy_shift=shift)
                 else:
-                    run(lambda: wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, dy_scale=g, dy_shift=shift),
+                    run(lambda: wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, dy_scale=g, dy_shift=shift, storage=wst),
                         (t1, dy, g, shift, dw2, db2))
                 grads[k * _GatedGroup.PER + 2:k * _GatedGroup.PER + 4] = [dw2, db2]
 
@@ -1374,7 +1458,7 @@ class _GatedGroup(Function):
                         gate_jobs.append((go["dzw"], hid, s, go["dcaw1"], go["dcab1"], go["dcaw2"], go["dcab2"], caw1c.shape[0]))
                     queue.add(xk, dt1, dw1, db1)
                 else:
-                    run(lambda: wgrad_c64(xk, v, dt1, v, dw1, db1, B, H, W, 64, 64), (xk, dt1, dw1, db1))
+                    run(lambda: wgrad_c64(xk, v, dt1, v, dw1, db1, B, H, W, 64, 64, storage=wst), (xk, dt1, dw1, db1))
                 P = _GatedGroup.PER
                 grads[k * P:k * P + 2] = [dw1, db1]
                 grads[k * P + 4:k * P + 9] = [go["dcaw1"], go["dcab1"], go["dcaw2"], go["dcab2"], go["dmv"] if has_m else None]
