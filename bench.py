@@ -351,8 +351,9 @@ def main():
                     help="arithmetic of the 64-channel convs: fp32 MFMA (reference arithmetic, the headline); bf16 MFMA "
                          "operands with fp32 accumulate / storage (BASELINE config 'HAN x4 bf16'); bf16x3 = fp32 operands "
                          "split exactly into three bf16 numbers, six products on the bf16 MFMA (fp32-class error)")
-    ap.add_argument("--storage", default="0", choices=["0", "act"],
-                    help="with --precision bf16: storage of the maps a residual group keeps: 0 = fp32, act = bf16 activations")
+    ap.add_argument("--storage", default="0", choices=["0", "act", "all"],
+                    help="with --precision bf16: storage of the maps a residual group keeps: 0 = fp32, act = bf16 activations, "
+                         "all = bf16 activations and gradient maps")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -365,7 +366,7 @@ def main():
     sisr.ops.set_precision(args.precision)
     if args.storage != "0":
         if args.precision != "bf16":
-            raise SystemExit("--storage act needs --precision bf16")
+            raise SystemExit("--storage act / all needs --precision bf16")
         sisr.ops.set_storage(args.storage)
     rank, world, local = sisr.parallel.init_distributed()
     if world != args.gpus:

@@ -60,6 +60,27 @@ def _st(x):
     return _StoreBf16.apply(x) if (MAP_STORAGE == "bf16" and CONV_PRECISION == "bf16") else x
 
 
+# ... and of the gradient maps a group's backward pass hands from launch to launch ("bf16": the gradient at every gated skip
+# u_k (k >= 1) and at every conv1 output is rounded to bf16 once, after the skip's gradient has been added / the ReLU mask
+# applied in fp32; the group's input gradient is not).  One difference to the product is left in this restatement: the
+# product takes the gate gradient's sums from the fp32 value BEFORE that rounding, autograd below from the rounded map.
+GRAD_STORAGE = "fp32"
+
+
+class _StoreGrad16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r16(g)
+
+
+def _gr(x):
+    return _StoreGrad16.apply(x) if (GRAD_STORAGE == "bf16" and MAP_STORAGE == "bf16" and CONV_PRECISION == "bf16") else x
+
+
 class _Bf16Conv(torch.autograd.Function):
     """alpha * (conv(r16(x), r16(w)) + b).  A residual scale (EDSR's res_scale) is part of the operator because the
     product applies it to the fp32 accumulator, i.e. AFTER the bf16 rounding of the incoming gradient in backward;
@@ -210,9 +231,9 @@ def _stored_group(x, n_resblocks, block_key, tail_key, sd, gate_fn):
     u = _st(x)
     for i in range(n_resblocks):
         key = block_key(i)
-        t1 = _st(F.relu(conv(sd, key + ".body.0", u)))
+        t1 = _st(F.relu(_gr(conv(sd, key + ".body.0", u))))
         t2 = conv(sd, key + ".body.2", t1)
-        u = _st(_st(t2) * gate_fn(i, t2) + u)
+        u = _gr(_st(_st(t2) * gate_fn(i, t2) + u))
     return conv(sd, tail_key, u) + x
 
 

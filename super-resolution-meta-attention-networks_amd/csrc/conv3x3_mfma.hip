@@ -2727,7 +2727,8 @@ extern "C" int sisr_conv3x3_c64_bf16s(const float* x, const int64_t* xview, cons
   if (storage == 6 && form == 1) PSX(false, false, false, false, true, false, true, true, false);    // fp32 dOut -> bf16 dU, DOT
   if (storage == 15 && form == 5) PSX(false, false, true, false, true, true, true, true, true);
   if (storage == 7 && form == 24) PSX(true, true, false, false, false, true, true, true, false);
-  if (storage == 11 && form == 4) PSX(false, false, true, false, false, true, true, false, true);    // block 0: dgrad + residual
+  if (storage == 11 && form == 4) PSX(false, false, true, false, false, true, true, false, true);    // dgrad + residual (bf16 out)
+  if (storage == 9 && form == 4) PSX(false, false, true, false, false, true, false, false, true);    // block 0: ... -> fp32 dX of the group
 #undef PSX
   return SISR_ERR_UNSUPPORTED;
 }

@@ -377,14 +377,18 @@ def conv_c64(x, xview, packed, bias, bias_nq, y, yview, B, H, W, cin, cout, res=
 # written; read back without conversion as MFMA operands), which halves what the group's HBM-bound kernels move for them.
 # Group inputs / outputs, gradient maps, gates, partial sums, weights' master copies and the optimiser stay fp32.
 #   "0"    fp32 maps (the default)      "act"  the group's activations as above
+#   "all"  ... and the gradient maps the group's backward pass hands from launch to launch (dU_k, dt1): rounded once where
+#          they are written, after the ReLU mask / the skip's gradient have been applied in fp32; the partial sums of the gate
+#          gradients and the bias gradients are taken from fp32 values, the group's input gradient leaves it in fp32
 BF16_STORAGE = os.environ.get("SISR_BF16_STORAGE", "0")
 
 
 def set_storage(name):
-    """Storage format of the maps a residual group keeps, in the bf16 operand mode: "0" (fp32) or "act" (bf16 activations)."""
+    """Storage format of the maps a residual group keeps, in the bf16 operand mode: "0" (fp32), "act" (bf16 activations) or
+    "all" (bf16 activations and gradient maps)."""
     global BF16_STORAGE
-    if name not in ("0", "act"):
-        raise ValueError(f"storage must be '0' or 'act', got {name!r}")
+    if name not in ("0", "act", "all"):
+        raise ValueError(f"storage must be '0', 'act' or 'all', got {name!r}")
     BF16_STORAGE = name
 
 
@@ -1198,7 +1202,7 @@ class _GatedGroup(Function):
         PER = _GatedGroup.PER
         lanes = _Lanes(dev, _lane_cuts(B, H, W))
         # bf16 operand mode with bf16 storage: the maps this group keeps (t1, t2, the gated skips) are bf16 in HBM
-        st16 = PRECISION == "bf16" and BF16_STORAGE == "act" and not tails and not heads
+        st16 = PRECISION == "bf16" and BF16_STORAGE in ("act", "all") and not tails and not heads
         new_map = _empty_cl16 if st16 else _empty_cl
         x_in = to_bf16_map(x) if st16 else x  # block 0's input and first skip, in the group's storage format
 
@@ -1294,7 +1298,7 @@ class _GatedGroup(Function):
         ctx.cfg = (n, (B, H, W), meta, parts)
         ctx.packs, ctx.pdt = packs, pdt
         ctx.small, ctx.bt = small, bt  # the small parameters: their gradients go straight into the optimiser's arena too
-        ctx.st16 = st16
+        ctx.st16, ctx.grad16 = st16, st16 and BF16_STORAGE == "all"
         return out
 
     @staticmethod
@@ -1322,13 +1326,19 @@ class _GatedGroup(Function):
             for cnt, has_m, s1, s2 in meta:
                 blocks.append((sv_all[pos:pos + cnt], has_m, s1, s2))
                 pos += cnt
-            st16 = ctx.st16  # the saved activations (un, every block's input, t1, t2) are bf16 maps; gradient maps are fp32
+            # st16: the saved activations (un, every block's input, t1, t2) are bf16 maps; g16: so are the gradient maps the
+            # launches of this pass hand to each other (the group's own input / output gradients stay fp32)
+            st16, g16 = ctx.st16, ctx.grad16
             wst = 1 if st16 else 0
+            grad_map = _empty_cl16 if g16 else _empty_cl
 
             def conv(xx, pk, yy, Bl, **kw):
-                """a backward conv of the group: fp32 gradient maps in and out, bf16 mask / dot operands under st16"""
-                if st16 and (kw.get("mask") is not None or kw.get("dot") is not None):
-                    conv_c64s(xx, pk, None, yy, Bl, H, W, 4, **kw)
+                """a backward conv of the group under st16: bf16 mask / dot operands; storage bits from the maps' own dtypes"""
+                st = ((1 if xx.dtype == torch.bfloat16 else 0) | (2 if yy.dtype == torch.bfloat16 else 0) |
+                      (4 if (kw.get("mask") is not None or kw.get("dot") is not None) else 0) |
+                      (8 if (kw.get("res") is not None and kw["res"].dtype == torch.bfloat16) else 0))
+                if st:
+                    conv_c64s(xx, pk, None, yy, Bl, H, W, st, **kw)
                 else:
                     conv_c64(xx, v, pk, None, (1, 64), yy, v, Bl, H, W, 64, 64, **kw)
 
@@ -1367,7 +1377,8 @@ class _GatedGroup(Function):
             def block_bufs(k):
                 """Maps block k's backward writes: dt1 (gradient at ReLU(conv1)) and dprev (gradient at the block's input), plus
                 the gate-backward outputs of block k - 1, which block k's last conv feeds."""
-                return dict(dt1=_empty_cl(B, 64, H, W, dev), dprev=_empty_cl(B, 64, H, W, dev), go=gate_bwd_out(k - 1) if k > 0 else None)
+                return dict(dt1=grad_map(B, 64, H, W, dev), dprev=(grad_map if k > 0 else _empty_cl)(B, 64, H, W, dev),
+                            go=gate_bwd_out(k - 1) if k > 0 else None)
 
             def first_conv(b0, b1, dy, go):
                 """dU_n = convT_tail(dout), with the partial sums of sum(dU_n * t2_n) for block n - 1's gate backward."""
@@ -1429,6 +1440,8 @@ class _GatedGroup(Function):
                     gn = bufs["go"]
                     conv_c64(dt1[sl], v, pd1, None, (1, 64), dprev[sl], v, Bl, H, W, 64, 64, res=dy[sl], gap=gn["dgp"][sl],
                              dot=blocks[k - 1][0][4][sl], ca_tail=tail_for(k - 1, gn))
+                elif g16:
+                    conv(dt1[sl], pd1, dprev[sl], Bl, res=dy[sl])  # block 0: bf16 in, bf16 residual, the group's fp32 dX out
                 else:
                     conv_c64(dt1[sl], v, pd1, None, (1, 64), dprev[sl], v, Bl, H, W, 64, 64, res=dy[sl])
 
@@ -1443,8 +1456,8 @@ class _GatedGroup(Function):
                 if queue is not None:
                     queue.add(t1, dy, dw2, db2, dy_scale=g, dy_shift=shift)
                 else:
-                    run(lambda: wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, dy_scale=g, dy_shift=shift, storage=wst),
-                        (t1, dy, g, shift, dw2, db2))
+                    run(lambda: wgrad_c64(t1, v, dy, v, dw2, db2, B, H, W, 64, 64, dy_scale=g, dy_shift=shift,
+                                          storage=3 if g16 else wst), (t1, dy, g, shift, dw2, db2))
                 grads[k * _GatedGroup.PER + 2:k * _GatedGroup.PER + 4] = [dw2, db2]
 
             def wgrad1(k, go, bufs):
@@ -1458,12 +1471,13 @@ class _GatedGroup(Function):
                         gate_jobs.append((go["dzw"], hid, s, go["dcaw1"], go["dcab1"], go["dcaw2"], go["dcab2"], caw1c.shape[0]))
                     queue.add(xk, dt1, dw1, db1)
                 else:
-                    run(lambda: wgrad_c64(xk, v, dt1, v, dw1, db1, B, H, W, 64, 64, storage=wst), (xk, dt1, dw1, db1))
+                    run(lambda: wgrad_c64(xk, v, dt1, v, dw1, db1, B, H, W, 64, 64, storage=3 if g16 else wst),
+                        (xk, dt1, dw1, db1))
                 P = _GatedGroup.PER
                 grads[k * P:k * P + 2] = [dw1, db1]
                 grads[k * P + 4:k * P + 9] = [go["dcaw1"], go["dcab1"], go["dcaw2"], go["dcab2"], go["dmv"] if has_m else None]
 
-            dy = _empty_cl(B, 64, H, W, dev)
+            dy = grad_map(B, 64, H, W, dev)
             go = gate_bwd_out(n - 1)
             if nl == 1:
                 # one chain on the calling stream: buffers come and go block by block, weight gradients follow their operands

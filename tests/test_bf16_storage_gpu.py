@@ -27,15 +27,16 @@ hip = sisr_amd.hip
 CL = torch.channels_last
 
 
-@pytest.fixture(autouse=True)
-def bf16_storage_mode():
+@pytest.fixture(autouse=True, params=["act", "all"])
+def bf16_storage_mode(request):
+    """act: the groups' activations are bf16 maps; all: the gradient maps their backward hands from launch to launch too"""
     ops.set_precision("bf16")
-    ops.set_storage("act")
-    O.CONV_PRECISION, O.MAP_STORAGE = "bf16", "bf16"
-    yield
+    ops.set_storage(request.param)
+    O.CONV_PRECISION, O.MAP_STORAGE, O.GRAD_STORAGE = "bf16", "bf16", ("bf16" if request.param == "all" else "fp32")
+    yield request.param
     ops.set_precision("fp32")
     ops.set_storage("0")
-    O.CONV_PRECISION, O.MAP_STORAGE = "fp32", "fp32"
+    O.CONV_PRECISION, O.MAP_STORAGE, O.GRAD_STORAGE = "fp32", "fp32", "fp32"
 
 
 def _maps(B, H, W, n, seed):
@@ -103,6 +104,12 @@ def test_every_bf16_storage_conv_form_equals_the_bf16_operand_kernel(B, H, W):
     same(new(dy, 4, False, gap=True, dot=d16), ref(dy, gap=True, dot=d32), "first backward conv: DOT")
     same(new(dy, 4, False, gap=True, dot=d16, res=x32), ref(dy, gap=True, dot=d32, res=x32), "dgrad + residual, DOT")
     same(new(dy, 4, False, mask=m16, in_scale=sc, in_shift=sh), ref(dy, mask=m32, in_scale=sc, in_shift=sh), "dgrad, mask + affine")
+    # ... and with bf16 gradient maps as well (storage 'all')
+    same(new(dy, 6, True, gap=True, dot=d16), ref(dy, gap=True, dot=d32), "first backward conv: fp32 dOut -> bf16 dU, DOT")
+    same(new(x16, 15, True, gap=True, dot=d16, res=s16), ref(x32, gap=True, dot=d32, res=s32), "dgrad + bf16 residual, DOT, bf16 maps")
+    same(new(x16, 7, True, mask=m16, in_scale=sc, in_shift=sh), ref(x32, mask=m32, in_scale=sc, in_shift=sh), "dgrad, mask + affine, bf16 maps")
+    same(new(x16, 11, True, res=s16), ref(x32, res=s32), "dgrad + bf16 residual, bf16 out")
+    same(new(x16, 9, False, res=s16), ref(x32, res=s32), "block 0: dgrad + bf16 residual -> the group's fp32 dX")
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 13, 9), (2, 40, 48), (3, 128, 128)])
@@ -113,12 +120,15 @@ def test_weight_gradient_reads_a_bf16_map_as_it_is(B, H, W):
     v = hip.view_plain(H, W, 64)
     for kw in (dict(), dict(dy_scale=sc, dy_shift=sh)):
         out = []
-        for xin, storage in ((x32, 0), (x16, 1)):
+        dy16 = dy.to(torch.bfloat16).contiguous(memory_format=CL)
+        dy16up = dy16.to(torch.float32).contiguous(memory_format=CL)
+        for xin, dyin, storage in ((x32, dy, 0), (x16, dy, 1), (x32, dy16up, 0), (x16, dy16, 3)):
             dw, db = torch.full((64, 64, 3, 3), float("nan"), device=DEV), torch.full((64,), float("nan"), device=DEV)
-            ops.wgrad_c64(xin, v, dy, v, dw, db, B, H, W, 64, 64, storage=storage, **kw)
+            ops.wgrad_c64(xin, v, dyin, v, dw, db, B, H, W, 64, 64, storage=storage, **kw)
             out.append((dw, db))
-        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), kw.keys()
-        assert not torch.isnan(out[1][0]).any()
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), kw.keys()  # bf16 x
+        assert torch.equal(out[2][0], out[3][0]) and torch.equal(out[2][1], out[3][1]), kw.keys()  # bf16 x and dY
+        assert not torch.isnan(out[1][0]).any() and not torch.isnan(out[3][0]).any()
 
 
 def test_storage_entry_points_refuse_what_they_do_not_build():
