@@ -105,6 +105,21 @@ for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
     print('"%s",%d,%.1f' % (k[:120], len(v), sum(v) / len(v)))
 PY
       rm -rf "$O/pmc_${tag}_$ctr"; head -6 "$O/pmc_${tag}_$ctr.csv" | cut -c1-200 ;;
+    pmcb)       # pmcb TAG COUNTER bench-args...: one rocprofv3 --pmc pass over bench.py -> per-kernel mean of the counter
+      local tag=$1 ctr=$2; shift 2
+      ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$O/pmc_${tag}_$ctr" -o p -- python "$R/bench.py" "$@" > "$O/pmc_${tag}_$ctr.log" 2>&1 )
+      python - "$O/pmc_${tag}_$ctr" $ctr <<'PY' > "$O/pmc_${tag}_$ctr.csv"
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if r["Counter_Name"] == sys.argv[2]:
+        acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+print("kernel,launches,mean_" + sys.argv[2])
+for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+    print('"%s",%d,%.1f' % (k[:140], len(v), sum(v) / len(v)))
+PY
+      rm -rf "$O/pmc_${tag}_$ctr"; head -8 "$O/pmc_${tag}_$ctr.csv" | cut -c1-200 ;;
     sh)         # sh 'command'   (ad-hoc)
       bash -c "$1" > "$O/sh.log" 2>&1 || { tail -40 "$O/sh.log"; return 1; }
       tail -40 "$O/sh.log" ;;

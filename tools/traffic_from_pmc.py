@@ -57,6 +57,26 @@ SPEC = {
         },
         "headline": "conv fwd, plain (conv3x3_c64_bf16_persist_kernel<0,0,0,0,0>)",
     },
+    # bf16 operands AND bf16 storage of everything a residual group keeps or hands on (ops.set_storage("all")): maps of
+    # 32 x 128 x 128 x 64 x 2 B; counters from one pass each over bench.py --workload han --batch 32 --precision bf16
+    # --storage all (tools/gpu/run.sh pmcb; side stream off).  maps are counted in fp32-map units (a bf16 map = 0.5).
+    "bf16_all": {
+        "csv": ("r04_c_pmc_han_bf16_all_FETCH_SIZE_b32.csv", "r04_c_pmc_han_bf16_all_WRITE_SIZE_b32.csv"),
+        "json": "traffic_conv3x3_c64_bf16_all.json",
+        "families": {
+            "conv fwd, bf16 map in / out (persist<0,0,0,0,0 | in16,out16>)":
+                (["void conv3x3_c64_bf16_persist_kernel<false, false, false, false, false, true, true, false, false>"], 1.0, 0),
+            "conv fwd, GATE prologue: t2 + skip in, new skip + t1 out, all bf16 (persist<0,0,0,1,0 | in16,out16>)":
+                (["void conv3x3_c64_bf16_persist_kernel<false, false, false, true, false, true, true, false, false>"], 2.0, 0),
+            "dgrad, ReLU mask + affine, bf16 maps (persist<1,1,0,0,0 | in16,out16,aux16>)":
+                (["void conv3x3_c64_bf16_persist_kernel<true, true, false, false, false, true, true, true, false>"], 1.5, 0),
+            "dgrad + residual, DOT epilogue, bf16 maps (persist<0,0,1,0,1 | in16,out16,aux16,res16>)":
+                (["void conv3x3_c64_bf16_persist_kernel<false, false, true, false, true, true, true, true, true>"], 2.0, 0),
+            "wgrad, bf16 x and dY (wgrad3x3_c64_bf16_xy16_kernel) + slab reduce":
+                (["wgrad3x3_c64_bf16_xy16_kernel", "wgrad_reduce_kernel"], 1.0, 256),
+        },
+        "headline": "conv fwd, bf16 map in / out (persist<0,0,0,0,0 | in16,out16>)",
+    },
 }
 
 
