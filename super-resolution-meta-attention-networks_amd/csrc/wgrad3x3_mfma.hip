@@ -649,20 +649,26 @@ static __device__ __forceinline__ void wgrad3x3_c64_bf16_body(const WgradParams&
     const bool has_next = tile + t_step < t_end;  // uniform
     if (has_next) issue(tile + t_step);
 
-    // ---- 16 K-steps of 16 pixels (tile row r, half hf), nine taps each
-#pragma unroll 1
-    for (int r = 0; r < WT_H; ++r) {
+    // ---- 16 K-steps of 16 pixels (tile row r = ks >> 1, half hf = ks & 1), nine taps each.  One wave per SIMD: nobody
+    // else covers an LDS round trip, so the ten fragments of K-step ks + 1 are requested before the nine MFMAs of step ks
+    // (two fragment sets, 80 VGPRs; the accumulation order of every tap is unchanged: same bits).
+    {
+      bf16x8 af[2][9], bf[2];
+      auto load_step = [&](int ks, bf16x8* a9, bf16x8& b1) {
+        const int r = ks >> 1, hf = ks & 1;
+        b1 = wg_tr_frag(ldy + (r * WT_W + 16 * hf) * BW_PIX, yoff[0], yoff[1]);
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const unsigned char* yb = ldy + (r * WT_W + 16 * hf) * BW_PIX;
-        const bf16x8 bfrag = wg_tr_frag(yb, yoff[0], yoff[1]);
+        for (int t = 0; t < 9; ++t)
+          a9[t] = wg_tr_frag(ldx + ((r + t / 3) * WH_W + 16 * hf) * BW_PIX, aoff[t % 3][0], aoff[t % 3][1]);
+      };
+      load_step(0, af[0], bf[0]);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const unsigned char* xa = ldx + ((r + t / 3) * WH_W + 16 * hf) * BW_PIX;
-          const bf16x8 afrag = wg_tr_frag(xa, aoff[t % 3][0], aoff[t % 3][1]);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
-          if (t % 3 == 2) __builtin_amdgcn_sched_barrier(0);  // keep at most three taps' fragments in flight
-        }
+      for (int ks = 0; ks < 2 * WT_H; ++ks) {
+        if (ks + 1 < 2 * WT_H) load_step(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][t], bf[ks & 1], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // one step's MFMAs stay together behind the next step's fragment requests
       }
     }
     __syncthreads();  // every wave is done with this tile's LDS image
