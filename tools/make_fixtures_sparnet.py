@@ -144,7 +144,28 @@ def make_full():
         json.dump(entry, f, indent=1)
 
 
+def make_full_f64():
+    """The first of P4's three training steps evaluated by the reference in FLOAT64 (same seed-8 weights, same batch): the
+    exact loss and gradient norm that both fp32 evaluations -- the reference's and the HIP path's -- approximate."""
+    torch.manual_seed(8)
+    model = ModelInterface.define_model("sparnet", device=torch.device("cpu"), model_save_dir="/tmp", eval_mode=False,
+                                        scale=4, lr=1e-4)
+    g = torch.Generator().manual_seed(55)
+    torch.rand(1, 3, 128, 128, generator=g)  # the eval input of make_full, drawn from the same stream
+    xb, yb = torch.rand(2, 3, 128, 128, generator=g), torch.rand(2, 3, 128, 128, generator=g)
+    net = model.net.double().train()
+    loss = (net(xb.double()) - yb.double()).abs().mean()
+    loss.backward()
+    gn = float(torch.sqrt(sum((p.grad ** 2).sum() for p in net.parameters())))
+    with open(os.path.join(M.OUT, "p_sparnet_f64.json"), "w") as f:
+        json.dump({"step0": {"loss": float(loss), "grad_norm": gn}}, f, indent=1)
+    print(f"p4 float64 step 0 loss={float(loss):.9f} gn={gn:.9f}")
+
+
 if __name__ == "__main__":
+    if "--f64" in sys.argv:
+        make_full_f64()
+        sys.exit(0)
     if "--nets-only" in sys.argv:
         make_net("p2_sparnet_reduced", False)
         make_net("p3_qsparnet_reduced", True)
@@ -155,3 +176,4 @@ if __name__ == "__main__":
     make_net("p2_sparnet_reduced", False)
     make_net("p3_qsparnet_reduced", True)
     make_full()
+    make_full_f64()
