@@ -1659,10 +1659,28 @@ __device__ __forceinline__ void sisr_store_bf16x4(float* base, long elem, f32x4 
   *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + elem) = __builtin_bit_cast(u32x2, r);
 }
 
+// ... and the same through a buffer resource (scalar base, 32-bit lane offset, scalar offset: sisr_common.h) -- beside an
+// MFMA stream a 64-bit lane address costs its SIMD tens of cycles of issue per access
+__device__ __forceinline__ f32x4 sisr_buf_load_bf16x4(sisr_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  const u32x2 w = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff_bytes, (int)soff_bytes, 0));
+  f32x4 o;
+  o[0] = __uint_as_float(w[0] << 16); o[1] = __uint_as_float(w[0] & 0xffff0000u);
+  o[2] = __uint_as_float(w[1] << 16); o[3] = __uint_as_float(w[1] & 0xffff0000u);
+  return o;
+}
+__device__ __forceinline__ void sisr_buf_store_bf16x4(f32x4 v, sisr_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  bf16x4_t t;
+  t[0] = (__bf16)v[0]; t[1] = (__bf16)v[1]; t[2] = (__bf16)v[2]; t[3] = (__bf16)v[3];
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, t), r, (int)voff_bytes, (int)soff_bytes, 0);
+}
+
 // IN16: x, gate_add and gate_out are bf16 maps (the halo goes to LDS without conversion unless a prologue touches it);
 // OUT16: y is a bf16 map (rounded once, in the epilogue's store); AUX16: mask and dot are bf16 maps; RES16: res is.
+// STAMP (diagnostic library only, tools/bf16s_timeline.py): every wave sums the shader cycles it spends in the K loop, in the
+// epilogue and in committing the next halo, and writes them with its lifetime to the record p.dot points to.
 template <bool AFFINE, bool MASK, bool RES, bool GATE, bool DOT, bool IN16 = false, bool OUT16 = false, bool AUX16 = false,
-          bool RES16 = false>
+          bool RES16 = false, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvParams p, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1706,29 +1724,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
     h0 = th * TH;
     w0 = (r - th * p.tiles_w) * TW;
   };
+  // Every map access below is {resource on a wave-uniform base, 32-bit lane byte offset, scalar byte offset}: beside the
+  // other resident workgroup's MFMA stream a vector-memory instruction with a 64-bit lane address costs the SIMD tens of
+  // issue cycles, and the 64-bit arithmetic that builds it more (sisr_common.h "buffer addressing").
+  constexpr unsigned EI = IN16 ? 2u : 4u;  // bytes per element of x / gate_add / gate_out
   auto issue = [&](const float* src, int tile, Halo& dst) {
     int b, h0, w0;
     decode(tile, b, h0, w0);
-    const int gwi = min(w0 + pcol, W - 1);
+    const sisr_rsrc_t rx = sisr_rsrc(reinterpret_cast<const unsigned char*>(src) + (long)b * p.xv.sB * EI);
+    const unsigned vin = (unsigned)(min(w0 + pcol, W - 1) * (int)p.xv.sW + c8 * 8) * EI;
     const int gwe = min(max(eside ? w0 + TW : w0 - 1, 0), W - 1);
-    if (IN16) {
-      const unsigned short* xb = reinterpret_cast<const unsigned short*>(src) + (long)b * p.xv.sB;
+    const unsigned ved = (unsigned)(min(max(h0 - 1 + er, 0), H - 1) * (int)p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8) * EI;
 #pragma unroll
-      for (int r = 0; r < HALO_H; ++r)
-        dst.in[r][0] = *reinterpret_cast<const f32x4*>(xb + (long)min(max(h0 - 1 + r, 0), H - 1) * p.xv.sH + gwi * (int)p.xv.sW + c8 * 8);
-      dst.ed[0] = *reinterpret_cast<const f32x4*>(xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8);
-    } else {
-      const float* xb = src + (long)b * p.xv.sB;
-#pragma unroll
-      for (int r = 0; r < HALO_H; ++r) {
-        const float* a = xb + (long)min(max(h0 - 1 + r, 0), H - 1) * p.xv.sH + gwi * (int)p.xv.sW + c8 * 8;
-        dst.in[r][0] = *reinterpret_cast<const f32x4*>(a);
-        dst.in[r][IN16 ? 0 : 1] = *reinterpret_cast<const f32x4*>(a + 4);
-      }
-      const float* e = xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8;
-      dst.ed[0] = *reinterpret_cast<const f32x4*>(e);
-      dst.ed[IN16 ? 0 : 1] = *reinterpret_cast<const f32x4*>(e + 4);
+    for (int r = 0; r < HALO_H; ++r) {
+      const unsigned ro = (unsigned)(min(max(h0 - 1 + r, 0), H - 1) * (int)p.xv.sH) * EI;  // scalar
+      dst.in[r][0] = sisr_buf_load4(rx, vin, ro);
+      if (!IN16) dst.in[r][IN16 ? 0 : 1] = sisr_buf_load4(rx, vin + 16u, ro);
     }
+    dst.ed[0] = sisr_buf_load4(rx, ved, 0u);
+    if (!IN16) dst.ed[IN16 ? 0 : 1] = sisr_buf_load4(rx, ved + 16u, 0u);
   };
   auto commit = [&](unsigned char* buf, int tile) {
     int b, h0, w0;
@@ -1753,6 +1767,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
     if (GATE) issue(p.gate_add, tile, u);
     const int col = pcol + 1, gw = w0 + pcol;
     const bool cok = gw < W;
+    const sisr_rsrc_t rgo = sisr_rsrc(GATE ? reinterpret_cast<unsigned char*>(p.gate_out) + (long)b * p.xv.sB * EI
+                                           : reinterpret_cast<unsigned char*>(p.y));
+    const unsigned vgo = (unsigned)(min(gw, W - 1) * (int)p.xv.sW + c8 * 8) * EI;
     const unsigned lo_in = col * BH_PIX + ((c8 ^ ((col >> 1) & 7)) << 4);
 #pragma unroll
     for (int r = 0; r < HALO_H; ++r) {
@@ -1776,15 +1793,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
           ta = sisr_mul_add4(ta, s4a, ua);
           tb = sisr_mul_add4(tb, s4b, ub);
           if (!IN16 && r >= 1 && r <= TH && gh < H && cok) {  // interior columns are exactly the pixels this tile owns
-            float* o = p.gate_out + (long)b * p.xv.sB + (long)gh * p.xv.sH + (long)gw * p.xv.sW + c8 * 8;
-            *reinterpret_cast<f32x4*>(o) = ta;
-            *reinterpret_cast<f32x4*>(o + 4) = tb;
+            // (row offset folded into the lane offset, scalar offset 0: see the epilogue's stores)
+            const unsigned ro = (unsigned)(min(gh, H - 1) * (int)p.xv.sH) * EI;
+            sisr_buf_store4(ta, rgo, vgo + ro, 0u);
+            sisr_buf_store4(tb, rgo, vgo + ro + 16u, 0u);
           }
         }
         pk = sisr_pack_bf16x8(ta, tb);
         if (IN16 && GATE && r >= 1 && r <= TH && gh < H && cok)  // the gated skip is stored as the bf16 the MFMA reads
-          *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.gate_out) + (long)b * p.xv.sB + (long)gh * p.xv.sH +
-                                    (long)gw * p.xv.sW + c8 * 8) = pk;
+          sisr_buf_store4(__builtin_bit_cast(f32x4, pk), rgo, vgo + (unsigned)(min(gh, H - 1) * (int)p.xv.sH) * EI, 0u);
       }
       const unsigned m = (rok && cok) ? 0xffffffffu : 0u;
       pk &= (u32x4){m, m, m, m};
@@ -1821,10 +1838,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
 
   int tile = g;
   if (tile >= total_tiles) return;
+  unsigned long long st_life = 0, st_a = 0, st_k = 0, st_e = 0, st_c = 0;
+  unsigned st_tiles = 0;
+  if (STAMP) st_life = __builtin_amdgcn_s_memtime();
   issue(p.x, tile, v);
   commit(ldsb, tile);
   __syncthreads();
   for (int it = 0;; ++it) {
+    if (STAMP) st_a = __builtin_amdgcn_s_memtime();
     unsigned char* cur = ldsb + (it & 1) * PB_BUF;
     unsigned char* nxt = ldsb + ((it + 1) & 1) * PB_BUF;
     const int next = tile + G;
@@ -1858,6 +1879,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
     }
 #undef PB_LOAD_A
 #undef PB_LOAD_B
+    if (STAMP) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      st_k += t - st_a;
+      st_a = t;
+      ++st_tiles;
+    }
 
     // ---- epilogue through `cur` (its halo is dead once every wave has left the K loop)
     float os = p.alpha;
@@ -1865,42 +1892,87 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
     const float lo = p.relu ? 0.f : -3.402823466e38f;
     float* ot = reinterpret_cast<float*>(cur);
     const int c4 = tid & 15, pr = tid >> 4;
-    const long tile_base = (long)b * p.yv.sB + (long)w0 * p.yv.sW + c4 * 4;
+    const long tile_base = (long)b * p.yv.sB + (long)w0 * p.yv.sW;  // wave-uniform, elements
+    constexpr unsigned EY = OUT16 ? 2u : 4u, EA = AUX16 ? 2u : 4u, ER = RES16 ? 2u : 4u;
+    const sisr_rsrc_t ry = sisr_rsrc(reinterpret_cast<unsigned char*>(p.y) + tile_base * EY);
+    const sisr_rsrc_t rrs = sisr_rsrc(RES ? reinterpret_cast<const unsigned char*>(p.res) + tile_base * ER : (const unsigned char*)p.y);
+    const sisr_rsrc_t rmk = sisr_rsrc(MASK ? reinterpret_cast<const unsigned char*>(p.mask) + tile_base * EA : (const unsigned char*)p.y);
+    const sisr_rsrc_t rdt = sisr_rsrc(DOT ? reinterpret_cast<const unsigned char*>(p.dot) + tile_base * EA : (const unsigned char*)p.y);
     __syncthreads();
-    float grow[2];
+    // (beside the other workgroup's MFMA stream every instruction here costs issue time: ReLU, scaling and the pooled sums sit
+    // behind wave-uniform branches, the transposing writes use one base register and immediate offsets)
+    const bool do_relu = p.relu != 0, scaled = p.out_scale != nullptr || p.alpha != 1.0f;  // uniform
+    const bool want_sum = !DOT && p.gap != nullptr, full_tile = (h0 + TH <= H) && (w0 + TW <= W);
+    (void)lo;
+    float grow[2] = {0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      float gsum = 0.f;
-      const f32x16 acc = m ? acc1 : acc0;
-      const int prow = (2 * ph + m) * TW;
+      f32x16 acc = m ? acc1 : acc0;
+      if (do_relu) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int pc = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const float val = fmaxf(acc[r], lo) * os;
-        ot[(prow + pc) * BE_LD + co] = val;
-        if (h0 + 2 * ph + m < H && w0 + pc < W) gsum += val;
+        for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
       }
-      grow[m] = gsum + __shfl_xor(gsum, 32);
+      if (scaled) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= os;
+      }
+      float* wb = ot + ((2 * ph + m) * TW + 4 * hh) * BE_LD + co;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wb[((r & 3) + 8 * (r >> 2)) * BE_LD] = acc[r];
+      if (want_sum) {
+        float gsum = 0.f;
+        if (full_tile) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gsum += acc[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (h0 + 2 * ph + m < H && w0 + (r & 3) + 8 * (r >> 2) + 4 * hh < W) gsum += acc[r];
+        }
+        grow[m] = gsum + __shfl_xor(gsum, 32);
+      }
     }
     const int tile_in_img = tile - b * tiles_per_img;
     const long parts = (long)tiles_per_img * 2;
     if (!DOT && p.gap && hh == 0) p.gap[(((long)b * parts) + tile_in_img * 2 + ph) * 64 + co] = grow[0] + grow[1];
+    // Whole tiles (every tile of a 128 x 128 map) take the straight-line form: no clamps, no per-store predicates -- the
+    // divergent branch around each store of the general form costs six scalar instructions.
     f32x4 rv[8], mv[8], dv[8];
     bool ok[8];
-    long off[8];
+    unsigned vo[8], so[8];  // element offsets inside the tile's resource: lane part, scalar (row) part
+    if (full_tile) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ok[i] = true;
+        vo[i] = (unsigned)((pr + 16 * (i & 1)) * (int)p.yv.sW + c4 * 4);
+        so[i] = (unsigned)((h0 + (i >> 1)) * (int)p.yv.sH);  // scalar
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = h0 + (i >> 1), col = pr + 16 * (i & 1);
+        ok[i] = row < H && w0 + col < W;
+        vo[i] = (unsigned)(min(col, W - 1 - w0) * (int)p.yv.sW + c4 * 4);
+        so[i] = (unsigned)(min(row, H - 1) * (int)p.yv.sH);  // scalar
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {  // epilogue operands (the accumulators are dead by now)
-      const int row = h0 + (i >> 1), col = pr + 16 * (i & 1);
-      ok[i] = row < H && w0 + col < W;
-      off[i] = tile_base + (long)min(row, H - 1) * p.yv.sH + (long)min(col, W - 1 - w0) * p.yv.sW;
-      if (RES) rv[i] = RES16 ? sisr_load_bf16x4(p.res, off[i]) : *reinterpret_cast<const f32x4*>(p.res + off[i]);
-      if (MASK) mv[i] = AUX16 ? sisr_load_bf16x4(p.mask, off[i]) : *reinterpret_cast<const f32x4*>(p.mask + off[i]);
-      if (DOT) dv[i] = AUX16 ? sisr_load_bf16x4(p.dot, off[i]) : *reinterpret_cast<const f32x4*>(p.dot + off[i]);
+      if (RES) rv[i] = RES16 ? sisr_buf_load_bf16x4(rrs, vo[i] * 2u, so[i] * 2u) : sisr_buf_load4(rrs, vo[i] * 4u, so[i] * 4u);
+      if (MASK) mv[i] = AUX16 ? sisr_buf_load_bf16x4(rmk, vo[i] * 2u, so[i] * 2u) : sisr_buf_load4(rmk, vo[i] * 4u, so[i] * 4u);
+      if (DOT) dv[i] = AUX16 ? sisr_buf_load_bf16x4(rdt, vo[i] * 2u, so[i] * 2u) : sisr_buf_load4(rdt, vo[i] * 4u, so[i] * 4u);
     }
     __syncthreads();
     f32x4 dsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    // Stores: a 128-bit buffer store carries its whole offset in the lane operand, scalar offset 0.  Found the hard way: a
+    // 128-bit buffer store with an SGPR scalar offset whose data registers the next VALU instruction overwrites loses that
+    // race on gfx950 (the compiler's hazard table covers the immediate-offset form only): 4 channels of every other row came
+    // out wrong.  The 64-bit (bf16) stores are outside that hazard and keep the row in the scalar offset.
+    auto put = [&](int i, f32x4 val) {
+      if (OUT16) sisr_buf_store_bf16x4(val, ry, vo[i] * 2u, so[i] * 2u);
+      else sisr_buf_store4(val, ry, (vo[i] + so[i]) * 4u, 0u);
+    };
+    auto finish = [&](int i) {
       f32x4 val = *reinterpret_cast<const f32x4*>(ot + (pr + 16 * i) * BE_LD + c4 * 4);
       if (MASK) {
         val[0] = mv[i][0] > 0.f ? val[0] : 0.f;
@@ -1909,10 +1981,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
         val[3] = mv[i][3] > 0.f ? val[3] : 0.f;
       }
       if (RES) val += rv[i];
-      if (ok[i]) {
-        if (OUT16) sisr_store_bf16x4(p.y, off[i], val);
-        else *reinterpret_cast<f32x4*>(p.y + off[i]) = val;
+      return val;
+    };
+    if (full_tile) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 val = finish(i);
+        put(i, val);
         if (DOT) dsum[i >> 2] += val * dv[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 val = finish(i);
+        if (ok[i]) {
+          put(i, val);
+          if (DOT) dsum[i >> 2] += val * dv[i];
+        }
       }
     }
     if (DOT) {
@@ -1929,10 +2014,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_bf16_persist_kernel(ConvPa
         p.gap[(((long)b * parts) + tile_in_img * 2 + strip) * 64 + chn] = sacc;
       }
     }
+    if (STAMP) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      st_e += t - st_a;
+      st_a = t;
+    }
     if (!has_next) break;
     commit(nxt, next);  // the prefetched halo of the next tile (nxt's previous reader finished one iteration ago)
     __syncthreads();
+    if (STAMP) st_c += __builtin_amdgcn_s_memtime() - st_a;
     tile = next;
+  }
+  if (STAMP && lane == 0) {
+    unsigned* dbg = reinterpret_cast<unsigned*>(const_cast<float*>(p.dot)) + ((long)blockIdx.x * 4 + wave) * 8;
+    dbg[0] = (unsigned)(__builtin_amdgcn_s_memtime() - st_life);
+    dbg[1] = (unsigned)st_k;
+    dbg[2] = (unsigned)st_e;
+    dbg[3] = (unsigned)st_c;
+    dbg[4] = st_tiles;
+    dbg[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11));   // HW_REG_HW_ID
+    dbg[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11));  // HW_REG_XCC_ID
+    dbg[7] = (unsigned)(st_life & 0xffffffffu);
   }
 }
 
@@ -2662,6 +2764,13 @@ extern "C" int sisr_conv3x3_c64_bf16s(const float* x, const int64_t* xview, cons
                                       float* gap_partial, const float* gate_add, float* gate_out, const float* dot, int B,
                                       int H, int W, int storage, void* stream) {
   if (!x || !wpacked_bf16 || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0 || storage < 0 || storage > 15) return SISR_ERR_ARG;
+#ifdef SISR_DIAG
+  const float* stamp_buf = nullptr;  // tools/bf16s_timeline.py: the plain bf16 -> bf16 form with in-kernel cycle sums
+  if (getenv("SISR_BF16S_STAMP") && storage == 3 && dot && !gap_partial && !gate_add && !mask && !res && !in_scale) {
+    stamp_buf = dot;
+    dot = nullptr;
+  }
+#endif
   const bool gate = gate_add != nullptr;
   if (gate != (gate_out != nullptr) || (gate && !in_scale) || (gate && dot) || (dot && !gap_partial) ||
       (gate && (in_shift || mask)) || memcmp(xview, yview, 6 * sizeof(int64_t)) != 0)
@@ -2715,6 +2824,15 @@ extern "C" int sisr_conv3x3_c64_bf16s(const float* x, const int64_t* xview, cons
     return sisr_check_launch();                                                                                         \
   } while (0)
   const int form = (in_scale && !gate ? 16 : 0) | (mask ? 8 : 0) | (res ? 4 : 0) | (gate ? 2 : 0) | (dot ? 1 : 0);
+#ifdef SISR_DIAG
+  if (stamp_buf) {
+    p.dot = stamp_buf;
+    SISR_ALLOW_LDS((conv3x3_c64_bf16_persist_kernel<false, false, false, false, false, true, true, false, false, true>), plb);
+    hipLaunchKernelGGL((conv3x3_c64_bf16_persist_kernel<false, false, false, false, false, true, true, false, false, true>), pg,
+                       dim3(256), plb, st, p, total);
+    return sisr_check_launch();
+  }
+#endif
   // forward of the group node: bf16 activations in and out
   if (storage == 3 && form == 0) PSX(false, false, false, false, false, true, true, false, false);   // conv (+ ReLU / GAP sums)
   if (storage == 3 && form == 2) PSX(false, false, false, true, false, true, true, false, false);    // GATE prologue

@@ -30,6 +30,11 @@ recipe() {
         SISR_HIP_LIB=$DIAG timeout -k 10 120 python tools/conv_timeline.py $b $f > "$O/timeline_b${b}_$f.json" 2> "$O/timeline_b${b}_$f.err" || tail -5 "$O/timeline_b${b}_$f.err"
         head -1 "$O/timeline_b${b}_$f.json" | cut -c1-1400
       done; done ;;
+    bf16s)      # in-kernel cycle sums of the bf16-map persistent conv (diagnostic library): bf16s [BATCHES]
+      for b in ${1:-32 16}; do
+        SISR_HIP_LIB=$DIAG timeout -k 10 120 python tools/bf16s_timeline.py $b > "$O/bf16s_b$b.json" 2> "$O/bf16s_b$b.err" || tail -5 "$O/bf16s_b$b.err"
+        cat "$O/bf16s_b$b.json"
+      done ;;
     kbench)     # kbench [BATCHES] [extra kbench args]
       local bs=${1:-4 32}; shift || true
       for b in $bs; do timeout -k 10 200 python tools/kbench.py --batch $b --iters 30 --only conv,conv_dgrad2,conv_res,conv_relu_gap,wgrad,wgrad_affine "$@" > "$O/kbench_b$b.jsonl"; cat "$O/kbench_b$b.jsonl"; done ;;
