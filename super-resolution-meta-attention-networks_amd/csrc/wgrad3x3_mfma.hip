@@ -481,8 +481,10 @@ __device__ __forceinline__ bf16x8 wg_tr_frag(const unsigned char* base, unsigned
 
 // X16 / Y16: x / dY is a bf16 map in HBM (same View, 2-byte elements; sisr_wgrad3x3_c64_bf16s): its 16-B pieces go to LDS
 // as they are (x) or after the fp32 affine rebuild and re-rounding (dY with dy_scale / dy_shift).
+// stamp (diagnostic library only, tools/bf16s_timeline.py --wgrad): per wave, the shader cycles spent in the K loops and in
+// committing the next tile (wait for its prefetched loads, conversions, LDS writes, barriers), with the wave's lifetime.
 template <bool X16, bool Y16>
-static __device__ __forceinline__ void wgrad3x3_c64_bf16_body(const WgradParams& p) {
+static __device__ __forceinline__ void wgrad3x3_c64_bf16_body(const WgradParams& p, unsigned* stamp = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* ldx = ldsb;
   unsigned char* ldy = ldsb + BW_X_BYTES;
@@ -640,6 +642,9 @@ static __device__ __forceinline__ void wgrad3x3_c64_bf16_body(const WgradParams&
     }
   };
 
+  unsigned long long st_life = 0, st_a = 0, st_k = 0, st_c = 0;
+  unsigned st_tiles = 0;
+  if (stamp) st_life = __builtin_amdgcn_s_memtime();
   if (t_begin < t_end) {
     issue(t_begin);
     commit(t_begin);
@@ -647,6 +652,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_bf16_body(const WgradParams&
   __syncthreads();
   for (int tile = t_begin; tile < t_end; tile += t_step) {
     const bool has_next = tile + t_step < t_end;  // uniform
+    if (stamp) st_a = __builtin_amdgcn_s_memtime();
     if (has_next) issue(tile + t_step);
 
     // ---- 16 K-steps of 16 pixels (tile row r = ks >> 1, half hf = ks & 1), nine taps each.  One wave per SIMD: nobody
@@ -671,11 +677,29 @@ static __device__ __forceinline__ void wgrad3x3_c64_bf16_body(const WgradParams&
         __builtin_amdgcn_sched_barrier(0);  // one step's MFMAs stay together behind the next step's fragment requests
       }
     }
+    if (stamp) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      st_k += t - st_a;
+      st_a = t;
+      ++st_tiles;
+    }
     __syncthreads();  // every wave is done with this tile's LDS image
     if (has_next) {
       commit(tile + t_step);
       __syncthreads();
     }
+    if (stamp) st_c += __builtin_amdgcn_s_memtime() - st_a;
+  }
+  if (stamp && lane == 0) {
+    unsigned* dbg = stamp + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    dbg[0] = (unsigned)(__builtin_amdgcn_s_memtime() - st_life);
+    dbg[1] = (unsigned)st_k;
+    dbg[2] = 0;
+    dbg[3] = (unsigned)st_c;
+    dbg[4] = st_tiles;
+    dbg[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+    dbg[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+    dbg[7] = (unsigned)(st_life & 0xffffffffu);
   }
 
   // ---- slabs: unit = pair*4 + (ci half, co half), the fp32 kernel's layout
@@ -703,6 +727,13 @@ static __device__ __forceinline__ void wgrad3x3_c64_bf16_body(const WgradParams&
 __global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_kernel(WgradParams p) { wgrad3x3_c64_bf16_body<false, false>(p); }
 __global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_x16_kernel(WgradParams p) { wgrad3x3_c64_bf16_body<true, false>(p); }
 __global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_xy16_kernel(WgradParams p) { wgrad3x3_c64_bf16_body<true, true>(p); }
+#ifdef SISR_DIAG
+static unsigned* g_diag_wgrad_stamp = nullptr;  // diagnostic library only (the product library keeps no state)
+extern "C" void sisr_diag_wgrad_stamp(void* buf) { g_diag_wgrad_stamp = static_cast<unsigned*>(buf); }
+__global__ __launch_bounds__(256, 1) void wgrad3x3_c64_bf16_xy16_stamp_kernel(WgradParams p, unsigned* stamp) {
+  wgrad3x3_c64_bf16_body<true, true>(p, stamp);
+}
+#endif
 
 // ------------------------------------------------------------------ bf16x3 weight gradient
 // The bf16 kernel above with every fp32 operand split exactly into three bf16 numbers (conv3x3_mfma.hip, "bf16x3") and six
@@ -1293,8 +1324,17 @@ static int wgrad3x3_c64_bf16_launch(const float* x, const int64_t* xview, const 
     SISR_ALLOW_LDS(wgrad3x3_c64_bf16_x16_kernel, lds_bytes);
     hipLaunchKernelGGL(wgrad3x3_c64_bf16_x16_kernel, dim3(p.S, pairs), dim3(256), lds_bytes, (hipStream_t)stream, p);
   } else {
-    SISR_ALLOW_LDS(wgrad3x3_c64_bf16_xy16_kernel, lds_bytes);
-    hipLaunchKernelGGL(wgrad3x3_c64_bf16_xy16_kernel, dim3(p.S, pairs), dim3(256), lds_bytes, (hipStream_t)stream, p);
+#ifdef SISR_DIAG
+    if (g_diag_wgrad_stamp) {
+      SISR_ALLOW_LDS(wgrad3x3_c64_bf16_xy16_stamp_kernel, lds_bytes);
+      hipLaunchKernelGGL(wgrad3x3_c64_bf16_xy16_stamp_kernel, dim3(p.S, pairs), dim3(256), lds_bytes, (hipStream_t)stream, p,
+                         g_diag_wgrad_stamp);
+    } else
+#endif
+    {
+      SISR_ALLOW_LDS(wgrad3x3_c64_bf16_xy16_kernel, lds_bytes);
+      hipLaunchKernelGGL(wgrad3x3_c64_bf16_xy16_kernel, dim3(p.S, pairs), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    }
   }
   int rc = sisr_check_launch();
   if (rc) return rc;

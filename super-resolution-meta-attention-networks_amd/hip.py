@@ -66,6 +66,7 @@ OPTIONAL_SIGS = {  # only in libsisr_hip_diag.so (csrc/build.sh diag; select it 
     "sisr_diag_conv_occupancy": (c_int, [c_int]),
     "sisr_diag_conv_stamp": (None, [P]),
     "sisr_diag_mfma_fill": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P]),
+    "sisr_diag_wgrad_stamp": (None, [P]),
 }
 _SIGS.update({
     "sisr_lam_workspace_bytes": (c_size_t, [c_int, c_int, c_long]),

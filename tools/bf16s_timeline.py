@@ -38,6 +38,37 @@ def launch(stamped):
     ops.conv_c64s(x, pk, b, y, B, H, W, 3, dot=stamp.view(torch.float32) if stamped else None)
 
 
+if "--wgrad" in sys.argv:  # the bf16 weight gradient reading bf16 x and dY (one persistent workgroup per CU)
+    dy = torch.randn(B, 64, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    dw, db = torch.empty(64, 64, 3, 3, device=dev), torch.empty(64, device=dev)
+    v = hip.view_plain(H, W, 64)
+    wst = torch.zeros(256 * 4 * 8, dtype=torch.int32, device=dev)
+    run = lambda: ops.wgrad_c64(x, v, dy, v, dw, db, B, H, W, 64, 64, storage=3)  # noqa: E731
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    hip.lib().sisr_diag_wgrad_stamp(wst.data_ptr())
+    run()
+    torch.cuda.synchronize()
+    hip.lib().sisr_diag_wgrad_stamp(None)
+    r = wst.cpu().numpy().astype(np.uint32).reshape(-1, 8).astype(np.float64)
+    r = r[r[:, 4] > 0]
+    life, k, c, n = r[:, 0], r[:, 1], r[:, 3], r[:, 4]
+    med = lambda a: float(np.median(a))  # noqa: E731
+    print(json.dumps({"kernel": "wgrad3x3_c64_bf16_xy16 (+ slab reduce)", "batch": B, "launch_us_with_reduce": us, "waves": int(len(r)),
+                      "wave_lifetime_cycles": med(life), "tiles_per_wave": med(n), "kloop_cycles_per_tile": med(k / n),
+                      "commit_and_barrier_cycles_per_tile": med(c / n), "kloop_share": med(k / life), "commit_share": med(c / life),
+                      "mfma_cycles_per_wave_tile": 144 * 32,
+                      "note": "K loop: 16 K-steps x (10 transposed fragment reads = 20 ds_read_b64_tr_b16, 9 MFMAs of 32 cycles); one wave per SIMD"}))
+    sys.exit(0)
+
 for _ in range(5):
     launch(False)
 torch.cuda.synchronize()

@@ -34,6 +34,8 @@ recipe() {
       for b in ${1:-32 16}; do
         SISR_HIP_LIB=$DIAG timeout -k 10 120 python tools/bf16s_timeline.py $b > "$O/bf16s_b$b.json" 2> "$O/bf16s_b$b.err" || tail -5 "$O/bf16s_b$b.err"
         cat "$O/bf16s_b$b.json"
+        SISR_HIP_LIB=$DIAG timeout -k 10 120 python tools/bf16s_timeline.py $b --wgrad > "$O/bf16s_wgrad_b$b.json" 2> "$O/bf16s_wgrad_b$b.err" || tail -5 "$O/bf16s_wgrad_b$b.err"
+        cat "$O/bf16s_wgrad_b$b.json"
       done ;;
     kbench)     # kbench [BATCHES] [extra kbench args]
       local bs=${1:-4 32}; shift || true
