@@ -602,10 +602,19 @@ class QEDSR(ChannelPadded, nn.Module):
         if self.padded():
             return self._run_padded(x, metadata)
         x = _conv(self.head, x)
-        res = x
-        for blk, m in zip(self.body, meta_gates([b.attention_layer for b in self.body], metadata)):
-            res, _ = blk((res, metadata), m)
-        res = _conv(self.final_body, res, residual=x)
+        gates = meta_gates([b.attention_layer for b in self.body], metadata)
+        if ops.fused_groups_enabled() and x.shape[1] == 64 and len(self.body) > 0:
+            # the whole body -- blocks, final conv, long skip -- as ONE node: the gated skips are built by the next conv's staging
+            # and the meta gates' gradients taken by the previous backward conv's epilogue (ops._GatedGroup without channel
+            # attention): no gate-multiply pass forward, no gradient-reduction pass backward
+            blocks = [(b.body[0].weight, b.body[0].bias, b.body[2].weight, b.body[2].bias, None, m)
+                      for b, m in zip(self.body, gates)]
+            res = ops.gated_group(x, blocks, self.final_body.weight, self.final_body.bias, alpha=self.body[0].res_scale)
+        else:
+            res = x
+            for blk, m in zip(self.body, gates):
+                res, _ = blk((res, metadata), m)
+            res = _conv(self.final_body, res, residual=x)
         return _conv(self.tail[1], self.tail[0](res))
 
     def meta_gate_layers(self):

@@ -494,7 +494,27 @@ __global__ __launch_bounds__(256) void gate_dg_partial_kernel(const float* __res
   }
 }
 
-// out[b][c] = scale * sum_k part[b][k][c]
+// out[b][c] = scale * sum_k part[b][k][c], C a multiple of 4: one workgroup per (64-channel chunk, b); 16 lanes cover the chunk with
+// one float4 each, the 16 lane groups take k = r, r + 16, ... (coalesced 256-B rows, 16 loads in flight per wave instead of
+// one thread walking all `parts` rows), and the 16 group sums are added in index order: the result does not depend on timing.
+__global__ __launch_bounds__(256) void sum_partials_c4_kernel(const float* __restrict__ part, int parts, int C, float scale,
+                                                              float* __restrict__ out) {
+  __shared__ f32x4 red[256];
+  const int lane = threadIdx.x & 15, r = threadIdx.x >> 4, b = blockIdx.y;
+  const int c = blockIdx.x * 64 + lane * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c < C)
+    for (int k = r; k < parts; k += 16) s += *reinterpret_cast<const f32x4*>(part + ((long)b * parts + k) * C + c);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && c < C) {
+    f32x4 t = red[threadIdx.x];
+    for (int q = 1; q < 16; ++q) t += red[q * 16 + threadIdx.x];
+    *reinterpret_cast<f32x4*>(out + (long)b * C + c) = t * scale;
+  }
+}
+
+// the same for any C (one thread per output, rows in order)
 __global__ void sum_partials_kernel(const float* __restrict__ part, int parts, int C, float scale,
                                     float* __restrict__ out, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -858,6 +878,11 @@ extern "C" int sisr_gate_dg_partial(const float* dy, const float* t, float* part
 extern "C" int sisr_sum_partials(const float* part, int parts, int B, int channels, float scale, float* out,
                                  void* stream) {
   if (!part || !out || parts <= 0 || B <= 0 || channels <= 0) return SISR_ERR_ARG;
+  if (!(channels & 3) && sisr_aligned16(part) && sisr_aligned16(out) && B <= 65535) {
+    hipLaunchKernelGGL(sum_partials_c4_kernel, dim3((unsigned)((channels + 63) / 64), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, part, parts, channels, scale, out);
+    return sisr_check_launch();
+  }
   const long total = (long)B * channels;
   hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
                      parts, channels, scale, out, total);

@@ -1187,18 +1187,25 @@ class _GatedGroup(Function):
     PER = 9  # w1, b1, w2, b2, caw1, cab1, caw2, cab2, m
 
     @staticmethod
-    def forward(ctx, x, n, *args):
+    def forward(ctx, x, n, alpha, *args):
         B, C, H, W = x.shape
         if C != 64:
             raise NotImplementedError("fused residual group is specialised for n_feats = 64")
+        # Blocks WITHOUT channel attention (QEDSR's ParamResBlock, ref attention_manipulators/architectures.py:348-356:
+        # x + m * (res_scale * conv2(relu(conv1 x)))): the gate is the meta-attention vector alone, known before the first
+        # launch -- no pooling, no gate launch; `alpha` = res_scale rides in conv2's epilogue.  All blocks of a group alike.
+        has_ca = args[4] is not None
+        if not has_ca and args[8] is None:
+            raise NotImplementedError("fused residual group: a block needs a channel-attention gate or a meta gate")
+        alpha = float(alpha)
         _join_pending.clear()
         dev, L = x.device, hip.lib()
         x = _cl(x)
         v = hip.view_plain(H, W, 64)
         need = any(ctx.needs_input_grad)
         parts = gap_parts(H, W)
-        tails = _use_ca_tail(B, H, W)
-        heads = GATE_HEADS and not tails and WgradQueue.wanted(B, H, W) and B * H * W <= GATE_HEADS_MAX_PIXELS
+        tails = has_ca and _use_ca_tail(B, H, W)
+        heads = has_ca and GATE_HEADS and not tails and WgradQueue.wanted(B, H, W) and B * H * W <= GATE_HEADS_MAX_PIXELS
         PER = _GatedGroup.PER
         lanes = _Lanes(dev, _lane_cuts(B, H, W))
         # bf16 operand mode with bf16 storage: the maps this group keeps (t1, t2, the gated skips) are bf16 in HBM
@@ -1217,24 +1224,36 @@ class _GatedGroup(Function):
 
         # every buffer of the group, on the calling stream
         blks, tensors, packs, meta, small = [], [], [], [], []
+        if not has_ca and alpha != 1.0:  # alpha * m of every block in two launches
+            gs_all = torch.stack([args[k * PER + 8] for k in range(n)]).mul_(alpha)
         for k in range(n):
             w1, b1, w2, b2, caw1, cab1, caw2, cab2, m = args[k * PER:(k + 1) * PER]
             w1, w2 = w1.contiguous(), w2.contiguous()
             p1, pd1 = pack(w1)
             p2, pd2 = pack(w2)
-            R = caw1.shape[0]
-            d = dict(p1=p1, p2=p2, b1=b1, b2=b2, R=R, t1=new_map(B, 64, H, W, dev), t2=new_map(B, 64, H, W, dev),
-                     u=new_map(B, 64, H, W, dev) if k > 0 else x_in,
-                     gap=torch.empty((B, parts, 64), device=dev, dtype=torch.float32),
-                     caw1c=caw1.reshape(R, 64).contiguous(), caw2c=caw2.reshape(64, R).contiguous(),
-                     cb1=cab1.contiguous(), cb2=cab2.contiguous(), mm=m.contiguous() if m is not None else None,
-                     sv=_vec(B, 64, dev), hid=_vec(B, R, dev), ca=_vec(B, 64, dev), g=_vec(B, 64, dev))
+            if has_ca:
+                R = caw1.shape[0]
+                d = dict(p1=p1, p2=p2, b1=b1, b2=b2, R=R, t1=new_map(B, 64, H, W, dev), t2=new_map(B, 64, H, W, dev),
+                         u=new_map(B, 64, H, W, dev) if k > 0 else x_in,
+                         gap=torch.empty((B, parts, 64), device=dev, dtype=torch.float32),
+                         caw1c=caw1.reshape(R, 64).contiguous(), caw2c=caw2.reshape(64, R).contiguous(),
+                         cb1=cab1.contiguous(), cb2=cab2.contiguous(), mm=m.contiguous() if m is not None else None,
+                         sv=_vec(B, 64, dev), hid=_vec(B, R, dev), ca=_vec(B, 64, dev), g=_vec(B, 64, dev))
+                blk = [d["u"], w1, w2, d["t1"], d["t2"], d["caw1c"], d["caw2c"], d["sv"], d["hid"], d["ca"], d["g"]]
+                if d["mm"] is not None:
+                    blk.append(d["mm"])
+                meta.append((len(blk), d["mm"] is not None, tuple(caw1.shape), tuple(caw2.shape)))
+            else:
+                mm = m.contiguous()
+                # gs = alpha * m: the scale of the gradient entering conv2 (its input gradient and its weight gradient both
+                # rebuild dt2 = dU * gs while staging, so both run with alpha = 1 and the weight gradient stays batchable)
+                d = dict(p1=p1, p2=p2, b1=b1, b2=b2, R=0, t1=new_map(B, 64, H, W, dev), t2=new_map(B, 64, H, W, dev),
+                         u=new_map(B, 64, H, W, dev) if k > 0 else x_in, gap=None, mm=mm, g=mm,
+                         gs=mm if alpha == 1.0 else gs_all[k], sv=None, hid=None, ca=None)
+                blk = [d["u"], w1, w2, d["t1"], d["t2"], d["g"], d["gs"]]
+                meta.append((len(blk), True, None, None))
             blks.append(d)
             small.append((b1, b2, caw1, cab1, caw2, cab2))
-            blk = [d["u"], w1, w2, d["t1"], d["t2"], d["caw1c"], d["caw2c"], d["sv"], d["hid"], d["ca"], d["g"]]
-            if d["mm"] is not None:
-                blk.append(d["mm"])
-            meta.append((len(blk), d["mm"] is not None, tuple(caw1.shape), tuple(caw2.shape)))
             tensors += blk
             packs.append((pd1, pd2))
         wt, bt = args[n * PER:n * PER + 2]
@@ -1250,8 +1269,8 @@ class _GatedGroup(Function):
             pend = None  # (t2, g, gate head) of the block whose gated skip the next conv builds
             for k in range(n):
                 d = blks[k]
-                t1, t2, gap = d["t1"][sl], d["t2"][sl], d["gap"][sl]
-                sv, hid, ca, g = d["sv"][sl], d["hid"][sl], d["ca"][sl], d["g"][sl]
+                t1, t2, g = d["t1"][sl], d["t2"][sl], d["g"][sl]
+                gap, sv, hid, ca = (d[key][sl] if has_ca else None for key in ("gap", "sv", "hid", "ca"))
                 mm = d["mm"][sl] if d["mm"] is not None else None
                 if pend is None:
                     conv(x_in[sl], d["p1"], d["b1"], t1, Bl, 3, relu=True)
@@ -1262,7 +1281,9 @@ class _GatedGroup(Function):
                     conv_c64(pend[0], v, d["p1"], d["b1"], (1, 64), t1, v, Bl, H, W, 64, 64, relu=True, in_scale=pend[1],
                              gate_add=blks[k - 1]["u"][sl], gate_out=d["u"][sl], ca_tail=pend[2])
                 hd = None
-                if tails:  # the gate is computed by conv2's last-arriving workgroup per sample
+                if not has_ca:  # the gate is the meta-attention vector: nothing to pool, nothing to launch
+                    conv(t1, d["p2"], d["b2"], t2, Bl, 3, alpha=alpha)
+                elif tails:  # the gate is computed by conv2's last-arriving workgroup per sample
                     conv_c64(t1, v, d["p2"], d["b2"], (1, 64), t2, v, Bl, H, W, 64, 64, gap=gap,
                              ca_tail=_tail_fwd(Bl, H, W, d["R"], d["caw1c"], d["cb1"], d["caw2c"], d["cb2"], mm, sv, hid, ca, g, dev))
                 elif heads:  # the gate is computed by the conv that consumes it (the next block's conv1, or the group's tail conv)
@@ -1299,6 +1320,7 @@ class _GatedGroup(Function):
         ctx.packs, ctx.pdt = packs, pdt
         ctx.small, ctx.bt = small, bt  # the small parameters: their gradients go straight into the optimiser's arena too
         ctx.st16, ctx.grad16 = st16, st16 and BF16_STORAGE == "all"
+        ctx.has_ca = has_ca
         return out
 
     @staticmethod
@@ -1329,6 +1351,7 @@ class _GatedGroup(Function):
             # st16: the saved activations (un, every block's input, t1, t2) are bf16 maps; g16: so are the gradient maps the
             # launches of this pass hand to each other (the group's own input / output gradients stay fp32)
             st16, g16 = ctx.st16, ctx.grad16
+            has_ca = ctx.has_ca
             wst = 1 if st16 else 0
             grad_map = _empty_cl16 if g16 else _empty_cl
 
@@ -1345,8 +1368,8 @@ class _GatedGroup(Function):
             side = _side_ok(wt, *(t for blk in blocks for t in blk[0][1:3]))
             # small launches: the group's 2n + 1 weight gradients go out eight to a launch (WgradQueue) instead of one by one
             queue = WgradQueue(B, H, W, dev) if WgradQueue.wanted(B, H, W) else None
-            tails = _use_ca_tail(B, H, W)
-            bheads = not tails and queue is not None and GATE_HEADS and B * H * W <= GATE_HEADS_MAX_PIXELS
+            tails = has_ca and _use_ca_tail(B, H, W)
+            bheads = has_ca and not tails and queue is not None and GATE_HEADS and B * H * W <= GATE_HEADS_MAX_PIXELS
             lanes = _Lanes(dev, _lane_cuts(B, H, W) if queue is not None else [(0, B)])
             nl = len(lanes.cuts)
             gate_jobs, keep = [], []
@@ -1361,6 +1384,9 @@ class _GatedGroup(Function):
                 """Outputs of block k's gate backward (allocated before the conv launch whose tail / head fills them)."""
                 tens, has_m, s_caw1, s_caw2 = blocks[k]
                 _, _, caw1, cab1, caw2, cab2 = ctx.small[k]
+                if not has_ca:  # the meta gate's gradient is the sum of the DOT partials; no pooling gradient, no CA parameters
+                    return dict(shift=None, dmv=_vec(B, 64, dev), dcaw1=None, dcab1=None, dcaw2=None, dcab2=None, dzw=None,
+                                dgp=torch.empty((B, parts, 64), device=dev, dtype=torch.float32))
                 return dict(shift=_vec(B, 64, dev), dmv=_vec(B, 64, dev) if has_m else None,
                             dcaw1=_grad_buf(caw1), dcab1=_grad_buf(cab1), dcaw2=_grad_buf(caw2), dcab2=_grad_buf(cab2),
                             dgp=torch.empty((B, parts, 64), device=dev, dtype=torch.float32),
@@ -1396,13 +1422,21 @@ class _GatedGroup(Function):
                 the gate backward / after the first conv (where a single chain issues the block's weight gradients)."""
                 sl, Bl = slice(b0, b1), b1 - b0
                 tens, has_m, s_caw1, s_caw2 = blocks[k]
-                xk, w1, w2, t1, t2, caw1c, caw2c, s, hid, ca, g = tens[:11]
-                mm = tens[11][sl] if has_m else None
                 pd1, pd2 = ctx.packs[k]
-                R = caw1c.shape[0]
-                shift, dmv = go["shift"][sl], go["dmv"][sl] if has_m else None
                 bhead = None
-                if bheads:  # the per-sample part of the gate backward is computed by the conv that consumes `shift` (gate head)
+                if not has_ca:
+                    xk, w1, w2, t1, t2, g, gs = tens
+                    hip.check(L.sisr_sum_partials(hip.ptr(go["dgp"][sl]), parts, Bl, 64, 1.0, hip.ptr(go["dmv"][sl]), hip.stream()),
+                              "sisr_sum_partials")
+                    g, shift = gs, None  # dt2 = dU * (alpha * m)
+                else:
+                    xk, w1, w2, t1, t2, caw1c, caw2c, s, hid, ca, g = tens[:11]
+                    mm = tens[11][sl] if has_m else None
+                    R = caw1c.shape[0]
+                    shift, dmv = go["shift"][sl], go["dmv"][sl] if has_m else None
+                if not has_ca:
+                    pass
+                elif bheads:  # the per-sample part of the gate backward is computed by the conv that consumes `shift` (gate head)
                     bhead = hip.CaTail()
                     bhead.backward, bhead.hidden, bhead.inv_hw, bhead.head, bhead.head_parts = 1, R, 1.0 / hw, 1, parts
                     bhead.w1, bhead.w2, bhead.hid, bhead.ca, bhead.mul = (hip.ptr(caw1c), hip.ptr(caw2c), hip.ptr(hid[sl]),
@@ -1450,7 +1484,7 @@ class _GatedGroup(Function):
             def wgrad2(k, dy, go):
                 """Weight gradient of block k's second conv, from (t1, the gated gradient dy * g + shift rebuilt while staging)."""
                 tens = blocks[k][0]
-                w2, t1, g = tens[2], tens[3], tens[10]
+                w2, t1, g = tens[2], tens[3], tens[10] if has_ca else tens[6]
                 dw2, db2 = _grad_buf(w2), _grad_buf_or(ctx.small[k][1], 64, dev)
                 shift = go["shift"]
                 if queue is not None:
@@ -1463,11 +1497,12 @@ class _GatedGroup(Function):
             def wgrad1(k, go, bufs):
                 """Weight gradient of block k's first conv, from (the block's input, dt1); the block's small gradients."""
                 tens, has_m = blocks[k][0], blocks[k][1]
-                xk, w1, caw1c, s, hid = tens[0], tens[1], tens[5], tens[7], tens[8]
+                xk, w1 = tens[0], tens[1]
+                caw1c, s, hid = (tens[5], tens[7], tens[8]) if has_ca else (None, None, None)
                 dw1, db1 = _grad_buf(w1), _grad_buf_or(ctx.small[k][0], 64, dev)
                 dt1 = bufs["dt1"]
                 if queue is not None:
-                    if not tails:
+                    if not tails and has_ca:
                         gate_jobs.append((go["dzw"], hid, s, go["dcaw1"], go["dcab1"], go["dcaw2"], go["dcab2"], caw1c.shape[0]))
                     queue.add(xk, dt1, dw1, db1)
                 else:
@@ -1538,17 +1573,18 @@ class _GatedGroup(Function):
                         arr[k].dw1, arr[k].db1, arr[k].dw2, arr[k].db2 = hip.ptr(a1), hip.ptr(c1), hip.ptr(a2), hip.ptr(c2)
                     hip.check(L.sisr_ca_gate_bwd_params_batch(ctypes.addressof(arr), len(chunk), B, chunk[0][7], hip.stream()),
                               "sisr_ca_gate_bwd_params_batch")
-            return (dx, None, *grads, dwt, dbt)
+            return (dx, None, None, *grads, dwt, dbt)
         finally:
             IN_BACKWARD = False
 
 
-def gated_group(x, blocks, tail_w, tail_b):
-    """blocks: list of (w1, b1, w2, b2, (caw1, cab1, caw2, cab2), m or None); see _GatedGroup."""
+def gated_group(x, blocks, tail_w, tail_b, alpha=1.0):
+    """blocks: list of (w1, b1, w2, b2, (caw1, cab1, caw2, cab2) or None, m or None); alpha: scale of every block's second conv
+    (res_scale); see _GatedGroup."""
     flat = []
     for w1, b1, w2, b2, ca, m in blocks:
-        flat += [w1, b1, w2, b2, *ca, m]
-    return _GatedGroup.apply(x, len(blocks), *flat, tail_w, tail_b)
+        flat += [w1, b1, w2, b2, *(ca if ca is not None else (None,) * 4), m]
+    return _GatedGroup.apply(x, len(blocks), float(alpha), *flat, tail_w, tail_b)
 
 
 def fused_groups_enabled():

@@ -137,12 +137,15 @@ def test_conv_gate_prologue_and_dot_epilogue(B, H, W):
         close(gap.sum(dim=1), (want * dot).sum(dim=(2, 3)), 2e-4, 2e-5, "dot partials")
 
 
-@pytest.mark.parametrize("meta", [False, True])
+@pytest.mark.parametrize("meta", [False, True, "qedsr"])
 def test_fused_group_node_matches_per_block_nodes(meta):
     """ops._GatedGroup (one autograd node per residual group, gate passes folded into the neighbouring convs) against
-    the per-block nodes it replaces: same outputs and gradients to fp32 reduction-order tolerance."""
+    the per-block nodes it replaces: same outputs and gradients to fp32 reduction-order tolerance.  'qedsr': the node without
+    channel attention (gate = the meta-attention vector, res_scale in conv2's epilogue) for the whole QEDSR body."""
     torch.manual_seed(8)
-    if meta:
+    if meta == "qedsr":
+        net = A.QEDSR(num_features=64, input_para=10, num_blocks=5, scale=2, res_scale=0.1).to(DEV)
+    elif meta:
         net = A.QRCAN(n_resblocks=3, n_resgroups=2, n_feats=64, scale=2, style="standard", num_metadata=10,
                       include_q_layer=True, num_q_layers_inner_residual=2).to(DEV)
     else:
