@@ -431,6 +431,24 @@ int sisr_pil_resample(const unsigned char* in, void* out, const int* bounds, con
  *   workspace: sisr_bn_workspace_bytes(npix, C) for both.
  * sisr_spar_combine_fwd: y = identity (nullable) + x * a, a = sigmoid(logits[p][0]) (logits NHWC with C_logits channels),
  *   att[p] = a.  _bwd: dx = dy * a; dlogits[p][0] = (sum_c dy x) a (1 - a), the other channels of dlogits zero. */
+/* The stride-1 ConvLayer conv WITHOUT the gathers (round 4): reflection and nearest upsampling as address arithmetic in the
+ * MFMA kernels' staging (csrc/conv3x3_mfma.hip template GEO, csrc/wgrad3x3_mfma.hip GEO bodies).
+ * sisr_conv3x3_c64_geo  mode 1: y (B,H,W,cout) = Conv2d(3x3, no padding)(ReflectionPad2d(1)(nearest_up^up(x))) + bias,
+ *     x (B, H >> up, W >> up, cin), up 0 | 1 (a SHIFT: 1 = nearest x2);
+ *   mode 2: y (B,H,W,cout) = zero-padded 3x3 conv of x (B,H-2,W-2,cin) placed at (1,1) of an H x W zero map -- with the
+ *     input-gradient packing of the weight, the gradient of mode 1's padded map; sisr_pad_reflect_up(adjoint) folds it back.
+ *   wpacked as for sisr_conv3x3_c64; gap_partial (nullable): per-strip channel sums of y in sisr_conv3x3_c64's layout;
+ *   kreal > 0 (cin == 64 only): the caller's promise that input channels >= kreal are zero (<= 8 / <= 32 run 1 / 4 of the 8
+ *   channel octets per tap).  Results equal the gather -> sisr_conv3x3_c64 -> gather composition bit for bit.
+ * sisr_wgrad3x3_c64_geo: dw (co_real, ci_real, 3, 3) and db (co_real, nullable) of mode 1 from x (B, H >> up, W >> up, cin) and
+ *   dy (B,H,W,cout); workspace: sisr_wgrad3x3_c64_workspace_bytes(B, H, W, cin, cout); active_units as in sisr_wgrad3x3_c64
+ *   (blocks that hold only channel padding may be masked; bias halves >= co_real need no unit). */
+int sisr_conv3x3_c64_geo(const float* x, const int64_t* xview, const float* wpacked, const float* bias, float* y,
+                         const int64_t* yview, float* gap_partial, int B, int H, int W, int cin, int cout, int mode, int up,
+                         int kreal, void* stream);
+int sisr_wgrad3x3_c64_geo(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview, float* dw, int co_real,
+                          int ci_real, float* dbias, float* workspace, size_t workspace_bytes, int B, int H, int W, int cin,
+                          int cout, int up, unsigned long long active_units, void* stream);
 /* sisr_nearest_up: nn.Upsample(scale_factor = up, 'nearest') on an NHWC map, up 1 .. 4 (ref: advanced/SRMD_blocks.py:58-63, the
  * 'upconv' tail of SRMD); adjoint != 0: the gradient summed back over the up x up replicas. */
 int sisr_nearest_up(const float* src, float* dst, int B, int H, int W, int C, int up, int adjoint, void* stream);

@@ -89,6 +89,13 @@ struct ConvParams {
   // blocks above carry the operands (fwd_tail: HEAD 1, bwd_tail: HEAD 2; counters and parameter-gradient fields unused).
   const float* head_part;  // [B][head_parts][64]
   int head_parts;
+  // Generalised input geometry (template GEO of conv3x3_c64_v4_kernel; all zero elsewhere).  Output pixel (h, w) of the H x W
+  // output reads the VIRTUAL input map of geo_h x geo_w pixels at (h + kh - 1 - geo_off, w + kw - 1 - geo_off):
+  //   geo_reflect: coordinates outside the virtual map are reflected (-1 -> 1, n -> n - 2: ReflectionPad2d(1)) instead of
+  //                reading zeros;  geo_up: the stored map is the virtual one subsampled by 2^geo_up (nearest upsampling read
+  //                in place: stored pixel = virtual >> geo_up);  geo_off = 1 with geo_h = H - 2: the transposed ("full")
+  //                form, an input-gradient map two pixels larger than the gradient it is computed from.
+  int geo_reflect, geo_up, geo_off, geo_h, geo_w;
 #ifdef SISR_DIAG
   unsigned* stamp;  // diagnostic library only: per wave {start lo, start hi, staging, K loop, epilogue, HW_ID, XCC_ID, 0}
 #endif
@@ -316,7 +323,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
 // its own sample; all write the same s / hid / ca / g); 2 = with AFFINE + MASK, the GAP-backward shift is computed here from
 // the previous conv's DOT partial sums (ca_gate_bwd_sample).  Same device functions as the stand-alone gate kernels.
 #define SISR_HEAD_LDS 256  // bytes behind the halo in the launches with a gate head: the 64 gate / shift values of the sample
-template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false, bool LEAKY = false, int KSEL = 0, int HEAD = 0>
+// GEO (SPARNet's ConvLayers, ref SPARNet/blocks.py:69-103: [nearest x2] -> ReflectionPad2d(1) -> Conv2d(3x3)): the halo is
+// staged through the coordinate map of ConvParams::geo_* -- reflection and nearest upsampling are address arithmetic on the
+// scalar row offsets and the three per-lane column offsets, so the padded / upsampled map is never materialised and no ring of
+// throw-away outputs is computed; with geo_off the same kernel produces the (H + 2) x (W + 2) transposed-conv result from an
+// H x W gradient.  KSEL 4 / 5 (one input chunk whose channels >= 32 / >= 8 are zero padding: 32-feature layers, RGB and
+// attention-logit ends): 4 / 1 of the 8 octets per tap.
+template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false, bool LEAKY = false, int KSEL = 0, int HEAD = 0,
+          bool GEO = false>
 __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_WGS : 4) : 3)) void conv3x3_c64_v4_kernel(ConvParams p) {
   constexpr int THv = 2 * MT, HHv = THv + 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -435,21 +449,30 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
       }
       unsigned goff[3], loff[3];
       bool cok[3];
+      // GEO: virtual input size, origin shift, reflection and subsampling of the stored map (all scalar)
+      const int Hv = GEO ? p.geo_h : H, Wv = GEO ? p.geo_w : W, goffs = GEO ? p.geo_off : 0;
+      const bool refl = GEO && p.geo_reflect;
+      const int gup = GEO ? p.geo_up : 0;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int col = pcol + 16 * k;
-        const int gw = w0 - 1 + col;
-        cok[k] = gw >= 0 && gw < W && col < HALO_W;
-        goff[k] = (unsigned)(min(max(gw, 0), W - 1) * (int)p.xv.sW + c4 * 4) * 4u;  // bytes
+        int gw = w0 - 1 + col - goffs;
+        cok[k] = (refl || (gw >= 0 && gw < Wv)) && col < HALO_W;
+        if (refl) gw = gw < 0 ? -gw : (gw >= Wv ? 2 * Wv - 2 - gw : gw);
+        goff[k] = (unsigned)((min(max(gw, 0), Wv - 1) >> gup) * (int)p.xv.sW + c4 * 4) * 4u;  // bytes
         loff[k] = col * 64 + ((c4 ^ (col & 15)) << 2);
       }
       // a tile whose halo lies inside the image needs no zero padding: its staging stores skip the masking (4 VALU per piece)
-      const bool interior = h0 >= 1 && h0 + THv + 1 <= H && w0 >= 1 && w0 + TW + 1 <= W;  // scalar
+      const bool interior = refl || (h0 - goffs >= 1 && h0 - goffs + THv + 1 <= Hv && w0 - goffs >= 1 && w0 - goffs + TW + 1 <= Wv);  // scalar
+      auto row_bytes = [&](int gh) -> unsigned {  // scalar: byte offset of the stored row behind (shifted) halo row gh
+        if (refl) gh = gh < 0 ? -gh : (gh >= Hv ? 2 * Hv - 2 - gh : gh);
+        return (unsigned)((min(max(gh, 0), Hv - 1) >> gup) * (int)p.xv.sH) * 4u;
+      };
       if (!GATE) {
         f32x4 v[HHv][3];
 #pragma unroll
         for (int r = 0; r < HHv; ++r) {
-          const unsigned ro = (unsigned)(min(max(h0 - 1 + r, 0), H - 1) * (int)p.xv.sH) * 4u;  // scalar, bytes
+          const unsigned ro = row_bytes(h0 - 1 + r - goffs);  // scalar, bytes
 #pragma unroll
           for (int k = 0; k < 3; ++k)
             if (k < 2 || pcol < 2) v[r][k] = sisr_buf_load4(rx, goff[k], ro);
@@ -467,8 +490,8 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
         } else {
 #pragma unroll
           for (int r = 0; r < HHv; ++r) {
-            const int gh = h0 - 1 + r;
-            const bool rok = gh >= 0 && gh < H;  // scalar
+            const int gh = h0 - 1 + r - goffs;
+            const bool rok = gh >= 0 && gh < Hv;  // scalar
 #pragma unroll
             for (int k = 0; k < 3; ++k)
               if (k < 2 || pcol < 2) {
@@ -566,6 +589,10 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
       };
       if constexpr (KSEL == 1) {
         kloop(std::integral_constant<int, 4>{}, wq + (long)q * (4 * 512));
+      } else if constexpr (KSEL == 4) {
+        kloop(std::integral_constant<int, 4>{}, wq);
+      } else if constexpr (KSEL == 5) {
+        kloop(std::integral_constant<int, 1>{}, wq);
       } else if constexpr (KSEL == 3) {
         kloop(std::integral_constant<int, 8>{}, p.w + ((long)q * p.cin_chunks + ch) * (9 * 64 * 64));
       } else {
@@ -2626,6 +2653,71 @@ extern "C" int sisr_conv3x3_c64(const float* x, const int64_t* xview, const floa
   else
 #endif
     hipLaunchKernelGGL(conv3x3_c64_kernel<0>, grid, dim3(256), lb, (hipStream_t)stream, p);
+  return sisr_check_launch();
+}
+
+// SPARNet's ConvLayer convs on the issue-lean kernel's GEO form (see conv3x3_c64_v4_kernel): plain bias epilogue [+ per-strip
+// channel sums of the output in `gap_partial`, the layout of sisr_conv3x3_c64's].
+//   mode 1  y[B][H][W][cout] = Conv2d(3x3, no padding)(ReflectionPad2d(1)(nearest-upsample^up(x))), x: [B][H >> up][W >> up][cin]
+//   mode 2  y[B][H][W][cout] = the zero-padded 3x3 conv of x: [B][H - 2][W - 2][cin] placed at offset (1, 1) of an H x W zero
+//           map: with the flipped / role-swapped packed weight, the input gradient of mode 1's valid conv before the
+//           reflection is folded back
+// kreal: the caller's promise that input channels >= kreal are zero (cin == 64 only): 8 / 32 select the 1- / 4-octet K loops.
+extern "C" int sisr_conv3x3_c64_geo(const float* x, const int64_t* xview, const float* wpacked, const float* bias, float* y,
+                                    const int64_t* yview, float* gap_partial, int B, int H, int W, int cin, int cout, int mode,
+                                    int up, int kreal, void* stream) {
+  if (!x || !wpacked || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
+  if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
+  if (mode != 1 && mode != 2) return SISR_ERR_ARG;
+  if (up < 0 || up > 1 || (mode == 2 && up) || kreal < 0) return SISR_ERR_UNSUPPORTED;
+  if (mode == 1 && (H < 2 || W < 2 || ((H | W) & ((1 << up) - 1)))) return SISR_ERR_ARG;  // ReflectionPad2d(1) needs 2 pixels
+  if (mode == 2 && (H < 3 || W < 3)) return SISR_ERR_ARG;
+  if (!sisr_aligned16(x) || !sisr_aligned16(wpacked) || !sisr_aligned16(y)) return SISR_ERR_ALIGN;
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+#ifdef SISR_DIAG
+  p.stamp = nullptr;
+#endif
+  p.x = x;
+  p.xv = view_from(xview);
+  p.y = y;
+  p.yv = view_from(yview);
+  if ((p.xv.sB | p.xv.sH | p.xv.sW | p.xv.chi | p.xv.clo) & 3) return SISR_ERR_ALIGN;
+  p.w = wpacked;
+  p.bias = bias;
+  p.gap = gap_partial;
+  p.alpha = 1.f;
+  p.bias_n = 1;
+  p.bias_q = 64;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.cin_chunks = cin / 64;
+  p.cout_chunks = cout / 64;
+  p.geo_reflect = mode == 1;
+  p.geo_up = up;
+  p.geo_off = mode == 2;
+  p.geo_h = mode == 2 ? H - 2 : H;
+  p.geo_w = mode == 2 ? W - 2 : W;
+  p.tiles_w = (W + TW - 1) / TW;
+  p.tiles_h = (H + TH - 1) / TH;
+  const long nblk = (long)p.tiles_w * p.tiles_h * B;
+  if (nblk > 0x7fffffffL) return SISR_ERR_ARG;
+  const int ksel = (cin == 64 && kreal > 0 && kreal <= 8) ? 5 : ((cin == 64 && kreal > 0 && kreal <= 32) ? 4 : 0);
+  const bool small = nblk * p.cout_chunks < SMALL_GRID_BLOCKS;
+  dim3 g((unsigned)nblk, p.cout_chunks);
+  size_t lb = HALO_H * HALO_W * 64 * sizeof(float);
+  if (small) {
+    p.tiles_h = (H + 1) / 2;
+    g = dim3((unsigned)((long)p.tiles_w * p.tiles_h * B), p.cout_chunks);
+    lb = 4 * HALO_W * 64 * sizeof(float);
+  }
+  hipStream_t st = (hipStream_t)stream;
+#define V4G(MTV, KS) hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, MTV, false, false, false, KS, 0, true>), g, dim3(256), lb, st, p)
+  if (ksel == 5) { if (small) V4G(1, 5); else V4G(2, 5); }
+  else if (ksel == 4) { if (small) V4G(1, 4); else V4G(2, 4); }
+  else { if (small) V4G(1, 0); else V4G(2, 0); }
+#undef V4G
   return sisr_check_launch();
 }
 

@@ -48,8 +48,12 @@ struct WgradParams {
   int mapped;
   unsigned char unit_map[WG_MAX_UNITS];
   unsigned long long bias_units;  // bit blockIdx.y: this workgroup row also sums dY for the bias gradient
+  // GEO kernels (SPARNet's ConvLayers): x is read through ReflectionPad2d(1) of the H x W map (geo_reflect: -1 -> 1, n -> n - 2
+  // instead of zeros) which is stored subsampled by 2^geo_up (nearest upsampling read in place)
+  int geo_reflect, geo_up;
 };
 
+template <bool GEO = false>
 static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ldx = lds;
@@ -90,7 +94,13 @@ static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
       const float* xb = p.x + (long)b * p.xv.sB + p.xv.chunk(cc) + cih * 32;
       const float* yb = p.dy + (long)b * p.yv.sB + p.yv.chunk(cq) + coh * 32;
       const bool okc = w0 + pcol < W;
-      const unsigned gx = (unsigned)(min(w0 + pcol, W - 1) * (int)p.xv.sW + c4 * 4), lx = (pcol + 1) * WSTR + c4 * 4;
+      const bool refl = GEO && p.geo_reflect;  // scalar
+      const int gup = GEO ? p.geo_up : 0;
+      auto xpix = [&](int g, int n) {  // stored row / column behind virtual coordinate g of an n-pixel axis
+        if (refl) g = g < 0 ? -g : (g >= n ? 2 * n - 2 - g : g);
+        return min(max(g, 0), n - 1) >> gup;
+      };
+      const unsigned gx = (unsigned)(xpix(w0 + pcol, W) * (int)p.xv.sW + c4 * 4), lx = (pcol + 1) * WSTR + c4 * 4;
       const unsigned gy = (unsigned)(min(w0 + pcol, W - 1) * (int)p.yv.sW + c4 * 4), ly = pcol * WSTR + c4 * 4;
       f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
       if (p.dy_scale) s4 = *reinterpret_cast<const f32x4*>(p.dy_scale + (long)b * Cout + cq * 64 + coh * 32 + c4 * 4);
@@ -106,23 +116,24 @@ static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
         f32x4 v[5], u[4], e;
 #pragma unroll
         for (int r = 0; r < 5; ++r)
-          v[r] = *reinterpret_cast<const f32x4*>(xb + (long)min(max(h0 - 1 + 5 * half + r, 0), H - 1) * p.xv.sH + gx);
+          v[r] = *reinterpret_cast<const f32x4*>(xb + (long)xpix(h0 - 1 + 5 * half + r, H) * p.xv.sH + gx);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           u[r] = *reinterpret_cast<const f32x4*>(yb + (long)min(h0 + 4 * half + r, H - 1) * p.yv.sH + gy);
         const int gwe = eside ? w0 + WT_W : w0 - 1;
         if (half == 0)
-          e = *reinterpret_cast<const f32x4*>(xb + (long)min(max(h0 - 1 + er, 0), H - 1) * p.xv.sH +
-                                              min(max(gwe, 0), W - 1) * (int)p.xv.sW + ec4 * 4);
+          e = *reinterpret_cast<const f32x4*>(xb + (long)xpix(h0 - 1 + er, H) * p.xv.sH + xpix(gwe, W) * (int)p.xv.sW + ec4 * 4);
         if (affine) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) u[r] = u[r] * s4 + t4;
         }
         if (!interior) {
+          if (!refl) {  // reflected reads are values of the map; what pairs with pixels outside it is zeroed with dY below
 #pragma unroll
-          for (int r = 0; r < 5; ++r) {
-            const int gh = h0 - 1 + 5 * half + r;
-            v[r] = sisr_keep_if(v[r], gh >= 0 && gh < H && okc);
+            for (int r = 0; r < 5; ++r) {
+              const int gh = h0 - 1 + 5 * half + r;
+              v[r] = sisr_keep_if(v[r], gh >= 0 && gh < H && okc);
+            }
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) u[r] = sisr_keep_if(u[r], okc && (h0 + 4 * half + r < H));
@@ -137,7 +148,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
         }
         if (half == 0) {
           const int ghe = h0 - 1 + er;
-          if (!interior) e = sisr_keep_if(e, ghe >= 0 && ghe < H && gwe >= 0 && gwe < W);
+          if (!interior && !refl) e = sisr_keep_if(e, ghe >= 0 && ghe < H && gwe >= 0 && gwe < W);
           if (tl < 160) *reinterpret_cast<f32x4*>(ldx + er * (WH_W * WSTR) + (eside ? WH_W - 1 : 0) * WSTR + ec4 * 4) = e;
         }
       }
@@ -202,6 +213,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
 }
 
 __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(WgradParams p) { wgrad3x3_c64_body(p); }
+__global__ __launch_bounds__(256, 2) void wgrad3x3_c64_geo_kernel(WgradParams p) { wgrad3x3_c64_body<true>(p); }
 
 // Several weight gradients of one geometry in ONE launch (blockIdx.z = job).  At a few tiles per GPU a single gradient has
 // two tiles per workgroup: slab epilogue, ramp and drain are as long as the work.  Eight of them share the 512 resident
@@ -230,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_batch_kernel(WgradBatch b
 #define FW_X (WH_H * WH_W * 64)  // floats
 #define FW_Y (WT_H * WT_W * 64)
 
+template <bool GEO = false>
 static __device__ __forceinline__ void wgrad3x3_c64_full_body(const WgradParams& p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ldx = lds;
@@ -274,22 +287,28 @@ static __device__ __forceinline__ void wgrad3x3_c64_full_body(const WgradParams&
     h0 = th * WT_H;
     w0 = (tr - th * p.tiles_w) * WT_W;
   };
+  const bool refl = GEO && p.geo_reflect;  // scalar
+  const int gup = GEO ? p.geo_up : 0;
+  auto xpix = [&](int g, int n) {  // stored row / column behind virtual coordinate g of an n-pixel axis
+    if (refl) g = g < 0 ? -g : (g >= n ? 2 * n - 2 - g : g);
+    return min(max(g, 0), n - 1) >> gup;
+  };
   auto issue = [&](int tile) {
     int b, h0, w0;
     decode(tile, b, h0, w0);
     const sisr_rsrc_t rx = sisr_rsrc(p.x + (long)b * p.xv.sB + p.xv.chunk(cc));
     const sisr_rsrc_t ry = sisr_rsrc(p.dy + (long)b * p.yv.sB + p.yv.chunk(cq));
-    const unsigned vx = (unsigned)(min(w0 + pcol, W - 1) * (int)p.xv.sW + c8 * 8) * 4u;
+    const unsigned vx = (unsigned)(xpix(w0 + pcol, W) * (int)p.xv.sW + c8 * 8) * 4u;
     const unsigned vy = (unsigned)(min(w0 + pcol, W - 1) * (int)p.yv.sW + c8 * 8) * 4u;
 #pragma unroll
     for (int r = 0; r < WH_H; ++r) {
-      const unsigned so = (unsigned)(min(max(h0 - 1 + r, 0), H - 1) * (int)p.xv.sH) * 4u;  // scalar
+      const unsigned so = (unsigned)(xpix(h0 - 1 + r, H) * (int)p.xv.sH) * 4u;  // scalar
       st.x[r][0] = sisr_buf_load4(rx, vx, so);
       st.x[r][1] = sisr_buf_load4(rx, vx + 16u, so);
     }
     {
-      const int gwe = min(max(eside ? w0 + WT_W : w0 - 1, 0), W - 1);
-      const unsigned ve = (unsigned)(min(max(h0 - 1 + er, 0), H - 1) * (int)p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8) * 4u;
+      const int gwe = xpix(eside ? w0 + WT_W : w0 - 1, W);
+      const unsigned ve = (unsigned)(xpix(h0 - 1 + er, H) * (int)p.xv.sH + gwe * (int)p.xv.sW + ec8 * 8) * 4u;
       st.xe[0] = sisr_buf_load4(rx, ve, 0u);
       st.xe[1] = sisr_buf_load4(rx, ve + 16u, 0u);
     }
@@ -306,7 +325,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_full_body(const WgradParams&
     const bool interior = h0 >= 1 && h0 + WT_H + 1 <= H && w0 >= 1 && w0 + WT_W + 1 <= W;  // scalar
     const bool okc = w0 + pcol < W;
     float* lx = ldx + (pcol + 1) * 64 + c8 * 8;
-    if (!interior) {
+    if (!interior && !refl) {  // (reflected reads are values of the map; what pairs with pixels outside it is zeroed with dY)
 #pragma unroll
       for (int r = 0; r < WH_H; ++r) {
         const int gh = h0 - 1 + r;
@@ -447,6 +466,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_full_body(const WgradParams&
 
 __global__ __launch_bounds__(256, 1) void wgrad3x3_c64_full_kernel(WgradParams p) { wgrad3x3_c64_full_body(p); }
 __global__ __launch_bounds__(256, 1) void wgrad3x3_c64_full_batch_kernel(WgradBatch bt) { wgrad3x3_c64_full_body(bt.job[blockIdx.z]); }
+__global__ __launch_bounds__(256, 1) void wgrad3x3_c64_full_geo_kernel(WgradParams p) { wgrad3x3_c64_full_body<true>(p); }
 
 // ------------------------------------------------------------------ bf16 matrix-core weight gradient
 // Operands rounded to bf16 (RNE) as they are staged into LDS, products exact, fp32 accumulation; the bias
@@ -975,6 +995,8 @@ struct ReduceParams {
   int S, units, cin_chunks, cout_chunks, flip, on, oq, in_, iq, bias_n, bias_q;
   int mapped;                             // != 0: slab row r holds unit unit_map[r] (launch with an active-unit mask)
   unsigned char unit_map[WG_MAX_UNITS];
+  int o_lim, i_lim;                       // > 0: dW has only that many output / input channels (the rest of a 64-chunk is
+                                          // zero padding of the caller's maps and is not written)
 };
 
 // blockDim = (64, RG): x = a run of FOUR consecutive elements (one 16-byte load per slab; 256 elements per workgroup), y = slab
@@ -1025,11 +1047,14 @@ static __device__ __forceinline__ void wgrad_reduce_body(const ReduceParams& p) 
       const int co = (quad & 1) * 32 + (l & 31);
       const long o = (long)co * p.on + (long)cq * p.oq;
       const long ii = (long)ci * p.in_ + (long)cc * p.iq;
+      if ((p.o_lim > 0 && o >= p.o_lim) || (p.i_lim > 0 && ii >= p.i_lim)) continue;
       p.dw[o * p.so + ii * p.si + (p.flip ? 8 - t : t)] = s[e4] * p.alpha;
     } else if (is_b) {
       const long je = j + e4;
       const int cq = (int)(je >> 6), co = (int)(je & 63);
-      p.db[(long)co * p.bias_n + (long)cq * p.bias_q] = s[e4] * p.alpha;
+      const long ob = (long)co * p.bias_n + (long)cq * p.bias_q;
+      if (p.o_lim > 0 && ob >= p.o_lim) continue;
+      p.db[ob] = s[e4] * p.alpha;
     }
   }
 }
@@ -1083,12 +1108,44 @@ extern "C" size_t sisr_wgrad3x3_c64_workspace_bytes(int B, int H, int W, int cin
   return (slabs * SLAB + (size_t)512 * cout) * sizeof(float);
 }
 
+static int wgrad_fp32_launch(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
+                             const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so,
+                             int64_t si, int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n,
+                             int in_perm_q, float* dbias, int bias_n, int bias_q, float* workspace,
+                             size_t workspace_bytes, int B, int H, int W, int cin, int cout,
+                             unsigned long long active_units, int geo, int geo_up, int o_lim, int i_lim, void* stream);
+
 extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
                                  const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so,
                                  int64_t si, int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n,
                                  int in_perm_q, float* dbias, int bias_n, int bias_q, float* workspace,
                                  size_t workspace_bytes, int B, int H, int W, int cin, int cout,
                                  unsigned long long active_units, void* stream) {
+  return wgrad_fp32_launch(x, xview, dy, dyview, dy_scale, dy_shift, alpha, dw, so, si, flip_taps, out_perm_n, out_perm_q,
+                           in_perm_n, in_perm_q, dbias, bias_n, bias_q, workspace, workspace_bytes, B, H, W, cin, cout,
+                           active_units, 0, 0, 0, 0, stream);
+}
+
+// Weight gradient of SPARNet's ConvLayer conv (see sisr_conv3x3_c64_geo mode 1): x [B][H >> up][W >> up][cin] read through
+// nearest upsampling and ReflectionPad2d(1), dy [B][H][W][cout]; dw [co_real][ci_real][3][3] plain OIHW (so = ci_real * 9,
+// si = 9), rows / columns >= co_real / ci_real of the 64-chunks are not written; db [co_real] or null.  active_units as in
+// sisr_wgrad3x3_c64 (a caller whose maps carry zero-padded channels masks the 32 x 32 blocks that only hold padding).
+extern "C" int sisr_wgrad3x3_c64_geo(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview, float* dw,
+                                     int co_real, int ci_real, float* dbias, float* workspace, size_t workspace_bytes, int B, int H,
+                                     int W, int cin, int cout, int up, unsigned long long active_units, void* stream) {
+  if (co_real <= 0 || ci_real <= 0 || co_real > cout || ci_real > cin || up < 0 || up > 1 || H < 2 || W < 2 ||
+      ((H | W) & ((1 << up) - 1)))
+    return SISR_ERR_ARG;
+  return wgrad_fp32_launch(x, xview, dy, dyview, nullptr, nullptr, 1.f, dw, (int64_t)ci_real * 9, 9, 0, 1, 64, 1, 64, dbias, 1, 64,
+                           workspace, workspace_bytes, B, H, W, cin, cout, active_units, 1, up, co_real, ci_real, stream);
+}
+
+static int wgrad_fp32_launch(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview,
+                             const float* dy_scale, const float* dy_shift, float alpha, float* dw, int64_t so,
+                             int64_t si, int flip_taps, int out_perm_n, int out_perm_q, int in_perm_n,
+                             int in_perm_q, float* dbias, int bias_n, int bias_q, float* workspace,
+                             size_t workspace_bytes, int B, int H, int W, int cin, int cout,
+                             unsigned long long active_units, int geo, int geo_up, int o_lim, int i_lim, void* stream) {
   if (!x || !dy || !dw || !xview || !dyview || !workspace || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
   if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
   if (workspace_bytes < sisr_wgrad3x3_c64_workspace_bytes(B, H, W, cin, cout)) return SISR_ERR_ARG;
@@ -1111,12 +1168,14 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   p.cout_chunks = cout / 64;
   p.tiles_w = (W + WT_W - 1) / WT_W;
   p.tiles_h = (H + WT_H - 1) / WT_H;
+  p.geo_reflect = geo;
+  p.geo_up = geo_up;
   // Units = (cin chunk, cout chunk, ci half, co half) blocks of the gradient, bit ((cc * cout_chunks + cq) * 4 + cih * 2 + coh)
   // of active_units (0 = all).  A caller whose weight is structurally sparse (SFTMD's merged convs) masks the blocks it
   // never reads: they are neither computed nor written, and the K-slices of the launch go to the rest.
   const int all_units = p.cin_chunks * p.cout_chunks * 4;
   if (active_units && all_units > WG_MAX_UNITS) return SISR_ERR_UNSUPPORTED;
-  ReduceParams r;
+  ReduceParams r = {};
   int units = all_units;
   p.bias_units = 0;
   if (active_units) {
@@ -1133,7 +1192,9 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
       ++units;
     }
     if (units == 0 || (all_units < 64 && (active_units >> all_units) != 0)) return SISR_ERR_ARG;
-    if (dbias && seen_bias != (1u << (p.cout_chunks * 2)) - 1) return SISR_ERR_ARG;  // a bias half nobody would sum
+    unsigned need_bias = (1u << (p.cout_chunks * 2)) - 1;  // every (cout chunk, co half) ...
+    if (o_lim > 0) need_bias = (1u << ((o_lim + 31) / 32)) - 1;  // ... that holds channels the caller reads
+    if (dbias && (seen_bias & need_bias) != need_bias) return SISR_ERR_ARG;  // a bias half nobody would sum
   }
   p.mapped = active_units != 0;
   r.mapped = active_units != 0;
@@ -1147,12 +1208,22 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   p.bias_slabs = dbias ? workspace + (size_t)p.S * units * SLAB : nullptr;
   if (dense) {  // one persistent workgroup per CU owning all four quadrants of its chunk pair
     const size_t lds_full = (size_t)(FW_X + FW_Y) * sizeof(float);
-    SISR_ALLOW_LDS(wgrad3x3_c64_full_kernel, lds_full);
-    hipLaunchKernelGGL(wgrad3x3_c64_full_kernel, dim3(p.S, units / 4), dim3(256), lds_full, (hipStream_t)stream, p);
+    if (geo) {
+      SISR_ALLOW_LDS(wgrad3x3_c64_full_geo_kernel, lds_full);
+      hipLaunchKernelGGL(wgrad3x3_c64_full_geo_kernel, dim3(p.S, units / 4), dim3(256), lds_full, (hipStream_t)stream, p);
+    } else {
+      SISR_ALLOW_LDS(wgrad3x3_c64_full_kernel, lds_full);
+      hipLaunchKernelGGL(wgrad3x3_c64_full_kernel, dim3(p.S, units / 4), dim3(256), lds_full, (hipStream_t)stream, p);
+    }
   } else {
     const size_t lds_bytes = (size_t)(LDS_X + LDS_Y) * sizeof(float);
-    SISR_ALLOW_LDS(wgrad3x3_c64_kernel, lds_bytes);
-    hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(p.S, units), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    if (geo) {
+      SISR_ALLOW_LDS(wgrad3x3_c64_geo_kernel, lds_bytes);
+      hipLaunchKernelGGL(wgrad3x3_c64_geo_kernel, dim3(p.S, units), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    } else {
+      SISR_ALLOW_LDS(wgrad3x3_c64_kernel, lds_bytes);
+      hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(p.S, units), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    }
   }
   int rc = sisr_check_launch();
   if (rc) return rc;
@@ -1174,6 +1245,8 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
   r.iq = in_perm_q;
   r.bias_n = bias_n;
   r.bias_q = bias_q;
+  r.o_lim = o_lim;
+  r.i_lim = i_lim;
   const long total = (long)units * SLAB + (dbias ? cout : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(64, RG), 0, (hipStream_t)stream, r);
   return sisr_check_launch();
@@ -1338,7 +1411,7 @@ static int wgrad3x3_c64_bf16_launch(const float* x, const int64_t* xview, const 
   }
   int rc = sisr_check_launch();
   if (rc) return rc;
-  ReduceParams r;
+  ReduceParams r = {};
   r.mapped = 0;
   r.slabs = p.slabs;
   r.bias_slabs = p.bias_slabs;
@@ -1439,7 +1512,7 @@ extern "C" int sisr_wgrad3x3_c64_x3(const float* x, const int64_t* xview, const 
   hipLaunchKernelGGL(wgrad3x3_c64_x3_kernel, dim3(p.S, pairs), dim3(256), lds_bytes, (hipStream_t)stream, p);
   int rc = sisr_check_launch();
   if (rc) return rc;
-  ReduceParams r;
+  ReduceParams r = {};
   r.mapped = 0;
   r.slabs = p.slabs;
   r.bias_slabs = p.bias_slabs;

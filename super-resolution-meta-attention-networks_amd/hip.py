@@ -137,6 +137,9 @@ _SIGS.update({  # around the non-local attention (csrc/nonlocal.hip)
 _SIGS.update({  # SPARNet pieces (csrc/sparnet.hip)
     "sisr_bn_workspace_bytes": (c_size_t, [c_long, c_int]),
     "sisr_nearest_up": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sisr_conv3x3_c64_geo": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "sisr_wgrad3x3_c64_geo": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      ctypes.c_uint64, P]),
     "sisr_pad_reflect_up": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_crop_stride": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_bn_act_fwd": (c_int, [P] * 8 + [c_long, c_int, c_int, c_int, c_float, c_float, c_float, P, c_size_t, P]),

@@ -1849,6 +1849,11 @@ def nchw_to_nhwc_pad(x, cp=None):
 
 
 # ----------------------------------------------------------------------------- SPARNet pieces (csrc/sparnet.hip)
+# SPARNet's stride-1 ConvLayer convs with reflection / nearest upsampling inside the MFMA kernels' staging (0: the gather ->
+# conv -> gather composition of round 3, kept for the stride-2 convs and as the A/B reference; results are bit-identical)
+REFL_GEO = os.environ.get("SISR_REFL_GEO", "1") != "0"
+
+
 class _ReflConv(Function):
     """The conv of one reference ConvLayer as one autograd node (ref: SPARNet/blocks.py:69-103):
     [nearest x2] -> ReflectionPad2d(1) -> Conv2d(3x3, stride 1 | 2, no padding).  x: channels-last map zero-padded to a
@@ -1868,6 +1873,26 @@ class _ReflConv(Function):
         dev, L = x.device, hip.lib()
         x = _cl(x)
         cop = _pad64(co)
+        ctx.geo = REFL_GEO and stride == 1 and up in (1, 2) and PRECISION == "fp32"
+        if ctx.geo:
+            # reflection / nearest upsampling as address arithmetic of the conv's own staging: no padded copy, no ring of
+            # throw-away outputs, no crop (csrc/conv3x3_mfma.hip GEO); channels >= ci of a 64-channel input are zero padding
+            # and their octets of the K loop are skipped
+            Hv, Wv = up * H, up * W
+            wp = _pad_oihw(weight, cop, Cp)
+            bp = _pad_oihw(bias.reshape(co, 1), cop, 1).reshape(cop) if bias is not None else None
+            if ctx.needs_input_grad[0]:
+                pf, ctx.pd = pack_pair(wp)
+            else:
+                pf, ctx.pd = pack_weight(wp, "fwd"), None
+            y = _empty_cl(B, cop, Hv, Wv, dev)
+            hip.check(L.sisr_conv3x3_c64_geo(hip.ptr(x), hip.view_plain(H, W, Cp), _wptr(pf), hip.ptr(bp), hip.ptr(y),
+                                             hip.view_plain(Hv, Wv, cop), None, B, Hv, Wv, Cp, cop, 1, up - 1,
+                                             ci if Cp == 64 else 0, hip.stream()), "sisr_conv3x3_c64_geo")
+            ctx.save_for_backward(x, weight)
+            ctx.bias = bias
+            ctx.geom = (B, H, W, Cp, cop, Hv, Wv, up, stride)
+            return y
         Hp, Wp = up * H + 2, up * W + 2
         xp = _empty_cl(B, Cp, Hp, Wp, dev)
         hip.check(L.sisr_pad_reflect_up(hip.ptr(x), hip.ptr(xp), B, H, W, Cp, up, 0, hip.stream()), "sisr_pad_reflect_up")
@@ -1893,6 +1918,38 @@ class _ReflConv(Function):
         B, H, W, Cp, cop, Hp, Wp, up, stride = ctx.geom
         dev, L = dy.device, hip.lib()
         dy = _cl(dy)
+        if ctx.geo:
+            x, (Hv, Wv), (co, ci) = xp, (Hp, Wp), tuple(weight.shape[:2])
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:
+                # gradient of the padded map: the transposed conv, two pixels larger than dy, straight from dy (no embedding
+                # into a zero map); then the reflection / upsampling folded back
+                dxp = _empty_cl(B, Cp, Hv + 2, Wv + 2, dev)
+                hip.check(L.sisr_conv3x3_c64_geo(hip.ptr(dy), hip.view_plain(Hv, Wv, cop), _wptr(ctx.pd), None, hip.ptr(dxp),
+                                                 hip.view_plain(Hv + 2, Wv + 2, Cp), None, B, Hv + 2, Wv + 2, cop, Cp, 2, 0,
+                                                 co if cop == 64 else 0, hip.stream()), "sisr_conv3x3_c64_geo(transposed)")
+                dx = _empty_cl(B, Cp, H, W, dev)
+                hip.check(L.sisr_pad_reflect_up(hip.ptr(dxp), hip.ptr(dx), B, H, W, Cp, up, 1, hip.stream()), "sisr_pad_reflect_up(adjoint)")
+            has_b = ctx.bias is not None
+            if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+                dw = _grad_buf(weight)
+                db = _grad_buf(ctx.bias) if has_b else None
+                # 32 x 32-channel blocks of the gradient that hold real channels (the others: zero padding of the maps)
+                units, n_in, n_out = 0, Cp // 64, cop // 64
+                for cc in range(n_in):
+                    for cq in range(n_out):
+                        for cih in range(2):
+                            for coh in range(2):
+                                if cc * 64 + cih * 32 < ci and cq * 64 + coh * 32 < co:
+                                    units |= 1 << ((cc * n_out + cq) * 4 + cih * 2 + coh)
+                if units == (1 << (n_in * n_out * 4)) - 1 or n_in * n_out * 4 > 64:
+                    units = 0
+                nbytes = L.sisr_wgrad3x3_c64_workspace_bytes(B, Hv, Wv, Cp, cop)
+                ws = hip.workspace(dev, nbytes)
+                hip.check(L.sisr_wgrad3x3_c64_geo(hip.ptr(x), hip.view_plain(H, W, Cp), hip.ptr(dy), hip.view_plain(Hv, Wv, cop),
+                                                  hip.ptr(dw), co, ci, hip.ptr(db), hip.ptr(ws), nbytes, B, Hv, Wv, Cp, cop, up - 1,
+                                                  units, hip.stream()), "sisr_wgrad3x3_c64_geo")
+            return dx, dw, db, None, None
         dyf = _empty_cl(B, cop, Hp, Wp, dev)
         hip.check(L.sisr_crop_stride(hip.ptr(dy), hip.ptr(dyf), B, Hp, Wp, cop, stride, 1, hip.stream()), "sisr_crop_stride(embed)")
         dx = dw = db = None
