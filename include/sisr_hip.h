@@ -449,6 +449,20 @@ int sisr_conv3x3_c64_geo(const float* x, const int64_t* xview, const float* wpac
 int sisr_wgrad3x3_c64_geo(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview, float* dw, int co_real,
                           int ci_real, float* dbias, float* workspace, size_t workspace_bytes, int B, int H, int W, int cin,
                           int cout, int up, unsigned long long active_units, void* stream);
+/* Any number of such weight gradients of DIFFERENT geometries, eight per launch (plain NHWC maps: x (B, H >> up, W >> up, cin),
+ * dy (B, H, W, cout)); jobs: HOST array of njobs records, read before the call returns.  Per job the result is that of
+ * sisr_wgrad3x3_c64_geo up to the summation order of its K-split. */
+typedef struct sisr_wgrad_geo_job {
+  const float* x;
+  const float* dy;
+  float* dw;
+  float* dbias; /* nullable */
+  int B, H, W, cin, cout, up, co_real, ci_real;
+  unsigned long long active_units;
+} sisr_wgrad_geo_job;
+size_t sisr_wgrad_geo_job_bytes(void);
+size_t sisr_wgrad3x3_c64_geo_batch_workspace_bytes(const void* jobs, int njobs);
+int sisr_wgrad3x3_c64_geo_batch(const void* jobs, int njobs, float* workspace, size_t workspace_bytes, void* stream);
 /* sisr_nearest_up: nn.Upsample(scale_factor = up, 'nearest') on an NHWC map, up 1 .. 4 (ref: advanced/SRMD_blocks.py:58-63, the
  * 'upconv' tail of SRMD); adjoint != 0: the gradient summed back over the up x up replicas. */
 int sisr_nearest_up(const float* src, float* dst, int B, int H, int W, int C, int up, int adjoint, void* stream);

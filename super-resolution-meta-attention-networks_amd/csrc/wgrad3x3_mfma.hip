@@ -51,6 +51,7 @@ struct WgradParams {
   // GEO kernels (SPARNet's ConvLayers): x is read through ReflectionPad2d(1) of the H x W map (geo_reflect: -1 -> 1, n -> n - 2
   // instead of zeros) which is stored subsampled by 2^geo_up (nearest upsampling read in place)
   int geo_reflect, geo_up;
+  int units;  // GEO batch launches: this job's workgroup rows (grid rows >= units and columns >= S leave at once); 0 = gridDim.y
 };
 
 template <bool GEO = false>
@@ -59,6 +60,8 @@ static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
   float* ldx = lds;
   float* ldy = lds + LDS_X;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nrows = GEO && p.units ? p.units : (int)gridDim.y;
+  if (GEO && ((int)blockIdx.x >= p.S || (int)blockIdx.y >= nrows)) return;  // a smaller job of a batched launch
   const int unit = p.mapped ? p.unit_map[blockIdx.y] : (int)blockIdx.y;
   const int quad = unit & 3, pair = unit >> 2;
   const int cq = pair % p.cout_chunks, cc = pair / p.cout_chunks;
@@ -198,7 +201,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
   if (do_bias) *reinterpret_cast<f32x4*>(red + SLAB + tid * 4) = bsum;
   __syncthreads();
   if (wave == 0) {
-    float* out = p.slabs + ((long)blockIdx.x * gridDim.y + blockIdx.y) * SLAB;
+    float* out = p.slabs + ((long)blockIdx.x * nrows + blockIdx.y) * SLAB;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -224,6 +227,9 @@ struct WgradBatch {
   WgradParams job[WG_BATCH];
 };
 __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_batch_kernel(WgradBatch bt) { wgrad3x3_c64_body(bt.job[blockIdx.z]); }
+// ... and of DIFFERENT geometries (SPARNet: ~110 weight gradients per step on maps of 4^2 .. 32^2 pixels, 16 - 64 workgroups and
+// ~20 us each when launched alone): the grid is sized for the largest job, the others' surplus workgroups leave at once.
+__global__ __launch_bounds__(256, 2) void wgrad3x3_c64_geo_batch_kernel(WgradBatch bt) { wgrad3x3_c64_body<true>(bt.job[blockIdx.z]); }
 
 // ------------------------------------------------------------------ fp32, one persistent workgroup per CU (round 3)
 // The kernel above splits a tile's OUTPUT over four workgroups (each re-reads its half of x and dY: 1.45x the algorithmic
@@ -1152,7 +1158,7 @@ static int wgrad_fp32_launch(const float* x, const int64_t* xview, const float* 
   if (!sisr_aligned16(x) || !sisr_aligned16(dy) || !sisr_aligned16(workspace) || !sisr_aligned16(dy_scale) ||
       !sisr_aligned16(dy_shift))
     return SISR_ERR_ALIGN;
-  WgradParams p;
+  WgradParams p = {};
   p.x = x;
   p.xv = view_from(xview);
   p.dy = dy;
@@ -1250,6 +1256,151 @@ static int wgrad_fp32_launch(const float* x, const int64_t* xview, const float* 
   const long total = (long)units * SLAB + (dbias ? cout : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(64, RG), 0, (hipStream_t)stream, r);
   return sisr_check_launch();
+}
+
+// ---- batched launch of sisr_wgrad3x3_c64_geo jobs of different geometries (<= 8 per launch, any number per call)
+struct sisr_wgrad_geo_job_host {
+  const float* x;
+  const float* dy;
+  float* dw;
+  float* dbias;
+  int B, H, W, cin, cout, up, co_real, ci_real;
+  unsigned long long active_units;
+};
+extern "C" size_t sisr_wgrad_geo_job_bytes(void) { return sizeof(sisr_wgrad_geo_job_host); }
+static int wgrad_geo_units(const sisr_wgrad_geo_job_host& j) {
+  const int all = (j.cin / 64) * (j.cout / 64) * 4;
+  if (!j.active_units) return all;
+  int n = 0;
+  for (int u = 0; u < all; ++u) n += (int)((j.active_units >> u) & 1);
+  return n;
+}
+// workgroups of one job inside a batch of `nj` jobs: the K-split that leaves the whole launch about two workgroups per CU
+static int wgrad_geo_batch_split(const sisr_wgrad_geo_job_host& j, int units, int nj) {
+  const long tiles = (long)j.B * ((j.H + WT_H - 1) / WT_H) * ((j.W + WT_W - 1) / WT_W);
+  long S = 512 / ((long)units * nj);
+  if (S < 1) S = 1;
+  if (S > tiles) S = tiles;
+  return (int)S;
+}
+static bool wgrad_geo_job_ok(const sisr_wgrad_geo_job_host& j) {
+  return j.x && j.dy && j.dw && j.B > 0 && j.H >= 2 && j.W >= 2 && j.cin > 0 && j.cout > 0 && !(j.cin & 63) && !(j.cout & 63) &&
+         (j.cin / 64) * (j.cout / 64) * 4 <= WG_MAX_UNITS && j.up >= 0 && j.up <= 1 && !((j.H | j.W) & ((1 << j.up) - 1)) &&
+         j.co_real > 0 && j.co_real <= j.cout && j.ci_real > 0 && j.ci_real <= j.cin;
+}
+extern "C" size_t sisr_wgrad3x3_c64_geo_batch_workspace_bytes(const void* jobs_host, int njobs) {
+  if (!jobs_host || njobs <= 0) return 0;
+  const sisr_wgrad_geo_job_host* jobs = static_cast<const sisr_wgrad_geo_job_host*>(jobs_host);
+  size_t worst = 0;
+  for (int k0 = 0; k0 < njobs; k0 += WG_BATCH) {
+    const int nj = njobs - k0 < WG_BATCH ? njobs - k0 : WG_BATCH;
+    size_t need = 0;
+    for (int k = k0; k < k0 + nj; ++k) {
+      if (!wgrad_geo_job_ok(jobs[k])) return 0;
+      const int units = wgrad_geo_units(jobs[k]);
+      if (units <= 0) return 0;
+      const int S = wgrad_geo_batch_split(jobs[k], units, nj);
+      need += ((size_t)S * units * SLAB + (size_t)S * jobs[k].cout + 64) * sizeof(float);
+    }
+    if (need > worst) worst = need;
+  }
+  return worst;
+}
+extern "C" int sisr_wgrad3x3_c64_geo_batch(const void* jobs_host, int njobs, float* workspace, size_t workspace_bytes,
+                                           void* stream) {
+  if (!jobs_host || njobs <= 0 || !workspace || !sisr_aligned16(workspace)) return SISR_ERR_ARG;
+  if (workspace_bytes < sisr_wgrad3x3_c64_geo_batch_workspace_bytes(jobs_host, njobs) || workspace_bytes == 0) return SISR_ERR_ARG;
+  const sisr_wgrad_geo_job_host* jobs = static_cast<const sisr_wgrad_geo_job_host*>(jobs_host);
+  for (int k0 = 0; k0 < njobs; k0 += WG_BATCH) {
+    const int nj = njobs - k0 < WG_BATCH ? njobs - k0 : WG_BATCH;
+    WgradBatch wb;
+    ReduceBatch rb;
+    memset(&wb, 0, sizeof(wb));
+    memset(&rb, 0, sizeof(rb));
+    float* ws = workspace;
+    int smax = 1, umax = 1;
+    long tmax = 0;
+    for (int k = 0; k < nj; ++k) {
+      const sisr_wgrad_geo_job_host& j = jobs[k0 + k];
+      if (!sisr_aligned16(j.x) || !sisr_aligned16(j.dy)) return SISR_ERR_ALIGN;
+      WgradParams& p = wb.job[k];
+      ReduceParams& r = rb.job[k];
+      const int Hs = j.H >> j.up, Ws = j.W >> j.up;
+      p.x = j.x;
+      p.xv.sB = (long)Hs * Ws * j.cin; p.xv.sH = (long)Ws * j.cin; p.xv.sW = j.cin; p.xv.chi = 0; p.xv.clo = 64; p.xv.cdiv = 1 << 30;
+      p.dy = j.dy;
+      p.yv.sB = (long)j.H * j.W * j.cout; p.yv.sH = (long)j.W * j.cout; p.yv.sW = j.cout; p.yv.chi = 0; p.yv.clo = 64; p.yv.cdiv = 1 << 30;
+      p.B = j.B;
+      p.H = j.H;
+      p.W = j.W;
+      p.cin_chunks = j.cin / 64;
+      p.cout_chunks = j.cout / 64;
+      p.tiles_w = (j.W + WT_W - 1) / WT_W;
+      p.tiles_h = (j.H + WT_H - 1) / WT_H;
+      p.geo_reflect = 1;
+      p.geo_up = j.up;
+      const int all_units = p.cin_chunks * p.cout_chunks * 4;
+      int units = all_units;
+      if (j.active_units) {
+        units = 0;
+        unsigned seen_bias = 0;
+        for (int u = 0; u < all_units; ++u) {
+          if (!((j.active_units >> u) & 1)) continue;
+          p.unit_map[units] = r.unit_map[units] = (unsigned char)u;
+          const int cq = (u >> 2) % p.cout_chunks, coh = u & 1;
+          if (!((seen_bias >> (cq * 2 + coh)) & 1)) {
+            p.bias_units |= 1ull << units;
+            seen_bias |= 1u << (cq * 2 + coh);
+          }
+          ++units;
+        }
+        if (units == 0 || (all_units < 64 && (j.active_units >> all_units) != 0)) return SISR_ERR_ARG;
+        const unsigned need_bias = (1u << ((j.co_real + 31) / 32)) - 1;
+        if (j.dbias && (seen_bias & need_bias) != need_bias) return SISR_ERR_ARG;
+      }
+      p.mapped = r.mapped = j.active_units != 0;
+      p.units = units;
+      p.S = wgrad_geo_batch_split(j, units, nj);
+      p.slabs = ws;
+      ws += (size_t)p.S * units * SLAB;
+      p.bias_slabs = j.dbias ? ws : nullptr;
+      ws += (size_t)p.S * j.cout + 64;
+      ws = reinterpret_cast<float*>(((uintptr_t)ws + 15) & ~(uintptr_t)15);
+      r.slabs = p.slabs;
+      r.bias_slabs = p.bias_slabs;
+      r.dw = j.dw;
+      r.db = j.dbias;
+      r.so = (long)j.ci_real * 9;
+      r.si = 9;
+      r.alpha = 1.f;
+      r.S = p.S;
+      r.units = units;
+      r.cin_chunks = p.cin_chunks;
+      r.cout_chunks = p.cout_chunks;
+      r.flip = 0;
+      r.on = 1;
+      r.oq = 64;
+      r.in_ = 1;
+      r.iq = 64;
+      r.bias_n = 1;
+      r.bias_q = 64;
+      r.o_lim = j.co_real;
+      r.i_lim = j.ci_real;
+      if (p.S > smax) smax = p.S;
+      if (units > umax) umax = units;
+      const long total = (long)units * SLAB + (j.dbias ? j.cout : 0);
+      if (total > tmax) tmax = total;
+    }
+    const size_t lds_bytes = (size_t)(LDS_X + LDS_Y) * sizeof(float);
+    SISR_ALLOW_LDS(wgrad3x3_c64_geo_batch_kernel, lds_bytes);
+    hipLaunchKernelGGL(wgrad3x3_c64_geo_batch_kernel, dim3(smax, umax, nj), dim3(256), lds_bytes, (hipStream_t)stream, wb);
+    int rc = sisr_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((tmax + 255) / 256), nj), dim3(64, RG), 0, (hipStream_t)stream, rb);
+    rc = sisr_check_launch();
+    if (rc) return rc;
+  }
+  return SISR_OK;
 }
 
 // ---- batched launch: njobs (<= 8) 64 -> 64 weight gradients of one (B, H, W), plain OIHW outputs
@@ -1368,7 +1519,7 @@ static int wgrad3x3_c64_bf16_launch(const float* x, const int64_t* xview, const 
   if (!sisr_aligned16(x) || !sisr_aligned16(dy) || !sisr_aligned16(workspace) || !sisr_aligned16(dy_scale) ||
       !sisr_aligned16(dy_shift))
     return SISR_ERR_ALIGN;
-  WgradParams p;
+  WgradParams p = {};
   p.x = x;
   p.xv = view_from(xview);
   p.dy = dy;
@@ -1486,7 +1637,7 @@ extern "C" int sisr_wgrad3x3_c64_x3(const float* x, const int64_t* xview, const 
   if (!sisr_aligned16(x) || !sisr_aligned16(dy) || !sisr_aligned16(workspace) || !sisr_aligned16(dy_scale) ||
       !sisr_aligned16(dy_shift))
     return SISR_ERR_ALIGN;
-  WgradParams p;
+  WgradParams p = {};
   p.x = x;
   p.xv = view_from(xview);
   p.dy = dy;

@@ -140,6 +140,9 @@ _SIGS.update({  # SPARNet pieces (csrc/sparnet.hip)
     "sisr_conv3x3_c64_geo": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_wgrad3x3_c64_geo": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int,
                                       ctypes.c_uint64, P]),
+    "sisr_wgrad_geo_job_bytes": (c_size_t, []),
+    "sisr_wgrad3x3_c64_geo_batch_workspace_bytes": (c_size_t, [P, c_int]),
+    "sisr_wgrad3x3_c64_geo_batch": (c_int, [P, c_int, P, c_size_t, P]),
     "sisr_pad_reflect_up": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_crop_stride": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_bn_act_fwd": (c_int, [P] * 8 + [c_long, c_int, c_int, c_int, c_float, c_float, c_float, P, c_size_t, P]),
@@ -190,6 +193,12 @@ class CaParamJob(ctypes.Structure):
 class WgradJob(ctypes.Structure):
     """Host mirror of sisr_wgrad_job (include/sisr_hip.h)."""
     _fields_ = [(n, c_void_p) for n in ("x", "dy", "dy_scale", "dy_shift", "dw", "dbias")]
+
+
+class WgradGeoJob(ctypes.Structure):
+    """Host mirror of sisr_wgrad_geo_job (include/sisr_hip.h)."""
+    _fields_ = [(n, c_void_p) for n in ("x", "dy", "dw", "dbias")] + \
+               [(n, c_int) for n in ("B", "H", "W", "cin", "cout", "up", "co_real", "ci_real")] + [("active_units", ctypes.c_uint64)]
 
 
 class CaTail(ctypes.Structure):

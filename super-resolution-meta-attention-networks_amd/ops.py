@@ -77,6 +77,40 @@ def _on_side(device, after_event, fn, tensors):
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(device))
 
 
+_side_groups = {}  # device index -> [(fn, tensors)] waiting for their group's fork
+
+
+def _on_side_grouped(device, fn, tensors, group):
+    """_on_side for many small launches: every cross-stream edge costs a barrier packet (a parallel branch per launch was
+    measured slower than no branch at all), so the launches wait and go to the side stream `group` at a time behind ONE
+    event; what is left goes out, and the side stream is joined, when the backward pass ends."""
+    lst = _side_groups.get(device.index)
+    if lst is None:
+        lst = _side_groups[device.index] = []
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_side_group(device, final=True))
+    lst.append((fn, tensors))
+    if len(lst) >= group:
+        _flush_side_group(device)
+
+
+def _flush_side_group(device, final=False):
+    lst = _side_groups.get(device.index)
+    if final:
+        _side_groups.pop(device.index, None)
+    elif lst is not None:
+        _side_groups[device.index] = []
+    if lst:
+        ev = torch.cuda.Event()
+        ev.record()
+
+        def run():
+            for fn, _ in lst:
+                fn()
+        _on_side(device, ev, run, [t for _, ts in lst for t in ts])
+    if final:
+        _join_side(device)
+
+
 def _cl(x):
     return x if x.is_contiguous(memory_format=CL) else x.contiguous(memory_format=CL)
 
@@ -105,7 +139,7 @@ def _grad_buf_or(p, n, device):
     return _grad_buf(p) if p is not None else torch.empty(n, device=device)
 
 
-def _side_ok(*weights, pixels=None):
+def _side_ok(*weights, pixels=None, fork=False):
     """pixels (B * H * W of the launches): inside a deferred_wgrads() block small weight gradients are queued for batched
     launches on the main stream instead (a queue flushed from the side stream would read operands the allocator only tracks
     on the main stream).
@@ -118,8 +152,9 @@ def _side_ok(*weights, pixels=None):
         return False
     if _DEFERRED is not None and pixels is not None and PRECISION == "fp32" and pixels <= BATCH_WGRAD_MAX_PIXELS:
         return False
-    # under hipGraph capture the fork / join would become graph edges (SISR_GRAPH_FORK=1); default: one stream
-    return GRAPH_FORK or not torch.cuda.is_current_stream_capturing()
+    # under hipGraph capture the fork / join would become graph edges (SISR_GRAPH_FORK=1); default: one stream.  fork=True: a
+    # caller whose launches leave most of the chip idle (SPARNet's small maps) asks for the branch under capture as well
+    return GRAPH_FORK or fork or not torch.cuda.is_current_stream_capturing()
 
 
 _gate_ws_cache = {}
@@ -566,6 +601,42 @@ class WgradQueue:
         import ctypes
         hip.check(L.sisr_wgrad3x3_c64_batch(ctypes.addressof(arr), n, v, v, hip.ptr(ws), nbytes, B, H, W, hip.stream()),
                   "sisr_wgrad3x3_c64_batch")
+        self.jobs = []
+
+
+class WgradGeoQueue:
+    """Weight gradients of SPARNet's ConvLayer convs (any geometry) queued by a backward pass inside a deferred_wgrads() block
+    and launched eight per launch, similar sizes together, when the block closes (sisr_wgrad3x3_c64_geo_batch).  Holds the
+    operands, and the STORAGES of the outputs (see WgradQueue.add), until the launches have been issued."""
+    MAX_JOBS = 256  # flush earlier than the end of the pass beyond this (bounds what the queue keeps alive)
+
+    def __init__(self, device):
+        self.device, self.jobs = device, []
+
+    def add(self, x, dy, dw, db, ints, units, work):
+        keep = (dw.untyped_storage(), db.untyped_storage() if db is not None else None)
+        self.jobs.append((work, x, dy, hip.ptr(dw), hip.ptr(db), ints, units, keep))
+        if len(self.jobs) >= self.MAX_JOBS:
+            self.flush()
+
+    def flush(self):
+        if not self.jobs:
+            return
+        import ctypes
+        L = hip.lib()
+        if L.sisr_wgrad_geo_job_bytes() != ctypes.sizeof(hip.WgradGeoJob):
+            raise RuntimeError("hip.WgradGeoJob does not match sisr_wgrad_geo_job of the loaded library")
+        jobs = sorted(self.jobs, key=lambda j: j[0])  # launches of eight similar sizes
+        arr = (hip.WgradGeoJob * len(jobs))()
+        for k, (_, x, dy, dw, db, ints, units, _keep) in enumerate(jobs):
+            a = arr[k]
+            a.x, a.dy, a.dw, a.dbias = hip.ptr(x), hip.ptr(dy), dw, db
+            a.B, a.H, a.W, a.cin, a.cout, a.up, a.co_real, a.ci_real = ints
+            a.active_units = units
+        nbytes = L.sisr_wgrad3x3_c64_geo_batch_workspace_bytes(ctypes.addressof(arr), len(jobs))
+        ws = hip.workspace(self.device, nbytes)
+        hip.check(L.sisr_wgrad3x3_c64_geo_batch(ctypes.addressof(arr), len(jobs), hip.ptr(ws), nbytes, hip.stream()),
+                  "sisr_wgrad3x3_c64_geo_batch")
         self.jobs = []
 
 
@@ -1852,6 +1923,11 @@ def nchw_to_nhwc_pad(x, cp=None):
 # SPARNet's stride-1 ConvLayer convs with reflection / nearest upsampling inside the MFMA kernels' staging (0: the gather ->
 # conv -> gather composition of round 3, kept for the stride-2 convs and as the A/B reference; results are bit-identical)
 REFL_GEO = os.environ.get("SISR_REFL_GEO", "1") != "0"
+REFL_BATCH = os.environ.get("SISR_REFL_BATCH", "1") != "0"  # their small weight gradients eight per launch (WgradGeoQueue)
+# ... or on the side stream (captured: a parallel branch).  Measured slower on MI355X, per launch (459 vs 500 images/s) and
+# forked sixteen at a time (467): off
+REFL_SIDE = os.environ.get("SISR_REFL_SIDE", "0") != "0"
+REFL_SIDE_GROUP = int(os.environ.get("SISR_REFL_SIDE_GROUP", 16))  # ... forked this many at a time
 
 
 class _ReflConv(Function):
@@ -1944,11 +2020,36 @@ class _ReflConv(Function):
                                     units |= 1 << ((cc * n_out + cq) * 4 + cih * 2 + coh)
                 if units == (1 << (n_in * n_out * 4)) - 1 or n_in * n_out * 4 > 64:
                     units = 0
+                # small launches (fewer 8 x 32-pixel tiles than half the CUs) inside a deferred_wgrads() block: queued, eight per
+                # launch when the block closes
+                tiles = B * ((Hv + 7) // 8) * ((Wv + 31) // 32) * n_in * n_out
+                owners = (weight, ctx.bias) if has_b else (weight,)
+                if (REFL_BATCH and _DEFERRED is not None and hip.stream() == _DEFERRED_STREAM and tiles < 128 and
+                        all(o.requires_grad and o.grad is None for o in owners)):
+                    if id(weight) in _DEFERRED_OWNERS:
+                        _flush_deferred()  # second gradient of one weight in this pass: the first must be written first
+                    else:
+                        _DEFERRED_OWNERS.add(id(weight))
+                        q = _DEFERRED.get(("geo", dev.index))
+                        if q is None:
+                            q = _DEFERRED[("geo", dev.index)] = WgradGeoQueue(dev)
+                        q.add(x, dy, dw, db, (B, Hv, Wv, Cp, cop, up - 1, co, ci), units, tiles)
+                        return dx, dw, db, None, None
                 nbytes = L.sisr_wgrad3x3_c64_workspace_bytes(B, Hv, Wv, Cp, cop)
-                ws = hip.workspace(dev, nbytes)
-                hip.check(L.sisr_wgrad3x3_c64_geo(hip.ptr(x), hip.view_plain(H, W, Cp), hip.ptr(dy), hip.view_plain(Hv, Wv, cop),
-                                                  hip.ptr(dw), co, ci, hip.ptr(db), hip.ptr(ws), nbytes, B, Hv, Wv, Cp, cop, up - 1,
-                                                  units, hip.stream()), "sisr_wgrad3x3_c64_geo")
+
+                def wgrad():  # (the workspace is per stream: taken where the launch is issued)
+                    ws = hip.workspace(dev, nbytes)
+                    hip.check(L.sisr_wgrad3x3_c64_geo(hip.ptr(x), hip.view_plain(H, W, Cp), hip.ptr(dy), hip.view_plain(Hv, Wv, cop),
+                                                      hip.ptr(dw), co, ci, hip.ptr(db), hip.ptr(ws), nbytes, B, Hv, Wv, Cp, cop,
+                                                      up - 1, units, hip.stream()), "sisr_wgrad3x3_c64_geo")
+
+                # The maps of this network are far smaller than the chip (most launches: 16 - 80 workgroups on 256 CUs): the
+                # weight gradients, which nothing on the input-gradient chain waits for, fill the idle CUs from a second stream
+                # (a parallel branch of the captured step), joined once at the end of the backward pass.
+                if REFL_SIDE and _side_ok(*((weight, ctx.bias) if has_b else (weight,)), fork=True):
+                    _on_side_grouped(dev, wgrad, (x, dy, dw, db), REFL_SIDE_GROUP)
+                else:
+                    wgrad()
             return dx, dw, db, None, None
         dyf = _empty_cl(B, cop, Hp, Wp, dev)
         hip.check(L.sisr_crop_stride(hip.ptr(dy), hip.ptr(dyf), B, Hp, Wp, cop, stride, 1, hip.stream()), "sisr_crop_stride(embed)")

@@ -69,7 +69,8 @@ def main():
     L = sisr_amd.hip.lib()
     wrapped = {}
     for sym, kind in (("sisr_pad_reflect_up", "pad"), ("sisr_crop_stride", "crop"), ("sisr_bn_act_fwd", "bn_fwd"),
-                      ("sisr_bn_act_bwd", "bn_bwd"), ("sisr_spar_combine_fwd", "combine"), ("sisr_spar_combine_bwd", "combine_bwd")):
+                      ("sisr_bn_act_bwd", "bn_bwd"), ("sisr_spar_combine_fwd", "combine"), ("sisr_spar_combine_bwd", "combine_bwd"),
+                      ("sisr_conv3x3_c64_geo", "conv_geo"), ("sisr_wgrad3x3_c64_geo", "wgrad_geo")):
         if not hasattr(L, sym):
             continue
         fn0 = getattr(L, sym)
@@ -77,8 +78,14 @@ def main():
 
         def make(fn0=fn0, kind=kind, sym=sym):
             def call(*a):
-                ints = tuple(v for v in a[2:8] if isinstance(v, int) and 0 < v < 100000)
-                return timed(kind, ints[:5], 0.0, fn0, *a)
+                if kind == "conv_geo":  # B, H, W, cin, cout, mode, up, kreal
+                    key = tuple(a[7:15])
+                    return timed(kind, key, 2.0 * a[7] * a[8] * a[9] * a[10] * a[11] * 9, fn0, *a)
+                if kind == "wgrad_geo":  # co, ci, B, H, W, cin, cout, up, active units
+                    key = (a[5], a[6]) + tuple(a[10:17])
+                    return timed(kind, key, 2.0 * a[10] * a[11] * a[12] * a[13] * a[14] * 9, fn0, *a)
+                ints = tuple(v for v in a[2:8] if isinstance(v, int) and 0 <= v < 100000)
+                return timed(kind, ints[:6], 0.0, fn0, *a)
             return call
         setattr(L, sym, make())
     side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, False
