@@ -330,9 +330,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c64_kernel(ConvParams p) {
 // H x W gradient.  KSEL 4 / 5 (one input chunk whose channels >= 32 / >= 8 are zero padding: 32-feature layers, RGB and
 // attention-logit ends): 4 / 1 of the 8 octets per tap.
 template <bool AFFINE, bool MASK, bool RES, int MT, bool GATE = false, bool DOT = false, bool LEAKY = false, int KSEL = 0, int HEAD = 0,
-          bool GEO = false>
+          bool GEO = false, bool S2 = false>
 __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_WGS : 4) : 3)) void conv3x3_c64_v4_kernel(ConvParams p) {
-  constexpr int THv = 2 * MT, HHv = THv + 2;
+  // S2 (GEO, 2-row tiles): the stride-2 ConvLayer conv computed at its OUTPUT pixels -- lane n of an M-tile reads halo column
+  // 2 n + kw of a 5-row x 66-column halo (84.5 KB) -- instead of the stride-1 conv subsampled (a quarter of the arithmetic)
+  static_assert(!S2 || (GEO && MT == 1 && !GATE && !AFFINE && HEAD == 0 && (KSEL == 0 || KSEL == 4)), "S2: plain GEO form only");
+  constexpr int SS = S2 ? 2 : 1, HWv = S2 ? 66 : HALO_W, NK = S2 ? 5 : 3;
+  constexpr int THv = 2 * MT, HHv = S2 ? 2 * THv + 1 : THv + 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // (Wave priorities were measured and left out: with staging and epilogue at s_setprio 3 the staging phase shrinks from
   // 42 k to 7 k cycles -- the unbroken MFMA stream of an older wave otherwise starves it -- but launches take the same time
@@ -374,20 +378,21 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
   for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      aoff[kw][j] = ((MT * ph) * HALO_W + n + kw) * 64 + (((2 * (KSEL == 1 ? (j & 3) + 4 * q : j) + hh) ^ ((n + kw) & 15)) << 2) +
-                    (KSEL == 3 ? ch * (HHv * HALO_W * 64) : 0);
+      aoff[kw][j] = ((SS * MT * ph) * HWv + SS * n + kw) * 64 +
+                    (((2 * (KSEL == 1 ? (j & 3) + 4 * q : j) + hh) ^ ((SS * n + kw) & 15)) << 2) +
+                    (KSEL == 3 ? ch * (HHv * HWv * 64) : 0);
   const unsigned boff = hh * 256 + co * 4;
 
   if constexpr (HEAD == 1) {
     ca_gate_fwd_sample<false>(p.head_part, p.head_parts, p.fwd_tail.inv_hw, b, p.fwd_tail.w1, p.fwd_tail.b1, p.fwd_tail.w2,
                               p.fwd_tail.b2, p.fwd_tail.R, p.fwd_tail.mul, p.fwd_tail.s, p.fwd_tail.hid, p.fwd_tail.ca,
-                              p.fwd_tail.g, lds, lds + HHv * HALO_W * 64);
+                              p.fwd_tail.g, lds, lds + HHv * HWv * 64);
     __syncthreads();  // g (= p.in_scale of this launch): 64 floats of LDS behind the halo (launched with SISR_HEAD_LDS more
                       // bytes) hand it to the staging below -- no store -> load round trip; the scratch is free again
   } else if constexpr (HEAD == 2) {
     ca_gate_bwd_sample<false>(p.head_part, p.head_parts, p.bwd_tail.inv_hw, b, p.bwd_tail.w1, p.bwd_tail.w2, p.bwd_tail.R,
                               p.bwd_tail.hid, p.bwd_tail.ca, p.bwd_tail.mul, p.bwd_tail.shift, p.bwd_tail.dmul,
-                              p.bwd_tail.dz2, p.bwd_tail.dz1, lds, lds + HHv * HALO_W * 64);
+                              p.bwd_tail.dz2, p.bwd_tail.dz1, lds, lds + HHv * HWv * 64);
     __syncthreads();  // shift (= p.in_shift of this launch), handed over the same way
   }
   int c_begin = 0;
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
       for (int k = 0; k < 3; ++k) {
         const int col = pcol + 16 * k, gw = w0 - 1 + col;
         if (k < 2 || pcol < 2)
-          *reinterpret_cast<f32x4*>(lds + r * (HALO_W * 64) + col * 64 + ((c4 ^ (col & 15)) << 2)) =
+          *reinterpret_cast<f32x4*>(lds + r * (HWv * 64) + col * 64 + ((c4 ^ (col & 15)) << 2)) =
               sisr_keep_if(v[r][k], gh >= 0 && gh < H && gw >= 0 && gw < W);
       }
     }
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
   }
   for (int c = c_begin; c < p.cin_chunks; ++c) {
     if (KSEL != 3 && c) __syncthreads();
-    float* ldsc = lds + (KSEL == 3 ? c * (HHv * HALO_W * 64) : 0);  // KSEL 3: both chunks' halos are resident
+    float* ldsc = lds + (KSEL == 3 ? c * (HHv * HWv * 64) : 0);  // KSEL 3: both chunks' halos are resident
     // The first six weight fragments of the K loop are requested BEFORE the halo is staged: they do not depend on it, and a
     // K loop that asks for them after the staging barrier opens with an L2 round trip (0.4-0.6 us per tile in which the
     // matrix pipe of this workgroup's SIMDs idles unless another workgroup happens to be mid-loop; per-CU timelines from
@@ -444,20 +449,20 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
       f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
       if (AFFINE) {
         s4 = *reinterpret_cast<const f32x4*>(p.in_scale + ((long)b * p.cin_chunks + c) * 64 + c4 * 4);
-        if constexpr (HEAD == 2) t4 = *reinterpret_cast<const f32x4*>(lds + HHv * HALO_W * 64 + c4 * 4);
+        if constexpr (HEAD == 2) t4 = *reinterpret_cast<const f32x4*>(lds + HHv * HWv * 64 + c4 * 4);
         else if (p.in_shift) t4 = *reinterpret_cast<const f32x4*>(p.in_shift + ((long)b * p.cin_chunks + c) * 64 + c4 * 4);
       }
-      unsigned goff[3], loff[3];
-      bool cok[3];
+      unsigned goff[NK], loff[NK];
+      bool cok[NK];
       // GEO: virtual input size, origin shift, reflection and subsampling of the stored map (all scalar)
       const int Hv = GEO ? p.geo_h : H, Wv = GEO ? p.geo_w : W, goffs = GEO ? p.geo_off : 0;
       const bool refl = GEO && p.geo_reflect;
       const int gup = GEO ? p.geo_up : 0;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < NK; ++k) {
         const int col = pcol + 16 * k;
-        int gw = w0 - 1 + col - goffs;
-        cok[k] = (refl || (gw >= 0 && gw < Wv)) && col < HALO_W;
+        int gw = SS * w0 - 1 + col - goffs;
+        cok[k] = (refl || (gw >= 0 && gw < Wv)) && col < HWv;
         if (refl) gw = gw < 0 ? -gw : (gw >= Wv ? 2 * Wv - 2 - gw : gw);
         goff[k] = (unsigned)((min(max(gw, 0), Wv - 1) >> gup) * (int)p.xv.sW + c4 * 4) * 4u;  // bytes
         loff[k] = col * 64 + ((c4 ^ (col & 15)) << 2);
@@ -469,40 +474,40 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
         return (unsigned)((min(max(gh, 0), Hv - 1) >> gup) * (int)p.xv.sH) * 4u;
       };
       if (!GATE) {
-        f32x4 v[HHv][3];
+        f32x4 v[HHv][NK];
 #pragma unroll
         for (int r = 0; r < HHv; ++r) {
-          const unsigned ro = row_bytes(h0 - 1 + r - goffs);  // scalar, bytes
+          const unsigned ro = row_bytes(SS * h0 - 1 + r - goffs);  // scalar, bytes
 #pragma unroll
-          for (int k = 0; k < 3; ++k)
-            if (k < 2 || pcol < 2) v[r][k] = sisr_buf_load4(rx, goff[k], ro);
+          for (int k = 0; k < NK; ++k)
+            if (k < NK - 1 || pcol < 2) v[r][k] = sisr_buf_load4(rx, goff[k], ro);
         }
         if (interior) {
 #pragma unroll
           for (int r = 0; r < HHv; ++r)
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-              if (k < 2 || pcol < 2) {
+            for (int k = 0; k < NK; ++k)
+              if (k < NK - 1 || pcol < 2) {
                 f32x4 t = v[r][k];
                 if (AFFINE) t = t * s4 + t4;
-                *reinterpret_cast<f32x4*>(ldsc + r * (HALO_W * 64) + loff[k]) = t;
+                *reinterpret_cast<f32x4*>(ldsc + r * (HWv * 64) + loff[k]) = t;
               }
         } else {
 #pragma unroll
           for (int r = 0; r < HHv; ++r) {
-            const int gh = h0 - 1 + r - goffs;
+            const int gh = SS * h0 - 1 + r - goffs;
             const bool rok = gh >= 0 && gh < Hv;  // scalar
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-              if (k < 2 || pcol < 2) {
+            for (int k = 0; k < NK; ++k)
+              if (k < NK - 1 || pcol < 2) {
                 f32x4 t = v[r][k];
                 if (AFFINE) t = t * s4 + t4;
-                *reinterpret_cast<f32x4*>(ldsc + r * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
+                *reinterpret_cast<f32x4*>(ldsc + r * (HWv * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
               }
           }
         }
       } else {  // y = t * gate + skip on the fly; rows in batches of HHv / 2 (two operand tensors in flight)
-        const f32x4 g4 = HEAD == 1 ? *reinterpret_cast<const f32x4*>(lds + HHv * HALO_W * 64 + c4 * 4)
+        const f32x4 g4 = HEAD == 1 ? *reinterpret_cast<const f32x4*>(lds + HHv * HWv * 64 + c4 * 4)
                                    : *reinterpret_cast<const f32x4*>(p.in_scale + (long)b * 64 + c4 * 4);
         const sisr_rsrc_t ru = sisr_rsrc(p.gate_add + (long)b * p.xv.sB);
         const sisr_rsrc_t ro_ = sisr_rsrc(p.gate_out + (long)b * p.xv.sB);
@@ -533,8 +538,8 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
             for (int k = 0; k < 3; ++k)
               if (k < 2 || pcol < 2) {
                 const f32x4 t = sisr_mul_add4(v[r][k], g4, u[r][k]);
-                if (interior) *reinterpret_cast<f32x4*>(lds + hr * (HALO_W * 64) + loff[k]) = t;
-                else *reinterpret_cast<f32x4*>(lds + hr * (HALO_W * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
+                if (interior) *reinterpret_cast<f32x4*>(lds + hr * (HWv * 64) + loff[k]) = t;
+                else *reinterpret_cast<f32x4*>(lds + hr * (HWv * 64) + loff[k]) = sisr_keep_if(t, rok && cok[k]);
                 const int col = pcol + 16 * k;
                 if (rown && cok[k] && col >= 1 && col <= TW) SISR_Y_STORE4(t, ro_, goff[k], ro);
               }
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
         const sisr_rsrc_t rwb = sisr_rsrc(wb);
         auto ldb = [&](int s) { return sisr_buf_load4(rwb, boff * 4u, (unsigned)(((s / NJ) * 8 + (s % NJ)) * 2048)); };
         auto lda = [&](int m, int s) {
-          return *reinterpret_cast<const f32x4*>(lds + (((s / NJ) / 3 + m) * (HALO_W * 64)) + aoff[(s / NJ) % 3][s % NJ]);
+          return *reinterpret_cast<const f32x4*>(lds + (((s / NJ) / 3 + m) * (HWv * 64)) + aoff[(s / NJ) % 3][s % NJ]);
         };
         f32x4 bq[8];
         f32x4 aq[4][2];
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
     } else {
 #define V4_LOAD_B(s) sisr_buf_load4(rw, boff * 4u, (unsigned)((s) * 2048))
 #define V4_LOAD_A(m, s) \
-  (*reinterpret_cast<const f32x4*>(lds + ((((s) >> 3) / 3 + (m)) * (HALO_W * 64)) + aoff[((s) >> 3) % 3][(s) & 7]))
+  (*reinterpret_cast<const f32x4*>(lds + ((((s) >> 3) / 3 + (m)) * (HWv * 64)) + aoff[((s) >> 3) % 3][(s) & 7]))
     f32x4 aq[4][2];
     if constexpr (!EARLY_B) {
 #pragma unroll
@@ -2668,9 +2673,9 @@ extern "C" int sisr_conv3x3_c64_geo(const float* x, const int64_t* xview, const 
                                     int up, int kreal, void* stream) {
   if (!x || !wpacked || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
   if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
-  if (mode != 1 && mode != 2) return SISR_ERR_ARG;
-  if (up < 0 || up > 1 || (mode == 2 && up) || kreal < 0) return SISR_ERR_UNSUPPORTED;
-  if (mode == 1 && (H < 2 || W < 2 || ((H | W) & ((1 << up) - 1)))) return SISR_ERR_ARG;  // ReflectionPad2d(1) needs 2 pixels
+  if (mode != 1 && mode != 2 && mode != 3) return SISR_ERR_ARG;
+  if (up < 0 || up > 1 || (mode != 1 && up) || kreal < 0) return SISR_ERR_UNSUPPORTED;
+  if (mode != 2 && (H < 2 || W < 2 || ((H | W) & ((1 << up) - 1)))) return SISR_ERR_ARG;  // ReflectionPad2d(1) needs 2 pixels
   if (mode == 2 && (H < 3 || W < 3)) return SISR_ERR_ARG;
   if (!sisr_aligned16(x) || !sisr_aligned16(wpacked) || !sisr_aligned16(y)) return SISR_ERR_ALIGN;
   ConvParams p;
@@ -2690,15 +2695,19 @@ extern "C" int sisr_conv3x3_c64_geo(const float* x, const int64_t* xview, const 
   p.bias_n = 1;
   p.bias_q = 64;
   p.B = B;
-  p.H = H;
-  p.W = W;
   p.cin_chunks = cin / 64;
   p.cout_chunks = cout / 64;
-  p.geo_reflect = mode == 1;
+  p.geo_reflect = mode != 2;
   p.geo_up = up;
   p.geo_off = mode == 2;
   p.geo_h = mode == 2 ? H - 2 : H;
   p.geo_w = mode == 2 ? W - 2 : W;
+  if (mode == 3) {  // H, W are the INPUT's; the output has every second pixel of the stride-1 result
+    H = (H + 1) / 2;
+    W = (W + 1) / 2;
+  }
+  p.H = H;
+  p.W = W;
   p.tiles_w = (W + TW - 1) / TW;
   p.tiles_h = (H + TH - 1) / TH;
   const long nblk = (long)p.tiles_w * p.tiles_h * B;
@@ -2713,6 +2722,19 @@ extern "C" int sisr_conv3x3_c64_geo(const float* x, const int64_t* xview, const 
     lb = 4 * HALO_W * 64 * sizeof(float);
   }
   hipStream_t st = (hipStream_t)stream;
+  if (mode == 3) {  // 2-row tiles, 5 x 66-pixel halo
+    p.tiles_h = (H + 1) / 2;
+    g = dim3((unsigned)((long)p.tiles_w * p.tiles_h * B), p.cout_chunks);
+    lb = 5 * 66 * 64 * sizeof(float);
+    if (ksel == 4) {
+      SISR_ALLOW_LDS((conv3x3_c64_v4_kernel<false, false, false, 1, false, false, false, 4, 0, true, true>), lb);
+      hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, 1, false, false, false, 4, 0, true, true>), g, dim3(256), lb, st, p);
+    } else {
+      SISR_ALLOW_LDS((conv3x3_c64_v4_kernel<false, false, false, 1, false, false, false, 0, 0, true, true>), lb);
+      hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, 1, false, false, false, 0, 0, true, true>), g, dim3(256), lb, st, p);
+    }
+    return sisr_check_launch();
+  }
 #define V4G(MTV, KS) hipLaunchKernelGGL((conv3x3_c64_v4_kernel<false, false, false, MTV, false, false, false, KS, 0, true>), g, dim3(256), lb, st, p)
   if (ksel == 5) { if (small) V4G(1, 5); else V4G(2, 5); }
   else if (ksel == 4) { if (small) V4G(1, 4); else V4G(2, 4); }

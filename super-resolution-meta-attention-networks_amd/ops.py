@@ -1970,6 +1970,25 @@ class _ReflConv(Function):
             ctx.geom = (B, H, W, Cp, cop, Hv, Wv, up, stride)
             return y
         Hp, Wp = up * H + 2, up * W + 2
+        ctx.s2 = REFL_GEO and stride == 2 and up == 1 and PRECISION == "fp32"
+        if ctx.s2:
+            # the stride-2 conv computed at its output pixels (a quarter of the stride-1 arithmetic, no gathers).  The backward
+            # pass still runs on the padded geometry: it rebuilds the padded map there instead of keeping it
+            wp = _pad_oihw(weight, cop, Cp)
+            bp = _pad_oihw(bias.reshape(co, 1), cop, 1).reshape(cop) if bias is not None else None
+            if ctx.needs_input_grad[0]:
+                pf, ctx.pd = pack_pair(wp)
+            else:
+                pf, ctx.pd = pack_weight(wp, "fwd"), None
+            Ho, Wo = (H + 1) // 2, (W + 1) // 2
+            y = _empty_cl(B, cop, Ho, Wo, dev)
+            hip.check(L.sisr_conv3x3_c64_geo(hip.ptr(x), hip.view_plain(H, W, Cp), _wptr(pf), hip.ptr(bp), hip.ptr(y),
+                                             hip.view_plain(Ho, Wo, cop), None, B, H, W, Cp, cop, 3, 0,
+                                             ci if Cp == 64 else 0, hip.stream()), "sisr_conv3x3_c64_geo(stride 2)")
+            ctx.save_for_backward(x, weight)
+            ctx.bias = bias
+            ctx.geom = (B, H, W, Cp, cop, Hp, Wp, up, stride)
+            return y
         xp = _empty_cl(B, Cp, Hp, Wp, dev)
         hip.check(L.sisr_pad_reflect_up(hip.ptr(x), hip.ptr(xp), B, H, W, Cp, up, 0, hip.stream()), "sisr_pad_reflect_up")
         wp = _pad_oihw(weight, cop, Cp)
@@ -2051,6 +2070,10 @@ class _ReflConv(Function):
                 else:
                     wgrad()
             return dx, dw, db, None, None
+        if ctx.s2:
+            x = xp
+            xp = _empty_cl(B, Cp, Hp, Wp, dev)
+            hip.check(L.sisr_pad_reflect_up(hip.ptr(x), hip.ptr(xp), B, H, W, Cp, up, 0, hip.stream()), "sisr_pad_reflect_up")
         dyf = _empty_cl(B, cop, Hp, Wp, dev)
         hip.check(L.sisr_crop_stride(hip.ptr(dy), hip.ptr(dyf), B, Hp, Wp, cop, stride, 1, hip.stream()), "sisr_crop_stride(embed)")
         dx = dw = db = None
