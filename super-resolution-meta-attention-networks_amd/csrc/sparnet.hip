@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void crop_stride_kernel(const f32x4* __restric
 // x: [npix][C] (C = 64 or 128 ... multiple of 64, at most SP_MAXC).  A workgroup = (C / 4) channel lanes x (1024 / C) pixel
 // lanes; workgroup k owns pixels [k * chunk, (k + 1) * chunk).
 #define SP_MAXC 256
-#define SP_MAXBLK 64
+#define SP_MAXBLK 256
 
 // z = x * sc + sh, the pre-activation value of the forward.  The backward needs its SIGN (the LeakyReLU mask) and must get the
 // forward's: a value recomputed as xhat * gamma + beta rounds differently, and an element within an ulp of zero then takes
@@ -133,6 +133,38 @@ __device__ __forceinline__ float sp_sum_parts(const float* __restrict__ part, in
   return s;
 }
 
+// The same sums for every channel of the map, by the whole 256-thread workgroup: C <= 256 channels x J = 256 / C slices, slice j
+// adds partials j, j + J, ... (sixteen loads in flight each), the J slice sums are then added in slice order.  out[c] (LDS) holds
+// the result after the closing barrier; tmp: 256 floats of LDS.  With up to 256 partials per launch a lone thread per channel
+// would walk them in sixteen dependent rounds (~10 us before every consumer's real work).
+__device__ __forceinline__ void sp_sum_parts_wg(const float* __restrict__ part, int n, long stride, int C, float* out, float* tmp) {
+  const int J = 256 / C > 0 ? 256 / C : 1;
+  for (int c0 = 0; c0 < C; c0 += 256) {  // (one trip: C <= SP_MAXC = 256)
+    const int c = c0 + (int)threadIdx.x % (C < 256 ? C : 256), j = (int)threadIdx.x / (C < 256 ? C : 256);
+    float s = 0.f;
+    if (j < J && c < C) {
+      int k = j;
+      for (; k + 15 * J < n; k += 16 * J) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = part[(long)(k + u * J) * stride + c];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += t[u];
+      }
+      for (; k < n; k += J) s += part[(long)k * stride + c];
+    }
+    __syncthreads();
+    tmp[threadIdx.x] = s;
+    __syncthreads();
+    if (j == 0 && c < C) {
+      float r = tmp[threadIdx.x];
+      for (int q = 1; q < J; ++q) r += tmp[threadIdx.x + q * C];
+      out[c] = r;
+    }
+  }
+  __syncthreads();
+}
+
 // MODE 0: sum of x.  MODE 1: sum of (x - mean)^2, mean from the MODE-0 partials (every workgroup adds them in index order).
 // MODE 2 (backward): sums of dz and dz * xhat,  dz = dy * act'(xhat * gamma + beta).
 template <int MODE>
@@ -147,9 +179,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   const int c4 = threadIdx.x % c4n, row = threadIdx.x / c4n;
   const int nblk = gridDim.x;
   if (MODE == 1) {
-    for (int c = threadIdx.x; c < C; c += 256) {
-      stat[c] = sp_sum_parts(part_in, nblk, C, c) / (float)npix;
-    }
+    sp_sum_parts_wg(part_in, nblk, C, C, stat, red);
+    for (int c = threadIdx.x; c < C; c += 256) stat[c] = stat[c] / (float)npix;
     __syncthreads();
   }
   f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, i4 = m4, sc4 = m4, sh4 = m4;
@@ -206,11 +237,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
                                                        float momentum, float eps, float slope, long npix, int C, int C_real) {
   __shared__ __attribute__((aligned(16))) float sc[SP_MAXC], sh[SP_MAXC];
+  __shared__ float tmp[256];
+  if (TRAIN) {  // sums of x and of the centred squares, parked in sc / sh until the coefficients replace them
+    sp_sum_parts_wg(part_sum, nblk, C, C, sc, tmp);
+    sp_sum_parts_wg(part_sq, nblk, C, C, sh, tmp);
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
     float mean, var;
     if (TRAIN) {
-      mean = sp_sum_parts(part_sum, nblk, C, c) / (float)npix;
-      var = sp_sum_parts(part_sq, nblk, C, c) / (float)npix;
+      mean = sc[c] / (float)npix;
+      var = sh[c] / (float)npix;
     } else {
       mean = c < C_real ? running_mean[c] : 0.f;
       var = c < C_real ? running_var[c] : 1.f;
@@ -251,8 +287,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float slope,
                                                            long npix, int C, int C_real) {
   __shared__ __attribute__((aligned(16))) float s1[SP_MAXC], s2[SP_MAXC], mn[SP_MAXC], iv[SP_MAXC], gm[SP_MAXC], sc[SP_MAXC], sh[SP_MAXC];
+  __shared__ float tmp[256];
+  sp_sum_parts_wg(part, nblk, 2L * C, C, s1, tmp);
+  sp_sum_parts_wg(part + C, nblk, 2L * C, C, s2, tmp);
   for (int c = threadIdx.x; c < C; c += 256) {
-    const float a = sp_sum_parts(part, nblk, 2L * C, c), b = sp_sum_parts(part + C, nblk, 2L * C, c);
+    const float a = s1[c], b = s2[c];
     if (blockIdx.x == 0 && c < C_real) {
       dbeta[c] = a;
       dgamma[c] = b;
@@ -280,6 +319,171 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       dz[e] = gm[c] * iv[c] * (d - s1[c] - xh * s2[c]);
     }
     reinterpret_cast<f32x4*>(dx)[i] = dz;
+  }
+}
+
+// ---- maps of at most 4 K pixels (SPARNet at 16 images: everything from 16^2 pixels down, 149 of the 187 batch norms of a
+// step), ONE launch per direction: a workgroup owns four channels and keeps its pixels (16 float4 per thread, NT = 256 or
+// 1024 threads) in registers through both statistics passes and the apply pass -- the same two-pass arithmetic as the partial-sum
+// kernels above without their three (two) dependent launches of 7 - 15 us each, no workspace, no cross-workgroup step.
+// Sums: per thread in pixel order, lanes by xor-shuffles (32, 16, .., 1), waves in wave order: fixed, independent of timing.
+template <int NT>
+__device__ __forceinline__ f32x4 sp_block_sum(f32x4 v, float* red /* [NT / 64][4] */) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o);
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();  // red is free again
+  if ((threadIdx.x & 63) == 0) *reinterpret_cast<f32x4*>(red + wave * 4) = v;
+  __syncthreads();
+  f32x4 s = *reinterpret_cast<const f32x4*>(red);
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) s += *reinterpret_cast<const f32x4*>(red + w * 4);
+  return s;
+}
+
+template <int NT, int PX>
+__global__ __launch_bounds__(NT) void bn_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                          float momentum, float eps, float slope, int npix, int C, int C_real) {
+  __shared__ __attribute__((aligned(16))) float red[(NT / 64) * 4];
+  const int c0 = blockIdx.x * 4;
+  // buffer addressing: a pixel's byte offset is two vector instructions where it is used, not a 64-bit address kept per pixel
+  const sisr_rsrc_t rx = sisr_rsrc(x), ry = sisr_rsrc(y);
+  auto pix_off = [&](int p) { return (unsigned)(min(p, npix - 1) * C + c0) * 4u; };
+  f32x4 v[PX];
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    const int p = threadIdx.x + k * NT;
+    v[k] = sisr_keep_if(sisr_buf_load4(rx, pix_off(p), 0u), p < npix);
+  }
+#pragma unroll
+  for (int k = 0; k < PX; ++k) a += v[k];
+  const f32x4 mean = sp_block_sum<NT>(a, red) / (float)npix;
+  f32x4 q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    if (threadIdx.x + k * NT < npix) {
+      const f32x4 d = v[k] - mean;
+      q += d * d;
+    }
+  }
+  const f32x4 var = sp_block_sum<NT>(q, red) / (float)npix;
+  f32x4 sc, sh;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c0 + e;
+    const float inv = 1.f / sqrtf(var[e] + eps);
+    if (threadIdx.x == 0) {
+      mean_out[c] = mean[e];
+      invstd_out[c] = inv;
+      if (running_mean && c < C_real) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[e];
+        const float unbiased = npix > 1 ? var[e] * ((float)npix / (float)(npix - 1)) : var[e];
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
+    }
+    float s_, t_;
+    sp_bn_coeffs(c < C_real ? gamma[c] : 0.f, c < C_real ? beta[c] : 0.f, mean[e], inv, s_, t_);
+    sc[e] = s_;
+    sh[e] = t_;
+  }
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    const int p = threadIdx.x + k * NT;
+    if (p < npix) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = sp_bn_z(v[k][e], sc[e], sh[e]);
+        o[e] = z > 0.f ? z : z * slope;
+      }
+      sisr_buf_store4(o, ry, pix_off(p), 0u);
+    }
+  }
+}
+
+// KEEP: dy stays in registers too (16 pixels per thread: 128 + 64 registers); else it is read again for the apply pass (32 pixels per
+// thread)
+template <int NT, int PX, bool KEEP>
+__global__ __launch_bounds__(NT) void bn_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean_in, const float* __restrict__ invstd_in,
+                                                          float* __restrict__ dx, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, float slope, int npix, int C, int C_real) {
+  __shared__ __attribute__((aligned(16))) float red[(NT / 64) * 4];
+  const int c0 = blockIdx.x * 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const sisr_rsrc_t rx = sisr_rsrc(x), rdy = sisr_rsrc(dy), rdx = sisr_rsrc(dx);
+  auto pix_off = [&](int p) { return (unsigned)(min(p, npix - 1) * C + c0) * 4u; };
+  f32x4 v[PX], d[KEEP ? PX : 1];
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    const int p = threadIdx.x + k * NT;
+    v[k] = sisr_keep_if(sisr_buf_load4(rx, pix_off(p), 0u), p < npix);
+    if (KEEP) d[k] = sisr_keep_if(sisr_buf_load4(rdy, pix_off(p), 0u), p < npix);
+  }
+  f32x4 m4, i4, g4, sc, sh;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c0 + e;
+    m4[e] = mean_in[c];
+    i4[e] = invstd_in[c];
+    g4[e] = c < C_real ? gamma[c] : 0.f;
+    float s_, t_;
+    sp_bn_coeffs(g4[e], c < C_real ? beta[c] : 0.f, m4[e], i4[e], s_, t_);
+    sc[e] = s_;
+    sh[e] = t_;
+  }
+  auto masked = [&](f32x4 dz, const f32x4& xv) {  // dy * LeakyReLU'(forward pre-activation), the forward's own sign test
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (!(sp_bn_z(xv[e], sc[e], sh[e]) > 0.f)) dz[e] *= slope;
+    return dz;
+  };
+  f32x4 a = z4, a2 = z4;
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    const int p = threadIdx.x + k * NT;
+    if (p < npix) {
+      const f32x4 xh = (v[k] - m4) * i4;
+      const f32x4 dz = masked(KEEP ? d[k] : sisr_buf_load4(rdy, pix_off(p), 0u), v[k]);
+      if (KEEP) d[k] = dz;
+      a += dz;
+      a2 += dz * xh;
+    }
+    if (!KEEP && (k & 7) == 7) asm volatile("" ::: "memory");  // eight re-reads in flight, not all 32 (256 registers per wave)
+  }
+  const f32x4 sa = sp_block_sum<NT>(a, red);
+  const f32x4 sb = sp_block_sum<NT>(a2, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c0 + e < C_real) {
+        dbeta[c0 + e] = sa[e];
+        dgamma[c0 + e] = sb[e];
+      }
+  }
+  const f32x4 s1 = sa / (float)npix, s2 = sb / (float)npix;
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    const int p = threadIdx.x + k * NT;
+    if (p < npix) {
+      const f32x4 dz = KEEP ? d[k] : masked(sisr_buf_load4(rdy, pix_off(p), 0u), v[k]);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (v[k][e] - m4[e]) * i4[e];
+        o[e] = g4[e] * i4[e] * (dz[e] - s1[e] - xh * s2[e]);
+      }
+      sisr_buf_store4(o, rdx, pix_off(p), 0u);
+    }
+    if (!KEEP && (k & 7) == 7) asm volatile("" ::: "memory");
   }
 }
 
@@ -312,6 +516,11 @@ extern "C" int sisr_bn_act_fwd(const float* x, float* y, const float* gamma, con
     return sisr_check_launch();
   }
   if (!mean_out || !invstd_out || !workspace || workspace_bytes < sisr_bn_workspace_bytes(npix, C)) return SISR_ERR_ARG;
+  if (npix <= 256 * 16) {
+    hipLaunchKernelGGL((bn_small_fwd_kernel<256, 16>), dim3(C / 4), dim3(256), 0, st, x, y, gamma, beta, running_mean, running_var,
+                       mean_out, invstd_out, momentum, eps, slope, (int)npix, C, C_real);
+    return sisr_check_launch();
+  }
   int nblk;
   long chunk;
   sp_bn_geometry(npix, C, &nblk, &chunk);
@@ -334,6 +543,11 @@ extern "C" int sisr_bn_act_bwd(const float* x, const float* dy, const float* gam
     return SISR_ERR_ARG;
   if (!sisr_aligned16(x) || !sisr_aligned16(dy) || !sisr_aligned16(dx)) return SISR_ERR_ALIGN;
   hipStream_t st = (hipStream_t)stream;
+  if (npix <= 256 * 16) {
+    hipLaunchKernelGGL((bn_small_bwd_kernel<256, 16, true>), dim3(C / 4), dim3(256), 0, st, x, dy, gamma, beta, mean, invstd, dx, dgamma,
+                       dbeta, slope, (int)npix, C, C_real);
+    return sisr_check_launch();
+  }
   int nblk;
   long chunk;
   sp_bn_geometry(npix, C, &nblk, &chunk);
