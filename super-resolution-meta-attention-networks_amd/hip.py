@@ -237,8 +237,9 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"(or csrc/build.sh).  This package has no CPU or PyTorch fallback.")
         L = ctypes.CDLL(LIB_PATH)
+        lenient = "SISR_HIP_LIB" in os.environ  # an A/B or diagnostic build named explicitly may predate newer entry points
         for name, (res, args) in list(_SIGS.items()) + list(OPTIONAL_SIGS.items()):
-            if name in OPTIONAL_SIGS and not hasattr(L, name):
+            if (name in OPTIONAL_SIGS or lenient) and not hasattr(L, name):
                 continue
             fn = getattr(L, name)
             fn.restype = res
