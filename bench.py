@@ -37,6 +37,8 @@ Extra objects on the JSON line:
   meta_edsr     N=1 default run only: BASELINE config 3 (QEDSR = EDSR-baseline + a meta-attention layer per block), 32 tiles.
   b1_point      N=1 default run only: ONE tile per step (the per-GPU batch SURVEY 8 puts configs 2 and 3 at, and the batch
                 cpu_baseline is timed at): RCAN and QEDSR, forward+backward replayed from a hipGraph.
+  sparnet       N=1 default run only: SURVEY 8 row f4, the default SPARNet plan at 16 images of 128 x 128 per step (hipGraph
+                replay), images/s.
   overlapped_grad_exchange   N > 1 default run only: the same workload with the replay's gradient exchange overlapped with its
                 backward (opt-in SISR_GRAPH_OVERLAP=1), measured last under a watchdog; config.grad_exchange names the mode
                 the headline ran.
@@ -526,6 +528,16 @@ def main():
             out[wl] = point(s, 1, what + ", ONE 128x128 tile per step, forward+backward replayed from a hipGraph", True)
         return out
 
+    def sparnet_point():
+        # SURVEY 8 row f4 ("then SPARNet"): the default SPARNet plan, 16 face images of 128 x 128 per step (input and output both at
+        # HR size), forward + backward replayed from a hipGraph; images/s, with the fraction of the fp32 matrix peak beside it
+        s = measure(sisr, "sparnet", 16, max(2, min(2 * args.steps, 40)), max(min(args.warmup, 3), 5 if args.warmup else 0), True,
+                    rank, world, local, dev)
+        p = point(s, 16, "SPARNet (default plan: 32 / 64 / 128 features, 10 body blocks, hourglass attention), 16 images of 128x128, "
+                         "train step (fwd + L1 + bwd + Adam)", True)
+        p["unit"] = "images/s"
+        return p
+
     if aux:
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -543,6 +555,7 @@ def main():
         guarded("han_bf16", han_bf16)
         guarded("meta_edsr", meta_edsr)
         guarded("b1_point", b1_point)
+        guarded("sparnet", sparnet_point)
         guarded("inference", lambda: measure_eval(sisr, "rcan", 32, max(2, min(args.steps, 10)), min(args.warmup, 3), local, dev))
 
         def bf16x3():
