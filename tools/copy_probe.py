@@ -18,14 +18,17 @@ torch.manual_seed(8)
 h = sisr_amd.available_models[name](device=0, model_save_dir="/tmp", eval_mode=False, scale=4, lr=1e-4, **kw)
 x, y = torch.rand(B, 3, 128, 128).cuda(), torch.rand(B, 3, 512, 512).cuda()
 extra = {"extra_channels": (torch.rand(B, 10, 1, 1) * 0.4).cuda()} if name.startswith("q") else {}
-if len(sys.argv) > 3:  # one-rank RCCL world, as bench.py --force-dp
+if len(sys.argv) > 3 and sys.argv[3] == "dp":  # one-rank RCCL world, as bench.py --force-dp
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     h.set_multi_gpu()
-for _ in range(2):
-    h.train_step(x, y, **extra)
+graph = len(sys.argv) > 4 and sys.argv[4] == "graph"  # profile the CAPTURE pass: its aten ops are the replay's nodes
+h.use_graph = graph
+if not graph:
+    for _ in range(2):
+        h.train_step(x, y, **extra)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     h.train_step(x, y, **extra)
@@ -45,5 +48,5 @@ for ev in prof.events():
 for (n, shp, s), c in by.most_common(40):
     print(c, n, shp, s)
 print("---- device activities")
-for n, c in kern.most_common(30):
+for n, c in kern.most_common(60):
     print(c, n)
