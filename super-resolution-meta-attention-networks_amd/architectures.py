@@ -45,10 +45,11 @@ def conv_weights(net):
                 if w.shape[0] == 64 * r * r and w.shape[1] % 64 == 0 and id(w) not in seen:
                     out.append((w, r))
                     seen.add(id(w))
+    any_width = getattr(net, "pack_padded_convs", False)  # SPARNet: maps zero-padded to 64-multiples, weights packed likewise
     for m in net.modules():
         if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.groups == 1 and id(m.weight) not in seen:
             w = m.weight
-            if w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
+            if (w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0) or any_width:
                 out.append((w, 1))
                 seen.add(id(w))
     return out

@@ -2252,6 +2252,7 @@ struct PackJob {
   void* pf;
   void* pd;
   int cout, cin, r, first_block;
+  int co_real, ci_real;  // > 0: w is (co_real, ci_real, 3, 3) and is packed as its zero-padded (cout, cin, 3, 3) twin (SPARNet)
 };
 
 template <int MODE>  // 0 fp32, 1 bf16, 2 bf16x3 (three planes `total` elements apart)
@@ -2267,8 +2268,16 @@ __global__ __launch_bounds__(256) void pack_conv3x3_many_kernel(const PackJob* _
   }
   __syncthreads();
   const PackJob jb = jobs[job_s];
-  const float* __restrict__ w = jb.w;
+  const float* __restrict__ wsrc = jb.w;
   const int cout = jb.cout, cin = jb.cin, r = jb.r;
+  const int cor = jb.co_real > 0 ? jb.co_real : cout, cir = jb.ci_real > 0 ? jb.ci_real : cin;
+  // element (o, i, tap) of the (zero-padded) weight; the index expression the packings below were written with
+  struct Src {
+    const float* __restrict__ p;
+    int cor, cir;
+    __device__ float at(long o, long i, int t) const { return (o < cor && i < cir) ? p[(o * cir + i) * 9 + t] : 0.f; }
+  };
+  const Src w{wsrc, cor, cir};
   const long total = (long)cout * cin * 9;
   const long idx = (long)(blockIdx.x - jb.first_block) * 256 + threadIdx.x;
   if (idx >= total) return;
@@ -2293,13 +2302,13 @@ __global__ __launch_bounds__(256) void pack_conv3x3_many_kernel(const PackJob* _
       const int c = t_ % ic, q = t_ / ic;
       const long o = r > 1 ? (long)n * rr + q : (long)q * 64 + n;
       const long i = (long)c * 64 + k8;
-      pf[idx] = w[(o * cin + i) * 9 + t];
+      pf[idx] = w.at(o, i, t);
     }
     {
       const int c = t_ % oc, q = t_ / oc;
       const long i = (long)q * 64 + n;
       const long o = r > 1 ? (long)k8 * rr + c : (long)c * 64 + k8;
-      pd[idx] = w[(o * cin + i) * 9 + (8 - t)];
+      pd[idx] = w.at(o, i, 8 - t);
     }
   } else {
     __bf16* pf = static_cast<__bf16*>(jb.pf);
@@ -2319,15 +2328,15 @@ __global__ __launch_bounds__(256) void pack_conv3x3_many_kernel(const PackJob* _
       const int c = t_ % ic, q = t_ / ic;
       const long o = r > 1 ? (long)n * rr + q : (long)q * 64 + n;
       const long i = (long)c * 64 + k;
-      if (MODE == 2) sisr_store_w3(pf, idx, total, w[(o * cin + i) * 9 + t]);
-      else pf[idx] = (__bf16)w[(o * cin + i) * 9 + t];
+      if (MODE == 2) sisr_store_w3(pf, idx, total, w.at(o, i, t));
+      else pf[idx] = (__bf16)w.at(o, i, t);
     }
     {
       const int c = t_ % oc, q = t_ / oc;
       const long i = (long)q * 64 + n;
       const long o = r > 1 ? (long)k * rr + c : (long)c * 64 + k;
-      if (MODE == 2) sisr_store_w3(pd, idx, total, w[(o * cin + i) * 9 + (8 - t)]);
-      else pd[idx] = (__bf16)w[(o * cin + i) * 9 + (8 - t)];
+      if (MODE == 2) sisr_store_w3(pd, idx, total, w.at(o, i, 8 - t));
+      else pd[idx] = (__bf16)w.at(o, i, 8 - t);
     }
   }
 }

@@ -225,23 +225,28 @@ class _PackPlan:
         self.items = [(w, int(r)) for w, r in weights]
         self.ptrs = [w.data_ptr() for w, _ in self.items]
         planes = 3 if PRECISION == "bf16x3" else 1
-        total = planes * sum(w.numel() for w, _ in self.items)
+        # a weight whose channel counts are not multiples of 64 (SPARNet) is packed as its zero-padded twin, same launch
+        padded = [(_pad64(w.shape[0]), _pad64(w.shape[1])) for w, _ in self.items]
+        numel = [co * ci * 9 for co, ci in padded]
+        total = planes * sum(numel)
         dt = torch.float32 if PRECISION == "fp32" else torch.bfloat16
         self.fwd = torch.empty(total, device=device, dtype=dt)
         self.dgrad = torch.empty(total, device=device, dtype=dt)
         esz = self.fwd.element_size()
         jobs = np.zeros(len(self.items), dtype=[("w", "<u8"), ("pf", "<u8"), ("pd", "<u8"), ("cout", "<i4"),
-                                                ("cin", "<i4"), ("r", "<i4"), ("first", "<i4")])
+                                                ("cin", "<i4"), ("r", "<i4"), ("first", "<i4"), ("co_real", "<i4"),
+                                                ("ci_real", "<i4")])
         assert jobs.dtype.itemsize == hip.lib().sisr_pack_job_bytes()
         off = blocks = 0
         self.slices = []
         for k, (w, r) in enumerate(self.items):
-            n = planes * w.numel()
-            jobs[k] = (w.data_ptr(), self.fwd.data_ptr() + off * esz, self.dgrad.data_ptr() + off * esz, w.shape[0],
-                       w.shape[1], r, blocks)
+            n = planes * numel[k]
+            real = (w.shape[0], w.shape[1]) if padded[k] != (w.shape[0], w.shape[1]) else (0, 0)
+            jobs[k] = (w.data_ptr(), self.fwd.data_ptr() + off * esz, self.dgrad.data_ptr() + off * esz, padded[k][0],
+                       padded[k][1], r, blocks, real[0], real[1])
             self.slices.append((self.fwd[off:off + n], self.dgrad[off:off + n]))
             off += n
-            blocks += (w.numel() + 255) // 256
+            blocks += (numel[k] + 255) // 256
         self.blocks = blocks
         self.jobs = torch.from_numpy(jobs.view(np.uint8)).to(device)
 
@@ -1920,6 +1925,18 @@ def nchw_to_nhwc_pad(x, cp=None):
 
 
 # ----------------------------------------------------------------------------- SPARNet pieces (csrc/sparnet.hip)
+def _padded_packs(weight, cop, cip, need_dgrad):
+    """(forward packing, input-gradient packing | None) of `weight` zero-padded to (cop, cip, 3, 3): the step-level packing
+    when the handler has run pack_all (the padding is part of that one launch), else pad + pack here."""
+    hit = _step_pack(weight, 1)
+    if hit is not None and hit[0].numel() == cop * cip * 9:
+        return hit[0], (hit[1] if need_dgrad else None)
+    wp = _pad_oihw(weight, cop, cip)
+    if need_dgrad:
+        return pack_pair(wp)
+    return pack_weight(wp, "fwd"), None
+
+
 # SPARNet's stride-1 ConvLayer convs with reflection / nearest upsampling inside the MFMA kernels' staging (0: the gather ->
 # conv -> gather composition of round 3, kept for the stride-2 convs and as the A/B reference; results are bit-identical)
 REFL_GEO = os.environ.get("SISR_REFL_GEO", "1") != "0"
@@ -1955,12 +1972,8 @@ class _ReflConv(Function):
             # throw-away outputs, no crop (csrc/conv3x3_mfma.hip GEO); channels >= ci of a 64-channel input are zero padding
             # and their octets of the K loop are skipped
             Hv, Wv = up * H, up * W
-            wp = _pad_oihw(weight, cop, Cp)
+            pf, ctx.pd = _padded_packs(weight, cop, Cp, ctx.needs_input_grad[0])
             bp = _pad_oihw(bias.reshape(co, 1), cop, 1).reshape(cop) if bias is not None else None
-            if ctx.needs_input_grad[0]:
-                pf, ctx.pd = pack_pair(wp)
-            else:
-                pf, ctx.pd = pack_weight(wp, "fwd"), None
             y = _empty_cl(B, cop, Hv, Wv, dev)
             hip.check(L.sisr_conv3x3_c64_geo(hip.ptr(x), hip.view_plain(H, W, Cp), _wptr(pf), hip.ptr(bp), hip.ptr(y),
                                              hip.view_plain(Hv, Wv, cop), None, B, Hv, Wv, Cp, cop, 1, up - 1,
@@ -1974,12 +1987,8 @@ class _ReflConv(Function):
         if ctx.s2:
             # the stride-2 conv computed at its output pixels (a quarter of the stride-1 arithmetic, no gathers).  The backward
             # pass still runs on the padded geometry: it rebuilds the padded map there instead of keeping it
-            wp = _pad_oihw(weight, cop, Cp)
+            pf, ctx.pd = _padded_packs(weight, cop, Cp, ctx.needs_input_grad[0])
             bp = _pad_oihw(bias.reshape(co, 1), cop, 1).reshape(cop) if bias is not None else None
-            if ctx.needs_input_grad[0]:
-                pf, ctx.pd = pack_pair(wp)
-            else:
-                pf, ctx.pd = pack_weight(wp, "fwd"), None
             Ho, Wo = (H + 1) // 2, (W + 1) // 2
             y = _empty_cl(B, cop, Ho, Wo, dev)
             hip.check(L.sisr_conv3x3_c64_geo(hip.ptr(x), hip.view_plain(H, W, Cp), _wptr(pf), hip.ptr(bp), hip.ptr(y),

@@ -253,6 +253,7 @@ class _count_batches:
 
 class SPARNet(nn.Module):
     """ref: architectures.py:7-76"""
+    pack_padded_convs = True  # architectures.conv_weights: every 3x3 weight rides in the step's one packing launch, zero-padded
 
     def __init__(self, min_ch=32, max_ch=128, in_size=128, out_size=128, min_feat_size=16, res_depth=10,
                  relu_type='leakyrelu', norm_type='bn', att_name='spar', bottleneck_size=4, **kwargs):
@@ -270,6 +271,7 @@ class SPARNet(nn.Module):
 
 class QSPARNet(nn.Module):
     """ref: architectures.py:79-155"""
+    pack_padded_convs = True
 
     def __init__(self, min_ch=32, max_ch=128, in_size=128, out_size=128, min_feat_size=16, res_depth=10,
                  relu_type='leakyrelu', norm_type='bn', att_name='spar', bottleneck_size=4, metadata_count=None,
