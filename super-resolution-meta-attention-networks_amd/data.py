@@ -191,7 +191,7 @@ class DeviceTileLoader:
                     hr.append(to_tensor(read_image(os.path.join(d.hr_base, base_name))))
                     self.tags.append(base_name)
                     self.hr_tags.append(base_name)
-                    meta.append(None)
+                    meta.append(d.metadata[i] if d.metadata is not None else None)  # file metadata, by HR name (ref :265)
                     self.degraders.append(d.degrader)
                 continue
             for i in range(len(d)):
@@ -235,12 +235,12 @@ class DeviceTileLoader:
                     lr_dev, code, kernel, (top, left, rh, rw) = self.degraders[i](hr_full)
                     hr_c = hr_full if (rh, rw) == tuple(hr_full.shape[1:]) else hr_full[:, top:top + rh, left:left + rw].contiguous()
                     pairs.append((lr_dev.contiguous(), hr_c))
-                    codes.append(code.numpy())
+                    codes.append(code.numpy() if self.metadata[i] is None else np.concatenate((self.metadata[i], code.numpy())))
                     kernels.append(kernel.numpy().squeeze())
                 lr, hr = self.sampler.sample_pairs(pairs)
                 yield {'lr': lr, 'hr': hr, 'tag': [self.tags[i] for i in idx], 'hr_tag': [self.hr_tags[i] for i in idx],
                        'mask': zeros.clone(), 'halfway_data': zeros.clone(), 'metadata': torch.from_numpy(np.stack(codes)),
-                       'metadata_keys': [tuple(k for _ in range(B)) for k in self.metadata_keys],
+                       'metadata_keys': _collate_keys(self.metadata_keys, B),
                        'blur_kernels': torch.from_numpy(np.stack(kernels))}
                 continue
             lr, hr = self.sampler.sample(idx)
@@ -251,6 +251,12 @@ class DeviceTileLoader:
             yield {'lr': lr, 'hr': hr, 'tag': [self.tags[i] for i in idx], 'hr_tag': [self.hr_tags[i] for i in idx],
                    'mask': zeros.clone(), 'halfway_data': zeros.clone(), 'metadata': md,
                    'metadata_keys': [tuple(k for _ in range(B)) for k in self.metadata_keys], 'blur_kernels': zeros.clone()}
+
+
+def _collate_keys(keys, B):
+    """What torch's default_collate makes of B copies of a dataset's metadata_keys: a string becomes a B-tuple of itself, a
+    nested list of strings (the reference's kernel keys next to file metadata, see SuperResImages) a list of such tuples."""
+    return [_collate_keys(k, B) if isinstance(k, (list, tuple)) else tuple(k for _ in range(B)) for k in keys]
 
 
 def read_degradation_metadata(metadata_file, filenames):
@@ -308,8 +314,6 @@ class SuperResImages(Dataset):
             # built here, from 30 000 random kernels of numpy's global stream, before any file is listed
             if hr_dir is None:
                 raise RuntimeError('Cannot synthesize LR images without specifying HR images.')
-            if degradation_metadata_file is not None:
-                raise NotImplementedError('online degradations together with a metadata file are not built')
             from . import degrade
             self.degrader = degrade.OnlineDegrader(scale=scale, **(online_degradation_params or {}))
             self.lr_base, lr_dir = None, hr_dir
@@ -329,10 +333,20 @@ class SuperResImages(Dataset):
             raise RuntimeError('No images were supplied or all images were filtered out!')
         self.metadata, self.metadata_keys = None, []
         if degradation_metadata_file is not None:
-            table, self.metadata_keys = read_degradation_metadata(degradation_metadata_file, self.lr_filenames)
-            self.metadata = [table[n] for n in self.lr_filenames]
+            # ref :264-287: rows are looked up by LR file name, or -- with online degradations, where there are no LR files --
+            # by the HR (base) name
+            names = self.base_filenames if self.online_degradations else self.lr_filenames
+            table, self.metadata_keys = read_degradation_metadata(degradation_metadata_file, names)
+            self.metadata = [table[n] for n in names]
         if self.online_degradations:
-            self.metadata_keys = ['blur_kernel'] * self.degrader.para_in  # ref :293-297
+            kernel_keys = ['blur_kernel'] * self.degrader.para_in
+            if len(self.metadata_keys) == 0:
+                self.metadata_keys = kernel_keys  # ref :293-295
+            else:
+                # ref :296-297 APPENDS the list as ONE element (keys = [k1, .., kn, ['blur_kernel', ...]]): a sample's vector
+                # is file metadata + kernel code, but the kernel code's entries have no key of their own, so a model that
+                # selects 'blur_kernel' by key finds none of them.  Kept as the reference has it (traps).
+                self.metadata_keys = list(self.metadata_keys) + [kernel_keys]
         self.image_count = len(self.lr_filenames)
         print('Initialized %s data with %d image%s.' % (dataset if dataset is not None else 'image', self.image_count,
                                                         's' if self.image_count > 1 else ''))
@@ -343,7 +357,7 @@ class SuperResImages(Dataset):
     def __getitem__(self, index):
         base_name, image_name = self.base_filenames[index], self.lr_filenames[index]
         if self.online_degradations:
-            return self._degraded_item(base_name)
+            return self._degraded_item(base_name, index)
         lr_im = read_image(os.path.join(self.lr_base, image_name))
         metadata = self.metadata[index] if self.metadata is not None else np.array(0)
         if self.hr_base is not None:
@@ -366,7 +380,7 @@ class SuperResImages(Dataset):
                 'halfway_data': np.array(0), 'metadata': metadata, 'metadata_keys': self.metadata_keys,
                 'blur_kernels': np.array(0)}
 
-    def _degraded_item(self, base_name):
+    def _degraded_item(self, base_name, index=None):
         """ref: data_handler.py:446-456 + the common tail of __getitem__: blur kernel drawn on the host (np.random), blur +
         quantisation + PIL bicubic on the device, kernel code as the sample's metadata, full kernel as 'blur_kernels'."""
         if not torch.cuda.is_available():
@@ -379,8 +393,11 @@ class SuperResImages(Dataset):
             lr_im, hr_im = random_flip_rotate(lr_im, hr_im)
         if self.patch_crop is not None:
             lr_im, hr_im = random_matched_crop(lr_im, hr_im, crop_size=self.patch_crop, scale=self.scale)
+        metadata = code.numpy()
+        if self.metadata is not None and index is not None:  # ref :451-452: file metadata first, then the kernel code
+            metadata = np.concatenate((self.metadata[index], metadata))
         return {'lr': lr_im, 'hr': hr_im, 'tag': base_name, 'hr_tag': base_name, 'mask': np.array(0),
-                'halfway_data': np.array(0), 'metadata': code.numpy(), 'metadata_keys': self.metadata_keys,
+                'halfway_data': np.array(0), 'metadata': metadata, 'metadata_keys': self.metadata_keys,
                 'blur_kernels': kernel.numpy().squeeze()}
 
 

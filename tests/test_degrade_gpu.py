@@ -83,6 +83,36 @@ def test_dataset_with_online_degradations_yields_the_reference_batch_schema(monk
         assert it["hr"].shape[1] == 4 * it["lr"].shape[1] and it["hr"].shape[2] == 4 * it["lr"].shape[2]
 
 
+def test_dataset_with_online_degradations_and_a_metadata_file(monkeypatch, tmp_path):
+    """ref: data_handler.py:264-297, :451-452: with online degradations the metadata file is looked up by HR name, a sample's
+    vector is [file metadata | kernel code], and the keys are the file's keys followed by the kernel keys AS ONE NESTED LIST
+    (the reference appends the list itself).  Same through the device tile loader, batched as default_collate would."""
+    import pandas as pd
+    real = D.pca_matrix
+    monkeypatch.setattr(D, "pca_matrix", lambda batch=2000, k=10: real(batch=2000, k=k))
+    hr_dir = os.path.join(GOLDEN, "set5", "hr")
+    names = sorted(os.listdir(hr_dir))
+    meta_file = tmp_path / "meta.csv"
+    pd.DataFrame({"QPI": [20 + 4 * i for i in range(len(names))]}, index=names).to_csv(meta_file)
+    np.random.seed(5)
+    ds = sisr_amd.data.SuperResImages(hr_dir=hr_dir, online_degradations=True, split="all", scale=4,
+                                      degradation_metadata_file=str(meta_file), random_crop=24)
+    assert ds.metadata_keys == ["qpi", ["blur_kernel"] * 10]
+    np.random.seed(7)
+    it = ds[1]
+    np.random.seed(7)
+    code = ds.degrader(torch.zeros(3, 64, 64).cuda())[1].numpy()  # the kernel draw only depends on the np.random stream
+    want_q = (20 + 4 * names.index(ds.base_filenames[1]) - 20) / 20.0
+    assert it["metadata"].shape == (11,) and abs(float(it["metadata"][0]) - want_q) < 1e-12
+    np.testing.assert_array_equal(it["metadata"][1:], code)
+    loader = sisr_amd.data.DeviceTileLoader([ds], batch_size=2, device=torch.device("cuda:0"))
+    batch = next(iter(loader))
+    assert tuple(batch["metadata"].shape) == (2, 11) and batch["metadata_keys"][0] == ("qpi", "qpi")
+    assert batch["metadata_keys"][1] == [("blur_kernel", "blur_kernel")] * 10
+    for row, tag in zip(batch["metadata"], batch["tag"]):
+        assert abs(float(row[0]) - 4 * names.index(tag) / 20.0) < 1e-12
+
+
 def test_online_degrader_with_noise_reproduces_the_reference():
     """ref: gaussian_utils.py:299-312, 371-424 (SRMDPreprocessing(noise=True, noise_high=0.08, rate_cln=0.2)): same seed and
     image as the fixture -- noise levels (one access drew a clean image, two a noisy one), 11-value codes and LR images."""
