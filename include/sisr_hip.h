@@ -463,6 +463,26 @@ typedef struct sisr_wgrad_geo_job {
 size_t sisr_wgrad_geo_job_bytes(void);
 size_t sisr_wgrad3x3_c64_geo_batch_workspace_bytes(const void* jobs, int njobs);
 int sisr_wgrad3x3_c64_geo_batch(const void* jobs, int njobs, float* workspace, size_t workspace_bytes, void* stream);
+/* Non-default ConvLayer options (ref: SPARNet/blocks.py:17-33 norm_type 'in' | 'gn' | 'pixel', :50-64 relu_type 'prelu' | 'selu',
+ * :147-151 att_name 'spar3d').  Maps NHWC, C a multiple of 4, channels >= C_real zero padding (written as zero).
+ * sisr_group_norm_fwd / _bwd: statistics per (sample, group of cg consecutive real channels) over hw pixels (InstanceNorm2d: cg = 1;
+ *   GroupNorm(32, C): cg = C / 32), biased variance, two passes; mean / invstd: [B][C_real / cg]; backward writes dx and the
+ *   per-sample sums dgamma_b, dbeta_b [B][C_real] (add them over the batch with sisr_sum_partials).
+ * sisr_pixel_norm: backward == 0: out = x / max(||x||_2 over the pixel's channels, 1e-12) (F.normalize(p = 2, dim = 1));
+ *   else out = dx from x and dy.  C / 4 a power of two <= 64.
+ * sisr_act: mode 0 PReLU (slope [C_real]), 1 SELU; backward == 0: out = act(x); else out = dx and, for PReLU, dyx = dy min(x, 0)
+ *   (its per-channel sum is the slope's gradient).
+ * sisr_spar3d: backward == 0: out0 = identity (nullable) + x sigmoid(logits); else (third argument = dy) out0 = dx = dy a,
+ *   out1 = dlogits = dy x a (1 - a); n elements (a multiple of 4). */
+int sisr_group_norm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* mean_out, float* invstd_out, int B,
+                        long hw, int C, int C_real, int cg, float eps, void* stream);
+int sisr_group_norm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* invstd, float* dx,
+                        float* dgamma_b, float* dbeta_b, int B, long hw, int C, int C_real, int cg, void* stream);
+int sisr_pixel_norm(const float* x, const float* dy, float* out, long npix, int C, int backward, void* stream);
+int sisr_act(const float* x, const float* dy, const float* slope, float* out, float* dyx, long npix, int C, int C_real, int mode,
+             int backward, void* stream);
+int sisr_spar3d(const float* x, const float* logits, const float* identity_or_dy, float* out0, float* out1, long n, int backward,
+                void* stream);
 /* sisr_nearest_up: nn.Upsample(scale_factor = up, 'nearest') on an NHWC map, up 1 .. 4 (ref: advanced/SRMD_blocks.py:58-63, the
  * 'upconv' tail of SRMD); adjoint != 0: the gradient summed back over the up x up replicas. */
 int sisr_nearest_up(const float* src, float* dst, int B, int H, int W, int C, int up, int adjoint, void* stream);

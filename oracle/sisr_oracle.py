@@ -793,15 +793,43 @@ META_NETS = META_NETS + ("sftmd",)
 # ref: SISR/models/SPARNet/blocks.py:10-243, SPARNet/architectures.py:7-155.  Batch norm: `training` selects batch
 # statistics (biased variance; the running statistics in `sd` are updated in place with momentum 0.1 and the unbiased
 # variance, as nn.BatchNorm2d does) or the running statistics.
-def _sp_conv_layer(sd, key, x, scale="none", norm=False, slope=1.0, training=True):
+def _sp_norm(sd, key, x, norm_type, training):
+    """ref: blocks.py:10-36 NormLayer (key = the NormLayer's prefix; its module is `.norm`)"""
+    if norm_type == "bn":
+        return _sp_bn(sd, key + ".norm", x, training)
+    if norm_type == "in":
+        return F.instance_norm(x, weight=sd[key + ".norm.weight"], bias=sd[key + ".norm.bias"], eps=1e-5)
+    if norm_type == "gn":
+        return F.group_norm(x, 32, sd[key + ".norm.weight"], sd[key + ".norm.bias"], 1e-5)
+    if norm_type == "pixel":
+        return F.normalize(x, p=2, dim=1)
+    if norm_type == "none":
+        return x
+    raise ValueError(norm_type)
+
+
+def _sp_act(sd, key, x, relu_type):
+    """ref: blocks.py:39-66 ReluLayer (key = the ReluLayer's prefix; PReLU's slopes are `.func.weight`)"""
+    if relu_type == "relu":
+        return F.relu(x)
+    if relu_type == "leakyrelu":
+        return F.leaky_relu(x, 0.2)
+    if relu_type == "prelu":
+        return F.prelu(x, sd[key + ".func.weight"])
+    if relu_type == "selu":
+        return F.selu(x)
+    if relu_type == "none":
+        return x
+    raise ValueError(relu_type)
+
+
+def _sp_conv_layer(sd, key, x, scale="none", norm="none", relu="none", training=True):
     """ref: blocks.py:69-103 ConvLayer.forward: [nearest x2] -> ReflectionPad2d(1) -> Conv2d(3x3, stride) -> norm -> relu."""
     if scale == "up":
         x = F.interpolate(x, scale_factor=2, mode="nearest")
     x = F.pad(x, (1, 1, 1, 1), mode="reflect")
     x = F.conv2d(x, sd[key + ".conv2d.weight"], sd.get(key + ".conv2d.bias"), stride=2 if scale == "down" else 1)
-    if norm:
-        x = _sp_bn(sd, key + ".norm.norm", x, training)
-    return x if slope == 1.0 else F.leaky_relu(x, slope)
+    return _sp_act(sd, key + ".relu", _sp_norm(sd, key + ".norm", x, norm, training), relu)
 
 
 def _sp_bn(sd, key, x, training):
@@ -809,16 +837,16 @@ def _sp_bn(sd, key, x, training):
                         training=training, momentum=0.1, eps=1e-5)
 
 
-def _sp_hourglass(sd, key, x, depth, slope, training):
-    """ref: blocks.py:177-243"""
+def _sp_hourglass(sd, key, x, depth, norm, relu, training):
+    """ref: blocks.py:177-243 (the attention map has one channel, 'spar', or one per feature, 'spar3d': the product broadcasts)"""
     if depth == 0:
         return x
 
     def level(lv, t):
-        up1 = _sp_conv_layer(sd, f"{key}.b1_{lv}", t, "none", True, slope, training)
-        low1 = _sp_conv_layer(sd, f"{key}.b2_{lv}", t, "down", True, slope, training)
-        low2 = level(lv - 1, low1) if lv > 1 else _sp_conv_layer(sd, f"{key}.b2_plus_{lv}", low1, "none", True, slope, training)
-        up2 = _sp_conv_layer(sd, f"{key}.b3_{lv}", low2, "up", True, slope, training)
+        up1 = _sp_conv_layer(sd, f"{key}.b1_{lv}", t, "none", norm, relu, training)
+        low1 = _sp_conv_layer(sd, f"{key}.b2_{lv}", t, "down", norm, relu, training)
+        low2 = level(lv - 1, low1) if lv > 1 else _sp_conv_layer(sd, f"{key}.b2_plus_{lv}", low1, "none", norm, relu, training)
+        up2 = _sp_conv_layer(sd, f"{key}.b3_{lv}", low2, "up", norm, relu, training)
         if up1.shape[2:] != up2.shape[2:]:
             up2 = F.interpolate(up2, up1.shape[2:])
         return up1 + up2
@@ -827,36 +855,39 @@ def _sp_hourglass(sd, key, x, depth, slope, training):
     return x * att
 
 
-def _sp_block(sd, key, x, scale, depth, slope, training, md=None):
+def _sp_block(sd, key, x, scale, depth, norm, relu, training, md=None):
     """ref: blocks.py:106-174 ResidualBlock.forward (metadata_attention when its parameters are present)"""
     identity = _sp_conv_layer(sd, key + ".shortcut_func", x, scale) if (key + ".shortcut_func.conv2d.weight") in sd else x
-    out = F.leaky_relu(_sp_bn(sd, key + ".preact_func.0.norm", x, training), slope)
+    out = _sp_act(sd, key + ".preact_func.1", _sp_norm(sd, key + ".preact_func.0", x, norm, training), relu)
     s1, s2 = {"down": ("none", "down"), "up": ("up", "none"), "none": ("none", "none")}[scale]
-    out = _sp_conv_layer(sd, key + ".conv1", out, s1, True, slope, training)
-    out = _sp_conv_layer(sd, key + ".conv2", out, s2, True, 1.0, training)
-    out = identity + _sp_hourglass(sd, key + ".att_func", out, depth, slope, training)
+    out = _sp_conv_layer(sd, key + ".conv1", out, s1, norm, relu, training)
+    out = _sp_conv_layer(sd, key + ".conv2", out, s2, norm, "none", training)
+    out = identity + _sp_hourglass(sd, key + ".att_func", out, depth, norm, relu, training)
     if md is not None and (key + ".metadata_attention.attribute_integrator.0.weight") in sd:
         out = para_ca_layer(sd, key + ".metadata_attention", out, md, True)
     return out
 
 
 def sparnet(sd, x, md=None, in_size=128, out_size=128, min_feat_size=16, res_depth=10, bottleneck_size=4, slope=0.2,
-            training=False):
+            training=False, norm_type="bn", relu_type=None):
     """ref: architectures.py:7-76 (SPARNet) / :79-155 (QSPARNet: md = (B, M, 1, 1) metadata).  Channel counts come from the
-    state dict; the layer plan (which blocks scale, the hourglass depths) from the size arguments as in the constructors."""
+    state dict; the layer plan (which blocks scale, the hourglass depths) from the size arguments as in the constructors.
+    relu_type None: LeakyReLU(0.2) / ReLU / none from `slope` (0.2 / 0 / 1), the round-3 signature."""
+    if relu_type is None:
+        relu_type = {0.2: "leakyrelu", 0.0: "relu", 1.0: "none"}[float(slope)]
     down_steps = int(np.log2(in_size // min_feat_size))
     up_steps = int(np.log2(out_size // min_feat_size))
     hg = int(np.log2(64 / bottleneck_size))
     out = _sp_conv_layer(sd, "encoder.0", x)
     for i in range(down_steps):
-        out = _sp_block(sd, f"encoder.{i + 1}", out, "down", hg, slope, training, md)
+        out = _sp_block(sd, f"encoder.{i + 1}", out, "down", hg, norm_type, relu_type, training, md)
         hg -= 1
     hg += 1
     for i in range(res_depth + 3 - down_steps):
-        out = _sp_block(sd, f"res_layers.{i}", out, "none", hg, slope, training, md)
+        out = _sp_block(sd, f"res_layers.{i}", out, "none", hg, norm_type, relu_type, training, md)
     for i in range(up_steps):
         hg += 1
-        out = _sp_block(sd, f"decoder.{i}", out, "up", hg, slope, training, md)
+        out = _sp_block(sd, f"decoder.{i}", out, "up", hg, norm_type, relu_type, training, md)
     return _sp_conv_layer(sd, "out_conv", out)
 
 

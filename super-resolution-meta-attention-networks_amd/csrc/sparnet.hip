@@ -700,3 +700,243 @@ extern "C" int sisr_spar_combine_bwd(const float* dy, const float* x, const floa
                      reinterpret_cast<f32x4*>(dlogits), c4n, C_logits >> 2, total);
   return sisr_check_launch();
 }
+
+// ================================================================================================ non-default ConvLayer options
+// ref: SPARNet/blocks.py:17-33 (norm_type 'in' = InstanceNorm2d(affine), 'gn' = GroupNorm(32, C), 'pixel' = F.normalize(x, p = 2,
+// dim = 1)), :50-64 (relu_type 'prelu' = PReLU(C), 'selu'), :147-151 (att_name 'spar3d': one attention map per channel).  The
+// reference's defaults (batch norm, LeakyReLU, one attention channel) are the fused kernels above; these options are plain
+// HBM-bound passes, one launch per direction, written for correctness first (maps of this network are small).
+//
+// Group statistics (instance norm: groups of one channel).  x, y: [B][HW][C]; group g of sample b = channels [g cg, (g + 1) cg)
+// over all HW pixels; C_real real channels (a multiple of cg), the padded ones are written as zero.  One workgroup per
+// (group, sample): mean, then centred squares (two passes, as torch), then the affine apply.  mean / invstd: [B][C_real / cg].
+__device__ __forceinline__ float sp_wg_sum(float v, float* red /* [4] */) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void group_norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ mean_out, float* __restrict__ invstd_out, long hw,
+                                                             int C, int C_real, int cg, float eps) {
+  __shared__ float red[4];
+  const int g = blockIdx.x, b = blockIdx.y, groups = C_real / cg;
+  const float* xb = x + (long)b * hw * C + g * cg;
+  float* yb = y + (long)b * hw * C + g * cg;
+  const long n = hw * cg;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) s += xb[(i / cg) * C + (i % cg)];
+  const float mean = sp_wg_sum(s, red) / (float)n;
+  float q = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const float d = xb[(i / cg) * C + (i % cg)] - mean;
+    q += d * d;
+  }
+  const float inv = 1.f / sqrtf(sp_wg_sum(q, red) / (float)n + eps);
+  if (threadIdx.x == 0) {
+    mean_out[b * groups + g] = mean;
+    invstd_out[b * groups + g] = inv;
+  }
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const int j = (int)(i % cg), c = g * cg + j;
+    const long o = (i / cg) * C + j;
+    yb[o] = (xb[o] - mean) * inv * gamma[c] + beta[c];
+  }
+}
+
+// dx = invstd (dxhat - mean_g(dxhat) - xhat mean_g(dxhat xhat)), dxhat = dy gamma[c];  per-sample partials dgamma_b[b][c] =
+// sum_hw dy xhat, dbeta_b[b][c] = sum_hw dy (the caller adds them over the batch with sisr_sum_partials).
+__global__ __launch_bounds__(256) void group_norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                             const float* __restrict__ invstd_in, float* __restrict__ dx,
+                                                             float* __restrict__ dgamma_b, float* __restrict__ dbeta_b, long hw,
+                                                             int C, int C_real, int cg) {
+  __shared__ float red[4];
+  const int g = blockIdx.x, b = blockIdx.y, groups = C_real / cg;
+  const long base = (long)b * hw * C + g * cg;
+  const float mean = mean_in[b * groups + g], inv = invstd_in[b * groups + g];
+  const long n = hw * cg;
+  float s1 = 0.f, s2 = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const int j = (int)(i % cg);
+    const long o = base + (i / cg) * C + j;
+    const float xh = (x[o] - mean) * inv, dh = dy[o] * gamma[g * cg + j];
+    s1 += dh;
+    s2 += dh * xh;
+  }
+  s1 = sp_wg_sum(s1, red) / (float)n;
+  s2 = sp_wg_sum(s2, red) / (float)n;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const int j = (int)(i % cg);
+    const long o = base + (i / cg) * C + j;
+    const float xh = (x[o] - mean) * inv, dh = dy[o] * gamma[g * cg + j];
+    dx[o] = inv * (dh - s1 - xh * s2);
+  }
+  for (int j = 0; j < cg; ++j) {  // per channel of the group: sums over this sample's pixels
+    float a = 0.f, c2 = 0.f;
+    for (long p = threadIdx.x; p < hw; p += 256) {
+      const long o = base + p * C + j;
+      const float d = dy[o];
+      a += d * ((x[o] - mean) * inv);
+      c2 += d;
+    }
+    a = sp_wg_sum(a, red);
+    c2 = sp_wg_sum(c2, red);
+    if (threadIdx.x == 0) {
+      dgamma_b[(long)b * C_real + g * cg + j] = a;
+      dbeta_b[(long)b * C_real + g * cg + j] = c2;
+    }
+  }
+}
+
+// channels >= C_real of y (dx): zero
+__global__ __launch_bounds__(256) void zero_pad_channels_kernel(float* __restrict__ y, long npix, int C, int C_real) {
+  const int w = C - C_real;
+  const long total = npix * w;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) y[(i / w) * C + C_real + (i % w)] = 0.f;
+}
+
+extern "C" int sisr_group_norm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* mean_out,
+                                   float* invstd_out, int B, long hw, int C, int C_real, int cg, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta || !mean_out || !invstd_out || B <= 0 || hw <= 0 || C <= 0 || C_real <= 0 || C_real > C || cg <= 0 ||
+      C_real % cg || B > 65535)
+    return SISR_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(group_norm_fwd_kernel, dim3(C_real / cg, B), dim3(256), 0, st, x, y, gamma, beta, mean_out, invstd_out, hw, C,
+                     C_real, cg, eps);
+  if (C_real < C)
+    hipLaunchKernelGGL(zero_pad_channels_kernel, dim3(sp_blocks((long)B * hw * (C - C_real))), dim3(256), 0, st, y, (long)B * hw, C, C_real);
+  return sisr_check_launch();
+}
+
+extern "C" int sisr_group_norm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* invstd,
+                                   float* dx, float* dgamma_b, float* dbeta_b, int B, long hw, int C, int C_real, int cg,
+                                   void* stream) {
+  if (!x || !dy || !gamma || !mean || !invstd || !dx || !dgamma_b || !dbeta_b || B <= 0 || hw <= 0 || C <= 0 || C_real <= 0 ||
+      C_real > C || cg <= 0 || C_real % cg || B > 65535)
+    return SISR_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(group_norm_bwd_kernel, dim3(C_real / cg, B), dim3(256), 0, st, x, dy, gamma, mean, invstd, dx, dgamma_b, dbeta_b,
+                     hw, C, C_real, cg);
+  if (C_real < C)
+    hipLaunchKernelGGL(zero_pad_channels_kernel, dim3(sp_blocks((long)B * hw * (C - C_real))), dim3(256), 0, st, dx, (long)B * hw, C, C_real);
+  return sisr_check_launch();
+}
+
+// Pixel norm: y = x / max(||x||_2 over the pixel's channels, 1e-12) (F.normalize).  The C / 4 lanes of a pixel are consecutive
+// lanes of one wave (C / 4 a power of two <= 64); padded channels are zero and stay zero.  backward != 0: x, dy -> dx =
+// (dy - y sum_c(dy y)) / max(||x||, eps)  (dy / eps where the norm is below eps).
+__global__ __launch_bounds__(256) void pixel_norm_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ dy, f32x4* __restrict__ out,
+                                                         int c4n, long total, int backward) {
+  for (long i0 = (long)blockIdx.x * 256; i0 < total; i0 += (long)gridDim.x * 256) {
+    const long i = i0 + threadIdx.x;
+    const bool on = i < total;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 v = on ? x[i] : z;
+    float n2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    for (int o = 1; o < c4n; o <<= 1) n2 += __shfl_xor(n2, o);
+    const float nrm = sqrtf(n2), den = fmaxf(nrm, 1e-12f);
+    if (!backward) {
+      if (on) out[i] = v / den;
+    } else {
+      const f32x4 g = on ? dy[i] : z;
+      const f32x4 yv = v / den;
+      float dot = (g[0] * yv[0] + g[1] * yv[1]) + (g[2] * yv[2] + g[3] * yv[3]);
+      for (int o = 1; o < c4n; o <<= 1) dot += __shfl_xor(dot, o);
+      if (on) out[i] = nrm > 1e-12f ? (g - yv * dot) / den : g / den;
+    }
+  }
+}
+
+extern "C" int sisr_pixel_norm(const float* x, const float* dy, float* out, long npix, int C, int backward, void* stream) {
+  if (!x || !out || (backward && !dy) || npix <= 0 || C <= 0 || (C & 3)) return SISR_ERR_ARG;
+  const int c4n = C >> 2;
+  if (!sp_pow2(c4n) || c4n > 64) return SISR_ERR_UNSUPPORTED;
+  if (!sisr_aligned16(x) || !sisr_aligned16(out) || !sisr_aligned16(dy)) return SISR_ERR_ALIGN;
+  const long total = npix * c4n;
+  unsigned blocks = sp_blocks(total);
+  hipLaunchKernelGGL(pixel_norm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(x),
+                     reinterpret_cast<const f32x4*>(dy), reinterpret_cast<f32x4*>(out), c4n, total, backward);
+  return sisr_check_launch();
+}
+
+// Activations with a parameter or a second branch.  mode 0: PReLU (slope a[c], c < C_real; padded channels pass zeros), mode 1:
+// SELU.  backward: dx, and for PReLU also dyx = dy * min(x, 0), whose per-channel sum is the slope's gradient.
+#define SP_SELU_ALPHA 1.6732632423543772848170429916717f
+#define SP_SELU_SCALE 1.0507009873554804934193349852946f
+__global__ __launch_bounds__(256) void act_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ dy, const float* __restrict__ a,
+                                                  f32x4* __restrict__ out, f32x4* __restrict__ dyx, int c4n, int C_real, long total,
+                                                  int mode, int backward) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c0 = (int)(i % c4n) * 4;
+    const f32x4 v = x[i];
+    f32x4 o, m = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 g = backward ? dy[i] : m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xv = v[e];
+      if (mode == 0) {
+        const float s = c0 + e < C_real ? a[c0 + e] : 0.f;
+        if (!backward) o[e] = xv > 0.f ? xv : s * xv;
+        else {
+          o[e] = xv > 0.f ? g[e] : s * g[e];
+          m[e] = xv > 0.f ? 0.f : g[e] * xv;
+        }
+      } else {
+        if (!backward) o[e] = SP_SELU_SCALE * (xv > 0.f ? xv : SP_SELU_ALPHA * (expf(xv) - 1.f));
+        else o[e] = g[e] * SP_SELU_SCALE * (xv > 0.f ? 1.f : SP_SELU_ALPHA * expf(xv));
+      }
+    }
+    out[i] = o;
+    if (backward && mode == 0) dyx[i] = m;
+  }
+}
+
+extern "C" int sisr_act(const float* x, const float* dy, const float* slope, float* out, float* dyx, long npix, int C, int C_real,
+                        int mode, int backward, void* stream) {
+  if (!x || !out || npix <= 0 || C <= 0 || (C & 3) || (mode != 0 && mode != 1) || (backward && !dy) || (mode == 0 && !slope) ||
+      (mode == 0 && backward && !dyx) || C_real <= 0 || C_real > C)
+    return SISR_ERR_ARG;
+  if (!sisr_aligned16(x) || !sisr_aligned16(out) || !sisr_aligned16(dy) || !sisr_aligned16(dyx)) return SISR_ERR_ALIGN;
+  const long total = npix * (C >> 2);
+  hipLaunchKernelGGL(act_kernel, dim3(sp_blocks(total)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(x),
+                     reinterpret_cast<const f32x4*>(dy), slope, reinterpret_cast<f32x4*>(out), reinterpret_cast<f32x4*>(dyx), C >> 2,
+                     C_real, total, mode, backward);
+  return sisr_check_launch();
+}
+
+// 'spar3d': y = identity + x * sigmoid(logits), one logit per element.  backward: dx = dy a, dlogits = dy x a (1 - a).
+__global__ __launch_bounds__(256) void spar3d_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ logits,
+                                                     const f32x4* __restrict__ idn_or_dy, f32x4* __restrict__ out0, f32x4* __restrict__ out1,
+                                                     long total, int backward) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const f32x4 v = x[i], l = logits[i];
+    f32x4 a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = 1.f / (1.f + expf(-l[e]));
+    if (!backward) {
+      f32x4 r = v * a;
+      if (idn_or_dy) r += idn_or_dy[i];
+      out0[i] = r;
+    } else {
+      const f32x4 g = idn_or_dy[i];
+      out0[i] = g * a;
+      out1[i] = g * v * a * (1.f - a);
+    }
+  }
+}
+
+extern "C" int sisr_spar3d(const float* x, const float* logits, const float* identity_or_dy, float* out0, float* out1, long n,
+                           int backward, void* stream) {
+  if (!x || !logits || !out0 || n <= 0 || (n & 3) || (backward && (!identity_or_dy || !out1))) return SISR_ERR_ARG;
+  if (!sisr_aligned16(x) || !sisr_aligned16(logits) || !sisr_aligned16(identity_or_dy) || !sisr_aligned16(out0) || !sisr_aligned16(out1))
+    return SISR_ERR_ALIGN;
+  hipLaunchKernelGGL(spar3d_kernel, dim3(sp_blocks(n >> 2)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(x),
+                     reinterpret_cast<const f32x4*>(logits), reinterpret_cast<const f32x4*>(identity_or_dy),
+                     reinterpret_cast<f32x4*>(out0), reinterpret_cast<f32x4*>(out1), n >> 2, backward);
+  return sisr_check_launch();
+}

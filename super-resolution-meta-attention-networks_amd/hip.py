@@ -143,6 +143,11 @@ _SIGS.update({  # SPARNet pieces (csrc/sparnet.hip)
     "sisr_wgrad_geo_job_bytes": (c_size_t, []),
     "sisr_wgrad3x3_c64_geo_batch_workspace_bytes": (c_size_t, [P, c_int]),
     "sisr_wgrad3x3_c64_geo_batch": (c_int, [P, c_int, P, c_size_t, P]),
+    "sisr_group_norm_fwd": (c_int, [P, P, P, P, P, P, c_int, c_long, c_int, c_int, c_int, c_float, P]),
+    "sisr_group_norm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_long, c_int, c_int, c_int, P]),
+    "sisr_pixel_norm": (c_int, [P, P, P, c_long, c_int, c_int, P]),
+    "sisr_act": (c_int, [P, P, P, P, P, c_long, c_int, c_int, c_int, c_int, P]),
+    "sisr_spar3d": (c_int, [P, P, P, P, P, c_long, c_int, P]),
     "sisr_pad_reflect_up": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_crop_stride": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "sisr_bn_act_fwd": (c_int, [P] * 8 + [c_long, c_int, c_int, c_int, c_float, c_float, c_float, P, c_size_t, P]),

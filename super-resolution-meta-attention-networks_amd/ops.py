@@ -2239,6 +2239,161 @@ def spar_combine(x, logits, identity=None):
     return _SparCombine.apply(x, logits, identity)
 
 
+# ---- SPARNet's non-default ConvLayer options (csrc/sparnet.hip, "non-default ConvLayer options")
+class _GroupNorm(Function):
+    """InstanceNorm2d(affine) (cg = 1) / GroupNorm(32, C) (cg = C / 32) on a channels-last map whose channels >= C_real are zero
+    padding (ref: SPARNet/blocks.py:21-24)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, cg, eps):
+        B, C, H, W = x.shape
+        Cr = gamma.shape[0]
+        if Cr > C or Cr % cg:
+            raise NotImplementedError(f"group statistics over groups of {cg} channels of {Cr}")
+        dev, L = x.device, hip.lib()
+        x = _cl(x)
+        y = torch.empty_like(x)
+        mean, inv = torch.empty(B * (Cr // cg), device=dev), torch.empty(B * (Cr // cg), device=dev)
+        g, b = gamma.contiguous(), beta.contiguous()
+        hip.check(L.sisr_group_norm_fwd(hip.ptr(x), hip.ptr(y), hip.ptr(g), hip.ptr(b), hip.ptr(mean), hip.ptr(inv), B, H * W, C, Cr,
+                                        cg, float(eps), hip.stream()), "sisr_group_norm_fwd")
+        ctx.save_for_backward(x, g, mean, inv)
+        ctx.geom = (B, C, H, W, Cr, cg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, inv = ctx.saved_tensors
+        B, C, H, W, Cr, cg = ctx.geom
+        dev, L = dy.device, hip.lib()
+        dy = _cl(dy)
+        dx = torch.empty_like(x)
+        dgb, dbb = torch.empty((B, Cr), device=dev), torch.empty((B, Cr), device=dev)
+        hip.check(L.sisr_group_norm_bwd(hip.ptr(x), hip.ptr(dy), hip.ptr(g), hip.ptr(mean), hip.ptr(inv), hip.ptr(dx), hip.ptr(dgb),
+                                        hip.ptr(dbb), B, H * W, C, Cr, cg, hip.stream()), "sisr_group_norm_bwd")
+        dg, db = torch.empty(Cr, device=dev), torch.empty(Cr, device=dev)
+        for part, out in ((dgb, dg), (dbb, db)):  # the samples' sums added in batch order
+            hip.check(L.sisr_sum_partials(hip.ptr(part), B, 1, Cr, 1.0, hip.ptr(out), hip.stream()), "sisr_sum_partials")
+        return dx, dg, db, None, None
+
+
+def group_norm(x, gamma, beta, cg, eps=1e-5):
+    return _GroupNorm.apply(x, gamma, beta, int(cg), float(eps))
+
+
+class _PixelNorm(Function):
+    """F.normalize(x, p = 2, dim = 1) on a channels-last map (ref: SPARNet/blocks.py:25-26)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        x = _cl(x)
+        y = torch.empty_like(x)
+        hip.check(hip.lib().sisr_pixel_norm(hip.ptr(x), None, hip.ptr(y), B * H * W, C, 0, hip.stream()), "sisr_pixel_norm")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dy = _cl(dy)
+        dx = torch.empty_like(x)
+        hip.check(hip.lib().sisr_pixel_norm(hip.ptr(x), hip.ptr(dy), hip.ptr(dx), B * H * W, C, 1, hip.stream()), "sisr_pixel_norm(bwd)")
+        return dx
+
+
+def pixel_norm(x):
+    return _PixelNorm.apply(x)
+
+
+class _Act(Function):
+    """PReLU(C) (mode 0, slope: the module's weight) / SELU (mode 1) on a channels-last map (ref: SPARNet/blocks.py:55-58)."""
+
+    @staticmethod
+    def forward(ctx, x, slope, mode):
+        B, C, H, W = x.shape
+        x = _cl(x)
+        y = torch.empty_like(x)
+        a = slope.contiguous() if slope is not None else None
+        if a is not None and a.shape[0] > C:
+            raise NotImplementedError("PReLU slope count above the map's channels")
+        if a is not None and a.shape[0] == 1 and C != 1:
+            a = a.expand(C).contiguous()  # nn.PReLU(1): one slope for every channel
+        hip.check(hip.lib().sisr_act(hip.ptr(x), None, hip.ptr(a), hip.ptr(y), None, B * H * W, C, a.shape[0] if a is not None else C,
+                                     mode, 0, hip.stream()), "sisr_act")
+        ctx.save_for_backward(x, a)
+        ctx.mode, ctx.n_slope = mode, (slope.shape[0] if slope is not None else 0)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dev, L = dy.device, hip.lib()
+        dy = _cl(dy)
+        dx = torch.empty_like(x)
+        dyx = torch.empty_like(x) if ctx.mode == 0 else None
+        hip.check(L.sisr_act(hip.ptr(x), hip.ptr(dy), hip.ptr(a), hip.ptr(dx), hip.ptr(dyx), B * H * W, C,
+                             a.shape[0] if a is not None else C, ctx.mode, 1, hip.stream()), "sisr_act(bwd)")
+        da = None
+        if ctx.mode == 0 and ctx.needs_input_grad[1]:
+            part, parts = _pixel_sums(dyx, None, B, H, W, C)  # [B][parts][C] ordered sums of dy * min(x, 0)
+            per = torch.empty(C, device=dev)
+            hip.check(L.sisr_sum_partials(hip.ptr(part), B * parts, 1, C, 1.0, hip.ptr(per), hip.stream()), "sisr_sum_partials")
+            da = per[:a.shape[0]] if ctx.n_slope != 1 else per[:a.shape[0]].sum().reshape(1)
+        return dx, da, None
+
+
+def prelu(x, slope):
+    return _Act.apply(x, slope, 0)
+
+
+def selu(x):
+    return _Act.apply(x, None, 1)
+
+
+_const_slopes = {}
+
+
+def leaky_relu(x, slope):
+    """LeakyReLU(slope) (0: ReLU) as the PReLU kernel with a constant slope vector -- the activation behind a norm other than
+    batch norm (behind batch norm it is part of the batch-norm kernel)."""
+    key = (x.device.index, x.shape[1], float(slope))
+    a = _const_slopes.get(key)
+    if a is None:
+        a = _const_slopes[key] = torch.full((x.shape[1],), float(slope), device=x.device)
+    return _Act.apply(x, a, 0)
+
+
+class _Spar3d(Function):
+    """identity + x * sigmoid(logits), one logit per element (ref: SPARNet/blocks.py:147-151 att_name 'spar3d', :241-243)."""
+
+    @staticmethod
+    def forward(ctx, x, logits, identity):
+        x, logits = _cl(x), _cl(logits)
+        idn = _cl(identity) if identity is not None else None
+        y = torch.empty_like(x)
+        hip.check(hip.lib().sisr_spar3d(hip.ptr(x), hip.ptr(logits), hip.ptr(idn), hip.ptr(y), None, x.numel(), 0, hip.stream()),
+                  "sisr_spar3d")
+        ctx.save_for_backward(x, logits)
+        ctx.has_idn = identity is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, logits = ctx.saved_tensors
+        dy = _cl(dy)
+        dx, dl = torch.empty_like(x), torch.empty_like(x)
+        hip.check(hip.lib().sisr_spar3d(hip.ptr(x), hip.ptr(logits), hip.ptr(dy), hip.ptr(dx), hip.ptr(dl), x.numel(), 1, hip.stream()),
+                  "sisr_spar3d(bwd)")
+        return dx, dl, (dy if ctx.has_idn else None)
+
+
+def spar_combine3d(x, logits, identity=None):
+    return _Spar3d.apply(x, logits, identity)
+
+
 class _ShuffleRGB(Function):
     """PixelShuffle(r) of the first C r^2 channels of a channels-last map into an NCHW (B, C, rH, rW) image."""
 

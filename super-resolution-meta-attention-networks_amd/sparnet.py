@@ -20,8 +20,11 @@ Every conv of the network is a reference ConvLayer: [nearest x2] -> ReflectionPa
 
 The nn.Module tree keeps the reference's names (encoder.1.conv1.conv2d.weight, res_layers.3.att_func.b2_plus_1.norm.norm
 .running_var, ...), shapes and construction order, so checkpoints interchange and the same seed gives the same initial
-weights.  Options covered: norm_type 'bn' | 'none', relu_type 'leakyrelu' | 'relu' | 'none', att_name 'spar' (one attention
-channel); map sizes must halve exactly through the hourglasses (powers of two times the bottleneck, as the reference's
+weights.  Options: norm_type 'bn' | 'in' | 'gn' | 'pixel' | 'none' ('layer' raises a TypeError, as it does in the reference, whose
+callers never pass the shape nn.LayerNorm needs), relu_type 'leakyrelu' | 'relu' | 'prelu' | 'selu' | 'none', att_name 'spar' |
+'spar3d'.  The reference's defaults (batch norm + LeakyReLU, one attention channel) run on the fused kernels; the other
+options are one plain HIP pass per norm / activation and direction (csrc/sparnet.hip, "non-default ConvLayer options";
+fixtures P5).  Map sizes must halve exactly through the hourglasses (powers of two times the bottleneck, as the reference's
 defaults are) -- the reference's fallback interpolation for odd sizes is not built.
 """
 import numpy as np
@@ -39,13 +42,22 @@ class NormLayer(nn.Module):
     def __init__(self, channels, normalize_shape=None, norm_type='bn'):
         super().__init__()
         norm_type = norm_type.lower()
+        self.kind, self.channels = norm_type, channels
         if norm_type == 'bn':
             self.norm = nn.BatchNorm2d(channels)
-        elif norm_type == 'none':
+        elif norm_type == 'in':
+            self.norm = nn.InstanceNorm2d(channels, affine=True)
+        elif norm_type == 'gn':
+            self.norm = nn.GroupNorm(32, channels, affine=True)  # (raises for channel counts that 32 does not divide, as the reference)
+        elif norm_type in ('pixel', 'none'):
             self.norm = None
+        elif norm_type == 'layer':
+            # ref blocks.py:27-28 builds nn.LayerNorm(normalize_shape), and every caller leaves normalize_shape at None: the
+            # reference itself raises a TypeError for this option
+            raise TypeError("norm_type 'layer': the reference's ConvLayer / ResidualBlock never pass normalize_shape, so "
+                            "nn.LayerNorm(None) fails there too")
         else:
-            raise NotImplementedError("SPARNet on the gfx950 kernels: norm_type 'bn' (the reference default) or 'none'; "
-                                      "got %r" % norm_type)
+            raise AssertionError('Norm type {} not support.'.format(norm_type))
 
 
 class ReluLayer(nn.Module):
@@ -54,23 +66,40 @@ class ReluLayer(nn.Module):
     def __init__(self, channels, relu_type='relu'):
         super().__init__()
         relu_type = relu_type.lower()
+        self.kind = relu_type
         if relu_type == 'relu':
             self.func, self.slope = nn.ReLU(True), 0.0
         elif relu_type == 'leakyrelu':
             self.func, self.slope = nn.LeakyReLU(0.2, inplace=True), 0.2
+        elif relu_type == 'prelu':
+            self.func, self.slope = nn.PReLU(channels), None
+        elif relu_type == 'selu':
+            self.func, self.slope = nn.SELU(True), None
         elif relu_type == 'none':
             self.func, self.slope = None, 1.0
         else:
-            raise NotImplementedError("SPARNet on the gfx950 kernels: relu_type 'leakyrelu' (the reference default), 'relu' "
-                                      "or 'none'; got %r" % relu_type)
+            raise AssertionError('Relu type {} not support.'.format(relu_type))
 
 
 def _norm_act(x, norm, relu):
-    if norm.norm is not None:
+    """norm then activation.  Batch norm with (Leaky)ReLU / no activation -- the reference's defaults -- is ONE kernel; every other
+    combination is the norm's op followed by the activation's."""
+    if norm.kind == 'bn' and relu.slope is not None:
         return ops.batch_norm_act(x, norm.norm, slope=relu.slope)
-    if relu.slope != 1.0:
-        raise NotImplementedError("an activation without batch norm in front of it is not built (the reference's "
-                                  "ConvLayers without a norm have no activation either)")
+    if norm.kind == 'bn':
+        x = ops.batch_norm_act(x, norm.norm, slope=1.0)
+    elif norm.kind == 'in':
+        x = ops.group_norm(x, norm.norm.weight, norm.norm.bias, 1, norm.norm.eps)
+    elif norm.kind == 'gn':
+        x = ops.group_norm(x, norm.norm.weight, norm.norm.bias, norm.channels // 32, norm.norm.eps)
+    elif norm.kind == 'pixel':
+        x = ops.pixel_norm(x)
+    if relu.kind == 'prelu':
+        return ops.prelu(x, relu.func.weight)
+    if relu.kind == 'selu':
+        return ops.selu(x)
+    if relu.kind in ('relu', 'leakyrelu'):
+        return ops.leaky_relu(x, relu.slope)
     return x
 
 
@@ -106,8 +135,8 @@ class HourGlassBlock(nn.Module):
         super().__init__()
         self.depth, self.c_in, self.c_mid, self.c_out = depth, c_in, c_mid, c_out
         self.kwargs = {'norm_type': norm_type, 'relu_type': relu_type}
-        if c_out != 1:
-            raise NotImplementedError("hourglass attention on the gfx950 kernels: one attention channel (att_name 'spar')")
+        if c_out not in (1, c_in):
+            raise NotImplementedError("hourglass attention: one attention channel ('spar') or one per feature ('spar3d')")
         if self.depth:
             self._generate_network(self.depth)
             self.out_block = nn.Sequential(ConvLayer(self.c_mid, self.c_out, norm_type='none', relu_type='none'), nn.Sigmoid())
@@ -136,7 +165,7 @@ class HourGlassBlock(nn.Module):
         if self.depth == 0:
             return x if identity is None else ops.add_residual(identity, x)
         logits = self.out_block[0](self._forward(self.depth, x))
-        out = ops.spar_combine(x, logits, identity)
+        out = ops.spar_combine(x, logits, identity) if self.c_out == 1 else ops.spar_combine3d(x, logits, identity)
         self.att_map = None  # (the reference keeps the map for visualisation; it lives in the kernel's saved state here)
         return out
 
@@ -157,8 +186,7 @@ class ResidualBlock(nn.Module):
         if att_name.lower() == 'spar':
             c_attn = 1
         elif att_name.lower() == 'spar3d':
-            raise NotImplementedError("att_name 'spar3d' (one attention map per channel) is not built; 'spar' is the "
-                                      "reference default")
+            c_attn = c_out
         else:
             raise Exception("Attention type {} not implemented".format(att_name))
         self.att_func = HourGlassBlock(self.hg_depth, c_out, c_attn, **kwargs)

@@ -11,6 +11,9 @@ P2  p2_sparnet_reduced           reduced SPARNet (32 -> 32 pixels, two down / up
                                  the input is the one of 400 seeded candidates that keeps every activated batch-norm output
                                  furthest from the LeakyReLU kink (kink_margin, recorded in the fixture's meta)
 P3  p3_qsparnet_reduced          the same for QSPARNet with 10 metadata values
+P5  p5_sparnet_*                 (--variants) reduced SPARNets (32 / 64 / 96 features) built with the non-default options:
+                                 instance norm + PReLU, group norm + SELU, pixel norm + ReLU, batch norm + PReLU + 'spar3d'
+                                 attention; contents as P2
 P4  p_sparnet.json               full default SPARNet: seed-8 state-dict SHA-256 + key list, eval()-mode output statistics
                                  and a centre crop for one 128 x 128 input; three handler.run_train steps (losses, gradient
                                  norms) of the default network on 2 x 3 x 128 x 128 batches
@@ -117,6 +120,57 @@ def make_net(name, q, candidates=range(91, 491)):
     print(f"{name:24s} {os.path.getsize(path) / 1e3:8.1f} KB out{tuple(out.shape)}")
 
 
+VARIANT = dict(min_ch=32, max_ch=96, in_size=32, out_size=32, min_feat_size=8, res_depth=1, bottleneck_size=16)  # 32 / 64 / 96 features
+VARIANTS = {  # P5: the non-default ConvLayer options (ref SPARNet/blocks.py:17-33, :50-64, :147-151), each in a reduced net
+    "p5_sparnet_in_prelu": dict(norm_type="in", relu_type="prelu"),
+    "p5_sparnet_gn_selu": dict(norm_type="gn", relu_type="selu"),
+    "p5_sparnet_pixel_relu": dict(norm_type="pixel", relu_type="relu"),
+    "p5_sparnet_bn_prelu_spar3d": dict(norm_type="bn", relu_type="prelu", att_name="spar3d"),
+}
+
+
+def make_variant(name, opts, candidates=range(91, 151)):
+    """As make_net, for a reduced SPARNet built with non-default options; the input is the one of 60 seeded candidates that
+    keeps every activation input furthest from the kink at zero (ReLU / PReLU / SELU all have one)."""
+    import copy
+    torch.manual_seed(8)
+    net = SA.SPARNet(**VARIANT, **opts)
+    sha = M.sd_digest({k: v for k, v in net.state_dict().items() if "running_" not in k and "num_batches" not in k})
+    net.train()
+    kinds = (torch.nn.ReLU, torch.nn.LeakyReLU, torch.nn.PReLU, torch.nn.SELU)
+
+    def margin(x):
+        n = copy.deepcopy(net).double().train()
+        lo = [float("inf")]
+
+        def hook(mod, inp):
+            lo[0] = min(lo[0], float(inp[0].abs().min()))
+        for m in n.modules():
+            if isinstance(m, kinds):
+                m.register_forward_pre_hook(hook)
+        with torch.no_grad():
+            n(x.double())
+        return lo[0]
+
+    best = max(candidates, key=lambda sd_: margin(M.rnd(2, 3, 32, 32, seed=sd_, scale=0.5, grad=False).abs()))
+    x = M.rnd(2, 3, 32, 32, seed=best, scale=0.5, grad=False).abs()
+    mg = margin(x)
+    out = net(x)
+    cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(93))
+    out.backward(cot)
+    blob = {"in0": M._np(x), "out": M._np(out), "cot": M._np(cot), "sd_sha256": np.array(sha),
+            "meta": np.array(json.dumps(dict(VARIANT, input_seed=best, kink_margin=mg, **opts)))}
+    grads_light(net, blob)
+    for k, v in bn_buffers(net).items():
+        blob["buf/" + k] = v
+    net.eval()
+    with torch.no_grad():
+        blob["out_eval"] = M._np(net(x))
+    path = os.path.join(M.OUT, name + ".npz")
+    np.savez_compressed(path, **blob)
+    print(f"{name:28s} {os.path.getsize(path) / 1e3:8.1f} KB out{tuple(out.shape)} input seed {best} margin {mg:.2e}")
+
+
 def make_full():
     torch.manual_seed(8)
     model = ModelInterface.define_model("sparnet", device=torch.device("cpu"), model_save_dir="/tmp", eval_mode=False,
@@ -165,6 +219,10 @@ def make_full_f64():
 if __name__ == "__main__":
     if "--f64" in sys.argv:
         make_full_f64()
+        sys.exit(0)
+    if "--variants" in sys.argv:
+        for name, opts in VARIANTS.items():
+            make_variant(name, opts)
         sys.exit(0)
     if "--nets-only" in sys.argv:
         make_net("p2_sparnet_reduced", False)

@@ -41,13 +41,13 @@ def run_oracle(dt):
     res = {}
     t = O._sp_conv_layer(sd, "encoder.0", xx); t.requires_grad_(True); t.retain_grad(); res["encoder.0"] = t
     for i in range(down):
-        t = O._sp_block(sd, f"encoder.{i+1}", t, "down", hg, 0.2, True, mm); t.retain_grad(); res[f"encoder.{i+1}"] = t; hg -= 1
+        t = O._sp_block(sd, f"encoder.{i+1}", t, "down", hg, "bn", "leakyrelu", True, mm); t.retain_grad(); res[f"encoder.{i+1}"] = t; hg -= 1
     hg += 1
     for i in range(cfg["res_depth"] + 3 - down):
-        t = O._sp_block(sd, f"res_layers.{i}", t, "none", hg, 0.2, True, mm); t.retain_grad(); res[f"res_layers.{i}"] = t
+        t = O._sp_block(sd, f"res_layers.{i}", t, "none", hg, "bn", "leakyrelu", True, mm); t.retain_grad(); res[f"res_layers.{i}"] = t
     for i in range(up):
         hg += 1
-        t = O._sp_block(sd, f"decoder.{i}", t, "up", hg, 0.2, True, mm); t.retain_grad(); res[f"decoder.{i}"] = t
+        t = O._sp_block(sd, f"decoder.{i}", t, "up", hg, "bn", "leakyrelu", True, mm); t.retain_grad(); res[f"decoder.{i}"] = t
     o = O._sp_conv_layer(sd, "out_conv", t)
     o.backward(torch.from_numpy(a["cot"]).to(dt))
     return res
