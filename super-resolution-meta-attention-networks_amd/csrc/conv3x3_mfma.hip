@@ -96,6 +96,8 @@ struct ConvParams {
   //                in place: stored pixel = virtual >> geo_up);  geo_off = 1 with geo_h = H - 2: the transposed ("full")
   //                form, an input-gradient map two pixels larger than the gradient it is computed from.
   int geo_reflect, geo_up, geo_off, geo_h, geo_w;
+  int geo_sub;  // with geo_up = 1 and zero padding: the virtual map is the stored one ZERO-STUFFED (value at even coordinates only:
+                // the gradient of a stride-2 conv seen at stride 1), not replicated
 #ifdef SISR_DIAG
   unsigned* stamp;  // diagnostic library only: per wave {start lo, start hi, staging, K loop, epilogue, HW_ID, XCC_ID, 0}
 #endif
@@ -458,17 +460,18 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
       const int Hv = GEO ? p.geo_h : H, Wv = GEO ? p.geo_w : W, goffs = GEO ? p.geo_off : 0;
       const bool refl = GEO && p.geo_reflect;
       const int gup = GEO ? p.geo_up : 0;
+      const bool sub = GEO && p.geo_sub;  // scalar
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         const int col = pcol + 16 * k;
         int gw = SS * w0 - 1 + col - goffs;
-        cok[k] = (refl || (gw >= 0 && gw < Wv)) && col < HWv;
+        cok[k] = (refl || (gw >= 0 && gw < Wv)) && col < HWv && !(sub && (gw & 1));
         if (refl) gw = gw < 0 ? -gw : (gw >= Wv ? 2 * Wv - 2 - gw : gw);
         goff[k] = (unsigned)((min(max(gw, 0), Wv - 1) >> gup) * (int)p.xv.sW + c4 * 4) * 4u;  // bytes
         loff[k] = col * 64 + ((c4 ^ (col & 15)) << 2);
       }
       // a tile whose halo lies inside the image needs no zero padding: its staging stores skip the masking (4 VALU per piece)
-      const bool interior = refl || (h0 - goffs >= 1 && h0 - goffs + THv + 1 <= Hv && w0 - goffs >= 1 && w0 - goffs + TW + 1 <= Wv);  // scalar
+      const bool interior = refl || (!sub && h0 - goffs >= 1 && h0 - goffs + THv + 1 <= Hv && w0 - goffs >= 1 && w0 - goffs + TW + 1 <= Wv);  // scalar
       auto row_bytes = [&](int gh) -> unsigned {  // scalar: byte offset of the stored row behind (shifted) halo row gh
         if (refl) gh = gh < 0 ? -gh : (gh >= Hv ? 2 * Hv - 2 - gh : gh);
         return (unsigned)((min(max(gh, 0), Hv - 1) >> gup) * (int)p.xv.sH) * 4u;
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256, KSEL == 3 ? 2 : (MT == 1 ? (GATE ? SISR_GATE_W
 #pragma unroll
           for (int r = 0; r < HHv; ++r) {
             const int gh = SS * h0 - 1 + r - goffs;
-            const bool rok = gh >= 0 && gh < Hv;  // scalar
+            const bool rok = gh >= 0 && gh < Hv && !(sub && (gh & 1));  // scalar
 #pragma unroll
             for (int k = 0; k < NK; ++k)
               if (k < NK - 1 || pcol < 2) {
@@ -2682,8 +2685,10 @@ extern "C" int sisr_conv3x3_c64_geo(const float* x, const int64_t* xview, const 
                                     int up, int kreal, void* stream) {
   if (!x || !wpacked || !y || !xview || !yview || B <= 0 || H <= 0 || W <= 0) return SISR_ERR_ARG;
   if ((cin & 63) || (cout & 63) || cin <= 0 || cout <= 0) return SISR_ERR_UNSUPPORTED;
-  if (mode != 1 && mode != 2 && mode != 3) return SISR_ERR_ARG;
+  if (mode < 1 || mode > 4) return SISR_ERR_ARG;
   if (up < 0 || up > 1 || (mode != 1 && up) || kreal < 0) return SISR_ERR_UNSUPPORTED;
+  const bool sub = mode == 4;  // mode 2 on the zero-stuffed gradient of a stride-2 conv: x is [B][(H - 1) / 2][(W - 1) / 2][cin]
+  if (sub) mode = 2;
   if (mode != 2 && (H < 2 || W < 2 || ((H | W) & ((1 << up) - 1)))) return SISR_ERR_ARG;  // ReflectionPad2d(1) needs 2 pixels
   if (mode == 2 && (H < 3 || W < 3)) return SISR_ERR_ARG;
   if (!sisr_aligned16(x) || !sisr_aligned16(wpacked) || !sisr_aligned16(y)) return SISR_ERR_ALIGN;
@@ -2707,7 +2712,8 @@ extern "C" int sisr_conv3x3_c64_geo(const float* x, const int64_t* xview, const 
   p.cin_chunks = cin / 64;
   p.cout_chunks = cout / 64;
   p.geo_reflect = mode != 2;
-  p.geo_up = up;
+  p.geo_up = sub ? 1 : up;
+  p.geo_sub = sub;
   p.geo_off = mode == 2;
   p.geo_h = mode == 2 ? H - 2 : H;
   p.geo_w = mode == 2 ? W - 2 : W;

@@ -51,6 +51,7 @@ struct WgradParams {
   // GEO kernels (SPARNet's ConvLayers): x is read through ReflectionPad2d(1) of the H x W map (geo_reflect: -1 -> 1, n -> n - 2
   // instead of zeros) which is stored subsampled by 2^geo_up (nearest upsampling read in place)
   int geo_reflect, geo_up;
+  int geo_ysub;  // GEO: dY is stored subsampled by 2 and read ZERO-STUFFED (the gradient of a stride-2 conv seen at stride 1)
   int units;  // GEO batch launches: this job's workgroup rows (grid rows >= units and columns >= S leave at once); 0 = gridDim.y
 };
 
@@ -104,7 +105,9 @@ static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
         return min(max(g, 0), n - 1) >> gup;
       };
       const unsigned gx = (unsigned)(xpix(w0 + pcol, W) * (int)p.xv.sW + c4 * 4), lx = (pcol + 1) * WSTR + c4 * 4;
-      const unsigned gy = (unsigned)(min(w0 + pcol, W - 1) * (int)p.yv.sW + c4 * 4), ly = pcol * WSTR + c4 * 4;
+      const int ysub = GEO ? p.geo_ysub : 0;  // scalar
+      const unsigned gy = (unsigned)((min(w0 + pcol, W - 1) >> ysub) * (int)p.yv.sW + c4 * 4), ly = pcol * WSTR + c4 * 4;
+      const bool oky = okc && !(ysub && ((w0 + pcol) & 1));
       f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};
       if (p.dy_scale) s4 = *reinterpret_cast<const f32x4*>(p.dy_scale + (long)b * Cout + cq * 64 + coh * 32 + c4 * 4);
       if (p.dy_shift) t4 = *reinterpret_cast<const f32x4*>(p.dy_shift + (long)b * Cout + cq * 64 + coh * 32 + c4 * 4);
@@ -112,7 +115,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
       // instruction here costs the co-resident workgroup's MFMA stream ~4.5 cycles): the zero-padding mask on tiles whose
       // halo lies inside the image, the affine rebuild when dY is taken as it is, the column sums where no bias gradient
       // is wanted from this quadrant
-      const bool interior = h0 >= 1 && h0 + WT_H + 1 <= H && w0 >= 1 && w0 + WT_W + 1 <= W;  // scalar
+      const bool interior = !ysub && h0 >= 1 && h0 + WT_H + 1 <= H && w0 >= 1 && w0 + WT_W + 1 <= W;  // scalar
       const bool affine = p.dy_scale != nullptr || p.dy_shift != nullptr;                     // scalar
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -122,7 +125,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
           v[r] = *reinterpret_cast<const f32x4*>(xb + (long)xpix(h0 - 1 + 5 * half + r, H) * p.xv.sH + gx);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          u[r] = *reinterpret_cast<const f32x4*>(yb + (long)min(h0 + 4 * half + r, H - 1) * p.yv.sH + gy);
+          u[r] = *reinterpret_cast<const f32x4*>(yb + (long)(min(h0 + 4 * half + r, H - 1) >> ysub) * p.yv.sH + gy);
         const int gwe = eside ? w0 + WT_W : w0 - 1;
         if (half == 0)
           e = *reinterpret_cast<const f32x4*>(xb + (long)xpix(h0 - 1 + er, H) * p.xv.sH + xpix(gwe, W) * (int)p.xv.sW + ec4 * 4);
@@ -139,7 +142,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_body(const WgradParams& p) {
             }
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) u[r] = sisr_keep_if(u[r], okc && (h0 + 4 * half + r < H));
+          for (int r = 0; r < 4; ++r) u[r] = sisr_keep_if(u[r], oky && (h0 + 4 * half + r < H) && !(ysub && ((h0 + r) & 1)));
         }
 #pragma unroll
         for (int r = 0; r < 5; ++r) *reinterpret_cast<f32x4*>(ldx + (5 * half + r) * (WH_W * WSTR) + lx) = v[r];
@@ -294,7 +297,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_full_body(const WgradParams&
     w0 = (tr - th * p.tiles_w) * WT_W;
   };
   const bool refl = GEO && p.geo_reflect;  // scalar
-  const int gup = GEO ? p.geo_up : 0;
+  const int gup = GEO ? p.geo_up : 0, ysub = GEO ? p.geo_ysub : 0;
   auto xpix = [&](int g, int n) {  // stored row / column behind virtual coordinate g of an n-pixel axis
     if (refl) g = g < 0 ? -g : (g >= n ? 2 * n - 2 - g : g);
     return min(max(g, 0), n - 1) >> gup;
@@ -305,7 +308,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_full_body(const WgradParams&
     const sisr_rsrc_t rx = sisr_rsrc(p.x + (long)b * p.xv.sB + p.xv.chunk(cc));
     const sisr_rsrc_t ry = sisr_rsrc(p.dy + (long)b * p.yv.sB + p.yv.chunk(cq));
     const unsigned vx = (unsigned)(xpix(w0 + pcol, W) * (int)p.xv.sW + c8 * 8) * 4u;
-    const unsigned vy = (unsigned)(min(w0 + pcol, W - 1) * (int)p.yv.sW + c8 * 8) * 4u;
+    const unsigned vy = (unsigned)((min(w0 + pcol, W - 1) >> ysub) * (int)p.yv.sW + c8 * 8) * 4u;
 #pragma unroll
     for (int r = 0; r < WH_H; ++r) {
       const unsigned so = (unsigned)(xpix(h0 - 1 + r, H) * (int)p.xv.sH) * 4u;  // scalar
@@ -320,7 +323,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_full_body(const WgradParams&
     }
 #pragma unroll
     for (int r = 0; r < WT_H; ++r) {
-      const unsigned so = (unsigned)(min(h0 + r, H - 1) * (int)p.yv.sH) * 4u;  // scalar
+      const unsigned so = (unsigned)((min(h0 + r, H - 1) >> ysub) * (int)p.yv.sH) * 4u;  // scalar
       st.y[r][0] = sisr_buf_load4(ry, vy, so);
       st.y[r][1] = sisr_buf_load4(ry, vy + 16u, so);
     }
@@ -328,8 +331,9 @@ static __device__ __forceinline__ void wgrad3x3_c64_full_body(const WgradParams&
   auto commit = [&](int tile) {
     int b, h0, w0;
     decode(tile, b, h0, w0);
-    const bool interior = h0 >= 1 && h0 + WT_H + 1 <= H && w0 >= 1 && w0 + WT_W + 1 <= W;  // scalar
+    const bool interior = !ysub && h0 >= 1 && h0 + WT_H + 1 <= H && w0 >= 1 && w0 + WT_W + 1 <= W;  // scalar
     const bool okc = w0 + pcol < W;
+    const bool oky = okc && !(ysub && ((w0 + pcol) & 1));
     float* lx = ldx + (pcol + 1) * 64 + c8 * 8;
     if (!interior && !refl) {  // (reflected reads are values of the map; what pairs with pixels outside it is zeroed with dY)
 #pragma unroll
@@ -375,7 +379,7 @@ static __device__ __forceinline__ void wgrad3x3_c64_full_body(const WgradParams&
     if (!interior) {
 #pragma unroll
       for (int r = 0; r < WT_H; ++r) {
-        const bool ok = okc && (h0 + r < H);
+        const bool ok = oky && (h0 + r < H) && !(ysub && ((h0 + r) & 1));
         st.y[r][0] = sisr_keep_if(st.y[r][0], ok);
         st.y[r][1] = sisr_keep_if(st.y[r][1], ok);
       }
@@ -1139,8 +1143,10 @@ extern "C" int sisr_wgrad3x3_c64(const float* x, const int64_t* xview, const flo
 extern "C" int sisr_wgrad3x3_c64_geo(const float* x, const int64_t* xview, const float* dy, const int64_t* dyview, float* dw,
                                      int co_real, int ci_real, float* dbias, float* workspace, size_t workspace_bytes, int B, int H,
                                      int W, int cin, int cout, int up, unsigned long long active_units, void* stream) {
-  if (co_real <= 0 || ci_real <= 0 || co_real > cout || ci_real > cin || up < 0 || up > 1 || H < 2 || W < 2 ||
-      ((H | W) & ((1 << up) - 1)))
+  // up: bit 0 = x stored at half size (nearest x2 read in place); bit 1 = dy stored at half size, ((H + 1) / 2, (W + 1) / 2), and
+  // read zero-stuffed (the stride-2 ConvLayer: dy of the strided conv seen on the stride-1 grid)
+  if (co_real <= 0 || ci_real <= 0 || co_real > cout || ci_real > cin || up < 0 || up > 2 || H < 2 || W < 2 ||
+      ((up & 1) && ((H | W) & 1)))
     return SISR_ERR_ARG;
   return wgrad_fp32_launch(x, xview, dy, dyview, nullptr, nullptr, 1.f, dw, (int64_t)ci_real * 9, 9, 0, 1, 64, 1, 64, dbias, 1, 64,
                            workspace, workspace_bytes, B, H, W, cin, cout, active_units, 1, up, co_real, ci_real, stream);
@@ -1175,7 +1181,8 @@ static int wgrad_fp32_launch(const float* x, const int64_t* xview, const float* 
   p.tiles_w = (W + WT_W - 1) / WT_W;
   p.tiles_h = (H + WT_H - 1) / WT_H;
   p.geo_reflect = geo;
-  p.geo_up = geo_up;
+  p.geo_up = geo_up & 1;
+  p.geo_ysub = (geo_up >> 1) & 1;
   // Units = (cin chunk, cout chunk, ci half, co half) blocks of the gradient, bit ((cc * cout_chunks + cq) * 4 + cih * 2 + coh)
   // of active_units (0 = all).  A caller whose weight is structurally sparse (SFTMD's merged convs) masks the blocks it
   // never reads: they are neither computed nor written, and the K-slices of the launch go to the rest.
@@ -1285,7 +1292,7 @@ static int wgrad_geo_batch_split(const sisr_wgrad_geo_job_host& j, int units, in
 }
 static bool wgrad_geo_job_ok(const sisr_wgrad_geo_job_host& j) {
   return j.x && j.dy && j.dw && j.B > 0 && j.H >= 2 && j.W >= 2 && j.cin > 0 && j.cout > 0 && !(j.cin & 63) && !(j.cout & 63) &&
-         (j.cin / 64) * (j.cout / 64) * 4 <= WG_MAX_UNITS && j.up >= 0 && j.up <= 1 && !((j.H | j.W) & ((1 << j.up) - 1)) &&
+         (j.cin / 64) * (j.cout / 64) * 4 <= WG_MAX_UNITS && j.up >= 0 && j.up <= 2 && !((j.up & 1) && ((j.H | j.W) & 1)) &&
          j.co_real > 0 && j.co_real <= j.cout && j.ci_real > 0 && j.ci_real <= j.cin;
 }
 extern "C" size_t sisr_wgrad3x3_c64_geo_batch_workspace_bytes(const void* jobs_host, int njobs) {
@@ -1325,11 +1332,12 @@ extern "C" int sisr_wgrad3x3_c64_geo_batch(const void* jobs_host, int njobs, flo
       if (!sisr_aligned16(j.x) || !sisr_aligned16(j.dy)) return SISR_ERR_ALIGN;
       WgradParams& p = wb.job[k];
       ReduceParams& r = rb.job[k];
-      const int Hs = j.H >> j.up, Ws = j.W >> j.up;
+      const int Hs = j.H >> (j.up & 1), Ws = j.W >> (j.up & 1);
+      const int Hy = (j.up & 2) ? (j.H + 1) / 2 : j.H, Wy = (j.up & 2) ? (j.W + 1) / 2 : j.W;
       p.x = j.x;
       p.xv.sB = (long)Hs * Ws * j.cin; p.xv.sH = (long)Ws * j.cin; p.xv.sW = j.cin; p.xv.chi = 0; p.xv.clo = 64; p.xv.cdiv = 1 << 30;
       p.dy = j.dy;
-      p.yv.sB = (long)j.H * j.W * j.cout; p.yv.sH = (long)j.W * j.cout; p.yv.sW = j.cout; p.yv.chi = 0; p.yv.clo = 64; p.yv.cdiv = 1 << 30;
+      p.yv.sB = (long)Hy * Wy * j.cout; p.yv.sH = (long)Wy * j.cout; p.yv.sW = j.cout; p.yv.chi = 0; p.yv.clo = 64; p.yv.cdiv = 1 << 30;
       p.B = j.B;
       p.H = j.H;
       p.W = j.W;
@@ -1338,7 +1346,8 @@ extern "C" int sisr_wgrad3x3_c64_geo_batch(const void* jobs_host, int njobs, flo
       p.tiles_w = (j.W + WT_W - 1) / WT_W;
       p.tiles_h = (j.H + WT_H - 1) / WT_H;
       p.geo_reflect = 1;
-      p.geo_up = j.up;
+      p.geo_up = j.up & 1;
+      p.geo_ysub = (j.up >> 1) & 1;
       const int all_units = p.cin_chunks * p.cout_chunks * 4;
       int units = all_units;
       if (j.active_units) {

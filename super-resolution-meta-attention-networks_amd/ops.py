@@ -2022,15 +2022,19 @@ class _ReflConv(Function):
         B, H, W, Cp, cop, Hp, Wp, up, stride = ctx.geom
         dev, L = dy.device, hip.lib()
         dy = _cl(dy)
-        if ctx.geo:
-            x, (Hv, Wv), (co, ci) = xp, (Hp, Wp), tuple(weight.shape[:2])
+        if ctx.geo or ctx.s2:
+            x, (co, ci) = xp, tuple(weight.shape[:2])
+            if ctx.geo:    # stride 1: saved geometry holds the conv's (= dy's) grid
+                Hv, Wv, Hd, Wd, tmode, wup = Hp, Wp, Hp, Wp, 2, up - 1
+            else:          # stride 2: the grid is the input's; dy has every second pixel of it and is read zero-stuffed
+                Hv, Wv, Hd, Wd, tmode, wup = H, W, (H + 1) // 2, (W + 1) // 2, 4, 2
             dx = dw = db = None
             if ctx.needs_input_grad[0]:
-                # gradient of the padded map: the transposed conv, two pixels larger than dy, straight from dy (no embedding
+                # gradient of the padded map: the transposed conv, two pixels larger than the grid, straight from dy (no embedding
                 # into a zero map); then the reflection / upsampling folded back
                 dxp = _empty_cl(B, Cp, Hv + 2, Wv + 2, dev)
-                hip.check(L.sisr_conv3x3_c64_geo(hip.ptr(dy), hip.view_plain(Hv, Wv, cop), _wptr(ctx.pd), None, hip.ptr(dxp),
-                                                 hip.view_plain(Hv + 2, Wv + 2, Cp), None, B, Hv + 2, Wv + 2, cop, Cp, 2, 0,
+                hip.check(L.sisr_conv3x3_c64_geo(hip.ptr(dy), hip.view_plain(Hd, Wd, cop), _wptr(ctx.pd), None, hip.ptr(dxp),
+                                                 hip.view_plain(Hv + 2, Wv + 2, Cp), None, B, Hv + 2, Wv + 2, cop, Cp, tmode, 0,
                                                  co if cop == 64 else 0, hip.stream()), "sisr_conv3x3_c64_geo(transposed)")
                 dx = _empty_cl(B, Cp, H, W, dev)
                 hip.check(L.sisr_pad_reflect_up(hip.ptr(dxp), hip.ptr(dx), B, H, W, Cp, up, 1, hip.stream()), "sisr_pad_reflect_up(adjoint)")
@@ -2061,15 +2065,15 @@ class _ReflConv(Function):
                         q = _DEFERRED.get(("geo", dev.index))
                         if q is None:
                             q = _DEFERRED[("geo", dev.index)] = WgradGeoQueue(dev)
-                        q.add(x, dy, dw, db, (B, Hv, Wv, Cp, cop, up - 1, co, ci), units, tiles)
+                        q.add(x, dy, dw, db, (B, Hv, Wv, Cp, cop, wup, co, ci), units, tiles)
                         return dx, dw, db, None, None
                 nbytes = L.sisr_wgrad3x3_c64_workspace_bytes(B, Hv, Wv, Cp, cop)
 
                 def wgrad():  # (the workspace is per stream: taken where the launch is issued)
                     ws = hip.workspace(dev, nbytes)
-                    hip.check(L.sisr_wgrad3x3_c64_geo(hip.ptr(x), hip.view_plain(H, W, Cp), hip.ptr(dy), hip.view_plain(Hv, Wv, cop),
+                    hip.check(L.sisr_wgrad3x3_c64_geo(hip.ptr(x), hip.view_plain(H, W, Cp), hip.ptr(dy), hip.view_plain(Hd, Wd, cop),
                                                       hip.ptr(dw), co, ci, hip.ptr(db), hip.ptr(ws), nbytes, B, Hv, Wv, Cp, cop,
-                                                      up - 1, units, hip.stream()), "sisr_wgrad3x3_c64_geo")
+                                                      wup, units, hip.stream()), "sisr_wgrad3x3_c64_geo")
 
                 # The maps of this network are far smaller than the chip (most launches: 16 - 80 workgroups on 256 CUs): the
                 # weight gradients, which nothing on the input-gradient chain waits for, fill the idle CUs from a second stream
@@ -2079,10 +2083,6 @@ class _ReflConv(Function):
                 else:
                     wgrad()
             return dx, dw, db, None, None
-        if ctx.s2:
-            x = xp
-            xp = _empty_cl(B, Cp, Hp, Wp, dev)
-            hip.check(L.sisr_pad_reflect_up(hip.ptr(x), hip.ptr(xp), B, H, W, Cp, up, 0, hip.stream()), "sisr_pad_reflect_up")
         dyf = _empty_cl(B, cop, Hp, Wp, dev)
         hip.check(L.sisr_crop_stride(hip.ptr(dy), hip.ptr(dyf), B, Hp, Wp, cop, stride, 1, hip.stream()), "sisr_crop_stride(embed)")
         dx = dw = db = None
